@@ -1,0 +1,130 @@
+/*
+ * include/seeq_amd.h -- batched, device-level C-ABI of seeq-mi355x.
+ *
+ * This is the boundary the HIP kernels sit behind.  Plain pointers and sizes
+ * only (no torch / C++ types).  What it replaces in the reference is the
+ * per-file hot loop: one `getline` + one `seeqStringMatch` per line
+ * (reference seeq.c:361-387 calling libseeq.c:171-352).  One `seeqdevScanRun`
+ * call performs that whole loop for every line of a text buffer that is
+ * already resident in HBM, and leaves counts + ordered hit records in HBM.
+ *
+ * The libseeq.h / seeq.h entry points (seeqStringMatch, seeqFileMatch) are
+ * implemented on top of these calls; bench.py and the Python module call
+ * them directly through ctypes with device pointers.
+ *
+ * Error convention (same as libseeq.h): functions return NULL / -1, set
+ * `seeqerr = 0` and `errno` (ENODEV: no usable GPU, ENOMEM: device or host
+ * allocation failed, EIO: a HIP call failed, EINVAL/E2BIG: bad arguments);
+ * seeqdevLastError() returns the HIP error text.
+ */
+#ifndef SEEQ_AMD_H_
+#define SEEQ_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "libseeq.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEEQ_AMD_VERSION "seeq-mi355x-0.1"
+
+/* Longest pattern (positions) the kernels are instantiated for. */
+#define SEEQDEV_MAX_WLEN 512
+
+/* What a scan must produce (`want`): mirrors the file options of reference
+ * seeq.h:64-68.  Counts are always produced; RECORDS adds hit records. */
+#define SEEQDEV_WANT_COUNTLINES 0   /* SQ_COUNTLINES: #lines with >=1 hit (seeq.c:349 forces FIRST)   */
+#define SEEQDEV_WANT_COUNTMATCH 1   /* SQ_COUNTMATCH: total hits under SQ_ALL (seeq.c:348)             */
+#define SEEQDEV_WANT_RECORDS    2   /* (line,start,end,dist) per hit under match_opt FIRST/BEST/ALL    */
+
+/* Extra scan flags, OR-ed into `options` above the libseeq.h option bits. */
+#define SEEQDEV_FASTA       0x100   /* lines starting with '>' are headers: skipped, not counted (seeq.c:367-374) */
+#define SEEQDEV_SINGLELINE  0x200   /* the buffer is ONE string (seeqStringMatch semantics, libseeq.c:171): no
+                                       newline index; with SQ_STREAM newlines are skipped (libseeq.c:265)  */
+
+/* One hit.  `line` is the 1-based index among counted lines of the scanned
+ * buffer (reference seeq.c:377); `end` is exclusive (libseeq.h:62-66).
+ * 16 bytes: the "algorithmic bytes per hit" of SURVEY section 8d. */
+typedef struct {
+   uint32_t line;
+   uint32_t start;
+   uint32_t end;
+   uint32_t dist;
+} seeqdev_hit_t;
+
+typedef struct {
+   uint64_t nlines;       /* counted lines (FASTA headers excluded)            */
+   uint64_t nmatchlines;  /* lines with at least one hit                       */
+   uint64_t nhits;        /* hits under the requested match mode               */
+   uint64_t nrecords;     /* records stored (== nhits for WANT_RECORDS else 0) */
+   uint64_t nheaders;     /* FASTA header lines skipped                        */
+} seeqdev_counts_t;
+
+typedef struct seeqdev_pattern seeqdev_pattern_t;   /* pattern tables in HBM */
+typedef struct seeqdev_scan    seeqdev_scan_t;      /* stream + workspace    */
+
+/* Number of usable HIP devices (0 if none / no runtime).  Never fails. */
+int seeqdevDeviceCount(void);
+/* Select the device used by subsequent calls of this thread (hipSetDevice). */
+int seeqdevSetDevice(int device);
+const char * seeqdevLastError(void);
+
+/* Upload the compiled pattern.  `keys` is the output of the pattern
+ * compiler (one byte per position, reference libseeq.c:517-543), wlen <=
+ * SEEQDEV_MAX_WLEN, 0 <= tau < wlen (reference libseeq.c:69-72,92-96). */
+seeqdev_pattern_t * seeqdevPatternNew(const char * keys, int wlen, int tau);
+void                seeqdevPatternFree(seeqdev_pattern_t * pat);
+/* The device pattern behind a seeq_t made by seeqNew() (sq->dfa). */
+seeqdev_pattern_t * seeqdevPatternOf(const seeq_t * sq);
+
+/* A scan context owns its workspace in HBM and runs on `hip_stream`
+ * (a hipStream_t passed as void*; NULL => a private stream). */
+seeqdev_scan_t * seeqdevScanNew(void * hip_stream);
+void             seeqdevScanFree(seeqdev_scan_t * scan);
+/* Pre-size the workspace so that seeqdevScanRun never allocates (so it can
+ * sit inside a timed region / graph).  Any argument may be 0 = keep. */
+int seeqdevScanReserve(seeqdev_scan_t * scan, size_t max_bytes, size_t max_lines, size_t max_hitlines,
+                       size_t max_records);
+
+/* Enqueue (asynchronously, on the context's stream) the whole hot path over
+ * d_text[0..nbytes): newline index -> per-line forward scan -> hit-line
+ * compaction -> exact pass (acceptance rules + reverse start recovery) ->
+ * ordered records.  `options` = libseeq.h match/non-DNA/input bits |
+ * SEEQDEV_* flags.  d_text must stay valid until seeqdevScanFetch returns. */
+int seeqdevScanRun(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const void * d_text, size_t nbytes,
+                   int options, int want);
+
+/* Wait for the scan and return its counts.  If the workspace was too small
+ * the scan is transparently re-run with a larger one (never happens after a
+ * sufficient seeqdevScanReserve). */
+int seeqdevScanFetch(seeqdev_scan_t * scan, seeqdev_counts_t * counts);
+
+/* Hit records of the last fetched scan: device pointer / copy to host. */
+const seeqdev_hit_t * seeqdevScanRecordsDevice(const seeqdev_scan_t * scan);
+int seeqdevScanCopyRecords(seeqdev_scan_t * scan, seeqdev_hit_t * host_out, size_t first, size_t n);
+
+/* Convenience: host buffer in, counts (+ records) out.  Stages through the
+ * context's pinned buffer, H2D, ScanRun, ScanFetch. */
+int seeqdevScanHost(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * host_text, size_t nbytes,
+                    int options, int want, seeqdev_counts_t * counts);
+
+/* Per-kernel device time (ms) of the last fetched scan, measured with HIP
+ * events on the scan's stream: [0] newline index, [1] forward scan
+ * (the dominant kernel), [2] compaction + exact pass + records, [3] total.
+ * Only filled when profiling was enabled with seeqdevScanSetProfiling(1). */
+int seeqdevScanSetProfiling(seeqdev_scan_t * scan, int on);
+int seeqdevScanLastTimes(const seeqdev_scan_t * scan, float ms[4]);
+
+/* Synthetic shape-R reads written straight into HBM (bench/test input; spec
+ * in SURVEY.md section 8d, CPU twin in oracle/seeq_oracle.c): n lines of
+ * `len` bases + '\n' for read indices [first, first+n). */
+int seeqdevSynthReads(void * d_out, uint64_t first, uint64_t n, int len, const char * pattern_plain, int plen,
+                      int tau, uint64_t seed, void * hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,972 @@
+/*
+ * seeq_device.hip -- HIP kernels and the device-level C-ABI (include/seeq_amd.h)
+ * of seeq-mi355x.  Written for gfx950 (MI355X, CDNA4): 64-wide wavefronts,
+ * one text line per lane, wave ballots for per-line flags, LDS for the Peq and
+ * class tables.  Integer/bitwise work only -- no MFMA.
+ *
+ * Pipeline of one seeqdevScanRun over a text buffer resident in HBM, per
+ * segment of < 4 GiB (all offsets inside a segment are u32):
+ *
+ *   K0  k_nl_count / k_nl_write      newline index -> line_start[]        (HBM stream)
+ *   K1  k_forward<W>                 one line per lane: Myers column per character,
+ *                                    acceptance rules; ballot -> hitmask[] (1 bit/line)
+ *   K2  scan of popc(hitmask)        ordered ranks of hit lines
+ *   K3  k_compact                    hitlines[]
+ *   K4  k_exact<W,COUNT>             (SQ_ALL / COUNTMATCH) hits per hit line, then scan
+ *   K5  k_exact<W,EMIT>              acceptance rules + reverse start recovery -> records[]
+ *
+ * replacing the reference's per-line loop seeq.c:361-387 -> libseeq.c:171-352.
+ * There is no host-side matcher: without a GPU every entry point fails.
+ */
+#include <hip/hip_runtime.h>
+
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "seeq_amd.h"
+#include "seeq_kernel_core.h"
+extern "C" {
+#include "seeq_pattern.h"
+}
+
+/* ========================================================================== */
+/* Error plumbing                                                             */
+/* ========================================================================== */
+static thread_local char g_last_error[256] = "";
+
+static int hip_fail(hipError_t e, const char *what, int err_no)
+{
+   snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString(e));
+   seeqerr = 0;
+   errno = err_no;
+   return -1;
+}
+
+#define HIP_TRY(call, err_no)                                        \
+   do {                                                              \
+      hipError_t e_ = (call);                                        \
+      if (e_ != hipSuccess) return hip_fail(e_, #call, (err_no));    \
+   } while (0)
+
+extern "C" const char *seeqdevLastError(void) { return g_last_error; }
+
+extern "C" int seeqdevDeviceCount(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+extern "C" int seeqdevSetDevice(int device)
+{
+   HIP_TRY(hipSetDevice(device), ENODEV);
+   return 0;
+}
+
+/* ========================================================================== */
+/* Device-side bookkeeping                                                    */
+/* ========================================================================== */
+struct Counters {
+   /* per segment */
+   uint32_t seg_nlines;     /* raw lines starting in the segment (FASTA headers included) */
+   uint32_t seg_nhitlines;
+   uint32_t seg_nheaders;
+   uint32_t seg_nrec;       /* hits (records) of the segment */
+   /* running totals over segments */
+   uint64_t lines;          /* counted lines (headers excluded) */
+   uint64_t matchlines;
+   uint64_t hits;
+   uint64_t records;
+   uint64_t headers;
+   /* workspace overflow report */
+   uint32_t overflow;       /* bit0 lines, bit1 hitlines, bit2 records */
+   uint32_t need_lines;     /* max over segments */
+   uint32_t need_hitlines;  /* max over segments */
+   uint32_t pad;
+   uint64_t need_records;   /* total */
+};
+
+struct ScanArgs {
+   const uint8_t *text;      /* whole buffer */
+   uint64_t       nbytes;
+   uint64_t       seg_base;  /* first byte of the segment */
+   uint32_t       seg_len;
+   uint32_t       first_seg; /* 1 for segment 0 */
+   const uint32_t *peq;      /* [2][5][W]: forward, reverse */
+   int            m, tau, options, want;
+   uint32_t      *line_start;   uint32_t cap_lines;
+   uint32_t      *tile_cnt;     uint32_t ntiles;
+   uint64_t      *hitmask;
+   uint64_t      *hdrmask;
+   uint32_t      *wave_off;
+   uint32_t      *hdr_off;
+   uint32_t      *hitlines;     uint32_t cap_hitlines;
+   uint32_t      *nh;           /* per hit line: hits, then exclusive offsets */
+   seeqdev_hit_t *records;      uint64_t cap_records;
+   Counters      *cnt;
+};
+
+static constexpr int WG = 256;           /* 4 waves */
+static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
+
+/* ========================================================================== */
+/* Block-level helpers                                                        */
+/* ========================================================================== */
+/* Exclusive prefix sum over the 256 threads of a block; *total = block sum. */
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *s_wave /* >= 4 */)
+{
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   uint32_t x = v;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      uint32_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+   }
+   if (lane == 63) s_wave[wave] = x;
+   __syncthreads();
+   uint32_t base = 0, tot = 0;
+#pragma unroll
+   for (int w = 0; w < WG / 64; w++) {
+      uint32_t s = s_wave[w];
+      if (w < wave) base += s;
+      tot += s;
+   }
+   __syncthreads();
+   *total = tot;
+   return base + x - v;
+}
+
+/* Exact per-byte "== '\n'" flags of 4 packed bytes (bit 7 of each byte). */
+__device__ __forceinline__ uint32_t nl_flags(uint32_t w)
+{
+   const uint32_t x = w ^ 0x0A0A0A0Au;
+   const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+   return ~t & 0x80808080u;
+}
+
+/* 64-bit mask of newline positions among the 64 bytes this thread owns
+ * (bytes seg_base + tile*TILE + tid*64 ...), restricted to positions q with
+ * q < seg_base+seg_len and q + 1 < nbytes (a final '\n' starts no line). */
+__device__ __forceinline__ uint64_t thread_nl_mask(const ScanArgs &a, uint32_t tile)
+{
+   const uint64_t seg_off = (uint64_t)tile * TILE + (uint64_t)threadIdx.x * 64;
+   if (seg_off >= a.seg_len) return 0;
+   const uint64_t q0 = a.seg_base + seg_off;
+   uint64_t limit = a.seg_base + a.seg_len;                /* exclusive */
+   if (a.nbytes - 1 < limit) limit = a.nbytes - 1;         /* q + 1 < nbytes  (nbytes > 0 here) */
+   uint64_t mask = 0;
+   if (q0 + 64 <= limit && ((uintptr_t)(a.text + q0) & 15) == 0) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(a.text + q0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+         const uint4 v = p[j];
+         const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
+         /* gather bit 7 of each byte into 4 consecutive bits */
+         const uint32_t b0 = ((f0 >> 7) * 0x00204081u >> 21) & 0xFu;
+         const uint32_t b1 = ((f1 >> 7) * 0x00204081u >> 21) & 0xFu;
+         const uint32_t b2 = ((f2 >> 7) * 0x00204081u >> 21) & 0xFu;
+         const uint32_t b3 = ((f3 >> 7) * 0x00204081u >> 21) & 0xFu;
+         const uint64_t m16 = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+         mask |= m16 << (16 * j);
+      }
+   } else {
+      for (int k = 0; k < 64; k++) {
+         const uint64_t q = q0 + k;
+         if (q < limit && a.text[q] == '\n') mask |= 1ull << k;
+      }
+   }
+   return mask;
+}
+
+/* ========================================================================== */
+/* K0: newline index                                                          */
+/* ========================================================================== */
+__global__ __launch_bounds__(WG) void k_nl_count(ScanArgs a)
+{
+   __shared__ uint32_t s_wave[4];
+   const uint64_t m = thread_nl_mask(a, blockIdx.x);
+   uint32_t tot;
+   block_excl_scan((uint32_t)__popcll(m), &tot, s_wave);
+   if (threadIdx.x == 0) a.tile_cnt[blockIdx.x] = tot;
+}
+
+/* After tile_cnt has been scanned in place (exclusive) and the total written
+ * to cnt->seg_nlines: add the line that starts at byte 0 of the buffer. */
+__global__ void k_index_finalize(ScanArgs a)
+{
+   Counters *c = a.cnt;
+   uint32_t n = c->seg_nlines;
+   if (a.first_seg && a.nbytes > 0) n += 1;
+   if (n > a.cap_lines) {
+      atomicOr(&c->overflow, 1u);
+      if (n > c->need_lines) c->need_lines = n;
+      n = 0;                       /* later kernels of this segment do nothing */
+   } else if (n > c->need_lines) {
+      c->need_lines = n;
+   }
+   c->seg_nlines = n;
+   if (n && a.first_seg) a.line_start[0] = 0;
+}
+
+__global__ __launch_bounds__(WG) void k_nl_write(ScanArgs a)
+{
+   __shared__ uint32_t s_wave[4];
+   if (a.cnt->seg_nlines == 0) return;
+   uint64_t m = thread_nl_mask(a, blockIdx.x);
+   uint32_t tot;
+   uint32_t rank = block_excl_scan((uint32_t)__popcll(m), &tot, s_wave);
+   rank += a.tile_cnt[blockIdx.x] + (a.first_seg ? 1u : 0u);
+   const uint32_t off0 = blockIdx.x * TILE + threadIdx.x * 64 + 1;   /* start = newline position + 1 */
+   while (m) {
+      const int b = __builtin_ctzll(m);
+      m &= m - 1;
+      a.line_start[rank++] = off0 + (uint32_t)b;
+   }
+}
+
+/* ========================================================================== */
+/* Generic two-level exclusive scan over u32 items with a device-side length   */
+/*   XF 0: in = u32[];  XF 1: in = u64[], item = popcount                     */
+/*   n = (*n_ptr + add) >> shift                                              */
+/* ========================================================================== */
+static constexpr int SCAN_ITEMS = 8;                     /* per thread */
+static constexpr int SCAN_BLOCK = WG * SCAN_ITEMS;       /* 2048 per block */
+
+template <int XF>
+__device__ __forceinline__ uint32_t scan_item(const void *in, uint32_t i)
+{
+   if (XF == 0) return reinterpret_cast<const uint32_t *>(in)[i];
+   return (uint32_t)__popcll(reinterpret_cast<const uint64_t *>(in)[i]);
+}
+
+template <int XF>
+__global__ __launch_bounds__(WG) void k_scan_reduce(const void *in, uint32_t *bsum, const uint32_t *n_ptr, uint32_t add,
+                                                    uint32_t shift)
+{
+   __shared__ uint32_t s_wave[4];
+   const uint32_t n = (*n_ptr + add) >> shift;
+   const uint32_t base = blockIdx.x * SCAN_BLOCK;
+   if (base >= n) return;
+   uint32_t v = 0;
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      if (i < n) v += scan_item<XF>(in, i);
+   }
+   uint32_t tot;
+   block_excl_scan(v, &tot, s_wave);
+   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+/* One block: exclusive scan of bsum[0..nb) in place, total -> *total_out. */
+__global__ __launch_bounds__(WG) void k_scan_top(uint32_t *bsum, const uint32_t *n_ptr, uint32_t add, uint32_t shift,
+                                                 uint32_t *total_out)
+{
+   __shared__ uint32_t s_wave[4];
+   const uint32_t n = (*n_ptr + add) >> shift;
+   const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+   uint32_t running = 0;
+   for (uint32_t b0 = 0; b0 < nb; b0 += WG) {
+      const uint32_t i = b0 + threadIdx.x;
+      const uint32_t v = i < nb ? bsum[i] : 0;
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan(v, &tot, s_wave);
+      if (i < nb) bsum[i] = running + ex;
+      running += tot;
+   }
+   if (threadIdx.x == 0) *total_out = running;
+}
+
+template <int XF>
+__global__ __launch_bounds__(WG) void k_scan_apply(const void *in, uint32_t *out, const uint32_t *bsum,
+                                                   const uint32_t *n_ptr, uint32_t add, uint32_t shift)
+{
+   __shared__ uint32_t s_wave[4];
+   const uint32_t n = (*n_ptr + add) >> shift;
+   const uint32_t base = blockIdx.x * SCAN_BLOCK;
+   if (base >= n) return;
+   uint32_t item[SCAN_ITEMS];
+   uint32_t v = 0;
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      item[k] = i < n ? scan_item<XF>(in, i) : 0;
+      v += item[k];
+   }
+   uint32_t tot;
+   uint32_t ex = block_excl_scan(v, &tot, s_wave) + bsum[blockIdx.x];
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      if (i < n) out[i] = ex;
+      ex += item[k];
+   }
+}
+
+/* ========================================================================== */
+/* K1: forward scan, one line per lane, 64 consecutive lines per wave          */
+/* ========================================================================== */
+template <int W>
+__device__ __forceinline__ void load_tables(const ScanArgs &a, uint32_t *s_peq, uint8_t *s_lut)
+{
+   for (int i = threadIdx.x; i < 10 * W; i += WG) {
+      /* a.peq holds [2][5][Wp] with Wp = words of the pattern; pad to W */
+      const int Wp = (a.m + 31) >> 5;
+      const int dir = i / (5 * W), rem = i % (5 * W), cls = rem / W, w = rem % W;
+      s_peq[i] = w < Wp ? a.peq[(dir * 5 + cls) * Wp + w] : 0u;
+   }
+   for (int b = threadIdx.x; b < 256; b += WG) s_lut[b] = sq_class_of((uint32_t)b, a.options);
+   __syncthreads();
+}
+
+template <int W>
+__global__ __launch_bounds__(WG) void k_forward(ScanArgs a)
+{
+   __shared__ uint32_t s_peq[10 * W];
+   __shared__ uint8_t s_lut[256];
+   load_tables<W>(a, s_peq, s_lut);
+   const uint32_t nlines = a.cnt->seg_nlines;
+   const int lane = threadIdx.x & 63;
+   const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6;
+   const uint32_t nwaves = (gridDim.x * WG) >> 6;
+   const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
+   const uint32_t nchunks = (nlines + 63) >> 6;
+   for (uint32_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+      const uint32_t idx = chunk * 64 + lane;
+      bool hit = false, hdr = false;
+      if (idx < nlines) {
+         const uint64_t off = a.seg_base + a.line_start[idx];
+         if (fasta && a.text[off] == '>') hdr = true;   /* off < nbytes: every line has >= 1 byte */
+         else
+            hit = sq_scan_line<W, SQ_MODE_ANY>(a.text, a.nbytes, off, (const uint32_t *)s_peq,
+                                               (const uint32_t *)(s_peq + 5 * W), (const uint8_t *)s_lut, a.m, a.tau,
+                                               a.options & 3, 0, nullptr, 0) != 0;
+      }
+      const uint64_t hm = __ballot(hit);
+      const uint64_t dm = __ballot(hdr);
+      if (lane == 0) {
+         a.hitmask[chunk] = hm;
+         if (fasta) a.hdrmask[chunk] = dm;
+      }
+   }
+}
+
+/* ========================================================================== */
+/* K3: ordered compaction of hit lines                                        */
+/* ========================================================================== */
+__global__ __launch_bounds__(WG) void k_compact(ScanArgs a)
+{
+   const uint32_t nlines = a.cnt->seg_nlines;
+   const uint32_t nchunks = (nlines + 63) >> 6;
+   const int lane = threadIdx.x & 63;
+   const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6;
+   const uint32_t nwaves = (gridDim.x * WG) >> 6;
+   for (uint32_t chunk = wave; chunk < nchunks; chunk += nwaves) {
+      const uint64_t hm = a.hitmask[chunk];
+      if ((hm >> lane) & 1) {
+         const uint32_t k = a.wave_off[chunk] + (uint32_t)__popcll(hm & ((1ull << lane) - 1));
+         if (k < a.cap_hitlines) a.hitlines[k] = chunk * 64 + lane;
+      }
+   }
+}
+
+/* After compaction: overflow check of the hit-line list; for FIRST/BEST the
+ * number of records of the segment is the number of hit lines. */
+__global__ void k_seg_mid(ScanArgs a)
+{
+   Counters *c = a.cnt;
+   uint32_t nhl = c->seg_nhitlines;
+   if (nhl > c->need_hitlines) c->need_hitlines = nhl;
+   if (nhl > a.cap_hitlines) {
+      atomicOr(&c->overflow, 2u);
+      nhl = 0;
+      c->seg_nhitlines = 0;      /* totals of this run are void anyway */
+   }
+   c->seg_nrec = nhl;            /* overwritten by the nh scan for SQ_ALL / COUNTMATCH */
+}
+
+/* Before the EMIT pass: do the records fit? */
+__global__ void k_rec_check(ScanArgs a)
+{
+   Counters *c = a.cnt;
+   c->need_records = c->records + c->seg_nrec;     /* running total incl. this segment */
+   if (c->records + c->seg_nrec > a.cap_records) atomicOr(&c->overflow, 4u);
+}
+
+/* ========================================================================== */
+/* K4/K5: exact pass over the hit lines                                       */
+/* ========================================================================== */
+__device__ __forceinline__ uint32_t counted_line_no(const ScanArgs &a, uint32_t idx, bool fasta)
+{
+   /* 1-based index among counted lines of the whole buffer (reference seeq.c:377) */
+   uint64_t n = a.cnt->lines + idx + 1;
+   if (fasta) {
+      const uint32_t chunk = idx >> 6;
+      n -= a.hdr_off[chunk] + (uint32_t)__popcll(a.hdrmask[chunk] & ((1ull << (idx & 63)) - 1));
+   }
+   return (uint32_t)n;
+}
+
+template <int W, int MODE>
+__global__ __launch_bounds__(WG) void k_exact(ScanArgs a)
+{
+   __shared__ uint32_t s_peq[10 * W];
+   __shared__ uint8_t s_lut[256];
+   load_tables<W>(a, s_peq, s_lut);
+   const Counters *c = a.cnt;
+   const uint32_t nhl = c->seg_nhitlines;
+   const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
+   const int match_opt = a.options & 3;
+   if (MODE == SQ_MODE_EMIT && (c->overflow & 4u)) return;
+   const uint32_t stride = gridDim.x * WG;
+   for (uint32_t k = blockIdx.x * WG + threadIdx.x; k < nhl; k += stride) {
+      const uint32_t idx = a.hitlines[k];
+      const uint64_t off = a.seg_base + a.line_start[idx];
+      if (MODE == SQ_MODE_COUNT) {
+         a.nh[k] = sq_scan_line<W, SQ_MODE_COUNT>(a.text, a.nbytes, off, (const uint32_t *)s_peq,
+                                                  (const uint32_t *)(s_peq + 5 * W), (const uint8_t *)s_lut, a.m,
+                                                  a.tau, match_opt, 0, nullptr, 0);
+      } else {
+         const uint32_t line_no = counted_line_no(a, idx, fasta);
+         uint64_t dst;
+         uint32_t cap;
+         if (match_opt == SQ_ALL) {
+            dst = c->records + a.nh[k];
+            cap = 0xFFFFFFFFu;       /* exact count known from the COUNT pass */
+         } else {
+            dst = c->records + k;
+            cap = 1;
+         }
+         sq_scan_line<W, SQ_MODE_EMIT>(a.text, a.nbytes, off, (const uint32_t *)s_peq,
+                                       (const uint32_t *)(s_peq + 5 * W), (const uint8_t *)s_lut, a.m, a.tau,
+                                       match_opt, line_no, reinterpret_cast<sq_hit_t *>(a.records + dst), cap);
+      }
+   }
+}
+
+/* End of segment: fold the segment into the running totals. */
+__global__ void k_seg_end(ScanArgs a, int hits_from_nh)
+{
+   Counters *c = a.cnt;
+   const uint32_t counted = c->seg_nlines - c->seg_nheaders;
+   const uint32_t seg_hits = hits_from_nh ? c->seg_nrec : c->seg_nhitlines;
+   c->lines += counted;
+   c->headers += c->seg_nheaders;
+   c->matchlines += c->seg_nhitlines;
+   c->hits += seg_hits;
+   if (a.want == SEEQDEV_WANT_RECORDS) c->records += seg_hits;
+   c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = 0;
+}
+
+/* SINGLELINE: the buffer is one string -> one line starting at 0. */
+__global__ void k_single_line(ScanArgs a)
+{
+   a.cnt->seg_nlines = 1;
+   if (a.cnt->need_lines < 1) a.cnt->need_lines = 1;
+   a.line_start[0] = 0;
+}
+
+/* ========================================================================== */
+/* Synthetic reads (bench / test input; CPU twin: oracle/seeq_oracle.c)        */
+/* ========================================================================== */
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+   x += 0x9E3779B97F4A7C15ull;
+   uint64_t z = x;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+   return z ^ (z >> 31);
+}
+
+struct SynthArgs {
+   uint8_t *out;
+   uint64_t first, n, seed;
+   int len, plen, tau;
+   char pattern[96];
+};
+
+__global__ __launch_bounds__(WG) void k_synth(SynthArgs s)
+{
+   const uint64_t k = (uint64_t)blockIdx.x * WG + threadIdx.x;
+   if (k >= s.n) return;
+   const uint64_t r = s.first + k;
+   uint8_t *line = s.out + k * (uint64_t)(s.len + 1);
+   const char B[4] = {'A', 'C', 'G', 'T'};
+   for (int p = 0; p < s.len; p++) line[p] = B[splitmix64(s.seed ^ (r * 256 + (uint64_t)p)) >> 62];
+   line[s.len] = '\n';
+   const uint64_t hr = splitmix64(s.seed ^ 0xA5A5A5A5DEADBEEFull ^ (r * 0x100000001B3ull));
+   if ((hr & 15) == 0 && s.plen > 0 && s.plen + s.tau + 2 <= 96 && s.plen + s.tau + 2 <= s.len) {
+      char t[96];
+      int cur = s.plen;
+      for (int i = 0; i < s.plen; i++) t[i] = s.pattern[i];
+      const int e = (int)((hr >> 4) % (uint64_t)(s.tau + 3));
+      for (int q = 0; q < e; q++) {
+         const uint64_t hk = splitmix64(hr + (uint64_t)q + 1);
+         const int type = (int)(hk % 3);
+         const int pos = (int)((hk >> 8) % (uint64_t)cur);
+         const char b = B[(hk >> 40) & 3];
+         if (type == 0) t[pos] = b;
+         else if (type == 1) {
+            for (int u = cur; u > pos; u--) t[u] = t[u - 1];
+            t[pos] = b;
+            cur++;
+         } else if (cur > 1) {
+            for (int u = pos; u < cur - 1; u++) t[u] = t[u + 1];
+            cur--;
+         }
+      }
+      const int off = (int)((hr >> 20) % (uint64_t)(s.len - cur + 1));
+      for (int i = 0; i < cur; i++) line[off + i] = (uint8_t)t[i];
+   }
+   const uint64_t hn = splitmix64(s.seed ^ 0x5BD1E9955BD1E995ull ^ (r * 0x9E3779B1ull));
+   if ((hn & 255) == 0) line[(hn >> 8) % (uint64_t)s.len] = 'N';
+}
+
+extern "C" int seeqdevSynthReads(void *d_out, uint64_t first, uint64_t n, int len, const char *pattern_plain, int plen,
+                                 int tau, uint64_t seed, void *hip_stream)
+{
+   if (!d_out || len <= 0 || plen < 0 || plen > 96) { seeqerr = 0; errno = EINVAL; return -1; }
+   if (n == 0) return 0;
+   SynthArgs s;
+   memset(&s, 0, sizeof s);
+   s.out = (uint8_t *)d_out; s.first = first; s.n = n; s.seed = seed; s.len = len; s.plen = plen; s.tau = tau;
+   memcpy(s.pattern, pattern_plain, (size_t)plen);
+   const uint64_t blocks = (n + WG - 1) / WG;
+   if (blocks > 0x7FFFFFFFull) { seeqerr = 0; errno = E2BIG; return -1; }
+   hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(WG), 0, (hipStream_t)hip_stream, s);
+   HIP_TRY(hipGetLastError(), EIO);
+   return 0;
+}
+
+/* ========================================================================== */
+/* Pattern handle                                                             */
+/* ========================================================================== */
+struct seeqdev_pattern {
+   int       wlen, tau, words;
+   int       device;
+   uint32_t *d_peq;          /* [2][5][words] */
+};
+
+extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int tau)
+{
+   seeqerr = 0;
+   if (!keys || wlen < 1 || tau < 0 || tau >= wlen) { errno = EINVAL; return NULL; }
+   if (wlen > SEEQDEV_MAX_WLEN) {
+      snprintf(g_last_error, sizeof g_last_error, "pattern longer than %d positions", SEEQDEV_MAX_WLEN);
+      errno = E2BIG;
+      return NULL;
+   }
+   if (seeqdevDeviceCount() < 1) {
+      snprintf(g_last_error, sizeof g_last_error, "no HIP device: seeq-mi355x has no CPU matcher");
+      errno = ENODEV;
+      return NULL;
+   }
+   seeqdev_pattern *p = (seeqdev_pattern *)calloc(1, sizeof *p);
+   if (!p) return NULL;
+   p->wlen = wlen; p->tau = tau; p->words = seeq_words_for(wlen);
+   const size_t nw = (size_t)10 * p->words;
+   uint32_t *h = (uint32_t *)malloc(nw * sizeof(uint32_t));
+   char *rkeys = (char *)malloc((size_t)wlen);
+   if (!h || !rkeys) { free(h); free(rkeys); free(p); errno = ENOMEM; return NULL; }
+   for (int i = 0; i < wlen; i++) rkeys[i] = keys[wlen - 1 - i];     /* reference libseeq.c:89 */
+   seeq_build_peq(keys, wlen, p->words, h);
+   seeq_build_peq(rkeys, wlen, p->words, h + 5 * p->words);
+   hipError_t e = hipGetDevice(&p->device);
+   if (e == hipSuccess) e = hipMalloc((void **)&p->d_peq, nw * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipMemcpy(p->d_peq, h, nw * sizeof(uint32_t), hipMemcpyHostToDevice);
+   free(h); free(rkeys);
+   if (e != hipSuccess) {
+      hip_fail(e, "seeqdevPatternNew", e == hipErrorOutOfMemory ? ENOMEM : EIO);
+      if (p->d_peq) (void)hipFree(p->d_peq);
+      free(p);
+      return NULL;
+   }
+   return p;
+}
+
+extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
+{
+   if (!p) return;
+   if (p->d_peq) (void)hipFree(p->d_peq);
+   free(p);
+}
+
+/* ========================================================================== */
+/* Scan context                                                               */
+/* ========================================================================== */
+struct seeqdev_scan {
+   hipStream_t stream;
+   bool        own_stream;
+   /* workspace (device) */
+   uint32_t *line_start;  size_t cap_lines;
+   uint32_t *tile_cnt;    size_t cap_tiles;
+   uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
+   uint32_t *hitlines, *nh;     size_t cap_hitlines;
+   seeqdev_hit_t *records;      size_t cap_records;
+   uint32_t *scan_ws;           size_t cap_scan_ws;
+   Counters *d_cnt;
+   Counters *h_cnt;            /* pinned */
+   /* staging for seeqdevScanHost */
+   uint8_t *d_text; size_t cap_text;
+   /* last run (for the transparent re-run on overflow) */
+   const seeqdev_pattern *pat; const void *text; size_t nbytes; int options, want;
+   bool ran;
+   seeqdev_counts_t counts;
+   /* profiling */
+   bool prof;
+   hipEvent_t ev[4];
+   float acc_ms[4];
+   size_t seg_bytes;           /* segment size */
+   bool user_reserved;         /* caller sized the per-line workspace: trust it */
+};
+
+static int ws_alloc(void **p, size_t bytes)
+{
+   if (*p) { (void)hipFree(*p); *p = NULL; }
+   hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+   if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)", ENOMEM);
+   return 0;
+}
+
+extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
+{
+   seeqerr = 0;
+   if (seeqdevDeviceCount() < 1) {
+      snprintf(g_last_error, sizeof g_last_error, "no HIP device: seeq-mi355x has no CPU matcher");
+      errno = ENODEV;
+      return NULL;
+   }
+   seeqdev_scan *s = (seeqdev_scan *)calloc(1, sizeof *s);
+   if (!s) return NULL;
+   s->seg_bytes = (size_t)1 << 31;          /* 2 GiB segments: u32 offsets, 16-byte aligned */
+   const char *env = getenv("SEEQ_SEGMENT_BYTES");
+   if (env && atoll(env) >= 65536) s->seg_bytes = ((size_t)atoll(env) + 15) & ~(size_t)15;
+   if (s->seg_bytes > 0xFFFF0000ull) s->seg_bytes = 0xFFFF0000ull;
+   hipError_t e = hipSuccess;
+   if (hip_stream) s->stream = (hipStream_t)hip_stream;
+   else { e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking); s->own_stream = true; }
+   if (e == hipSuccess) e = hipMalloc((void **)&s->d_cnt, sizeof(Counters));
+   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_cnt, sizeof(Counters), hipHostMallocDefault);
+   for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
+   if (e != hipSuccess) {
+      hip_fail(e, "seeqdevScanNew", EIO);
+      seeqdevScanFree(s);
+      return NULL;
+   }
+   return s;
+}
+
+extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
+{
+   if (!s) return;
+   (void)hipStreamSynchronize(s->stream);
+   void *bufs[] = {s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hitlines,
+                   s->nh, s->records, s->scan_ws, s->d_cnt, s->d_text};
+   for (void *b : bufs) if (b) (void)hipFree(b);
+   if (s->h_cnt) (void)hipHostFree(s->h_cnt);
+   for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+   free(s);
+}
+
+static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, size_t max_hitlines, size_t max_records)
+{
+   seeqerr = 0;
+   if (!s) { errno = EINVAL; return -1; }
+   /* Everything per-line is per SEGMENT; only records span the whole buffer. */
+   if (max_bytes) {
+      const size_t seg = max_bytes < s->seg_bytes ? max_bytes : s->seg_bytes;
+      const size_t tiles = (seg + TILE - 1) / TILE + 1;
+      if (tiles > s->cap_tiles) {
+         if (ws_alloc((void **)&s->tile_cnt, tiles * sizeof(uint32_t))) return -1;
+         s->cap_tiles = tiles;
+      }
+   }
+   if (max_lines > s->cap_lines) {
+      const size_t chunks = (max_lines + 63) / 64 + 1;
+      if (ws_alloc((void **)&s->line_start, (max_lines + 1) * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->hitmask, chunks * sizeof(uint64_t))) return -1;
+      if (ws_alloc((void **)&s->hdrmask, chunks * sizeof(uint64_t))) return -1;
+      if (ws_alloc((void **)&s->wave_off, chunks * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->hdr_off, chunks * sizeof(uint32_t))) return -1;
+      s->cap_lines = max_lines;
+      s->cap_chunks = chunks;
+   }
+   if (max_hitlines > s->cap_hitlines) {
+      if (ws_alloc((void **)&s->hitlines, max_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->nh, max_hitlines * sizeof(uint32_t))) return -1;
+      s->cap_hitlines = max_hitlines;
+   }
+   if (max_records > s->cap_records) {
+      if (ws_alloc((void **)&s->records, max_records * sizeof(seeqdev_hit_t))) return -1;
+      s->cap_records = max_records;
+   }
+   /* block sums for the two-level scans: the largest scanned array */
+   size_t largest = s->cap_tiles;
+   if (s->cap_chunks > largest) largest = s->cap_chunks;
+   if (s->cap_hitlines > largest) largest = s->cap_hitlines;
+   const size_t nb = largest / SCAN_BLOCK + 2;
+   if (nb > s->cap_scan_ws) {
+      if (ws_alloc((void **)&s->scan_ws, nb * sizeof(uint32_t))) return -1;
+      s->cap_scan_ws = nb;
+   }
+   return 0;
+}
+
+extern "C" int seeqdevScanReserve(seeqdev_scan_t *s, size_t max_bytes, size_t max_lines, size_t max_hitlines,
+                                  size_t max_records)
+{
+   if (reserve_impl(s, max_bytes, max_lines, max_hitlines, max_records)) return -1;
+   if (max_lines) s->user_reserved = true;
+   return 0;
+}
+
+extern "C" int seeqdevScanSetProfiling(seeqdev_scan_t *s, int on)
+{
+   if (!s) { errno = EINVAL; return -1; }
+   s->prof = on != 0;
+   return 0;
+}
+
+extern "C" int seeqdevScanLastTimes(const seeqdev_scan_t *s, float ms[4])
+{
+   if (!s || !ms) { errno = EINVAL; return -1; }
+   for (int i = 0; i < 4; i++) ms[i] = s->acc_ms[i];
+   return 0;
+}
+
+/* ---- launch helpers ------------------------------------------------------- */
+template <int XF>
+static void launch_scan(seeqdev_scan *s, const void *in, uint32_t *out, size_t cap_items, const uint32_t *n_ptr,
+                        uint32_t add, uint32_t shift, uint32_t *total_out)
+{
+   const unsigned nb = (unsigned)((cap_items + SCAN_BLOCK - 1) / SCAN_BLOCK);
+   if (nb == 0) return;
+   hipLaunchKernelGGL(k_scan_reduce<XF>, dim3(nb), dim3(WG), 0, s->stream, in, s->scan_ws, n_ptr, add, shift);
+   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WG), 0, s->stream, s->scan_ws, n_ptr, add, shift, total_out);
+   hipLaunchKernelGGL(k_scan_apply<XF>, dim3(nb), dim3(WG), 0, s->stream, in, out, (const uint32_t *)s->scan_ws,
+                      n_ptr, add, shift);
+}
+
+/* The tile_cnt scan has a host-known length (ntiles); a dedicated small kernel
+ * avoids routing a host constant through device memory. */
+__global__ __launch_bounds__(WG) void k_scan_tiles(uint32_t *tile_cnt, uint32_t ntiles, uint32_t *total_out)
+{
+   __shared__ uint32_t s_wave[4];
+   uint32_t running = 0;
+   for (uint32_t b0 = 0; b0 < ntiles; b0 += WG * SCAN_ITEMS) {
+      uint32_t item[SCAN_ITEMS];
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; k++) {
+         const uint32_t i = b0 + threadIdx.x * SCAN_ITEMS + k;
+         item[k] = i < ntiles ? tile_cnt[i] : 0;
+         v += item[k];
+      }
+      uint32_t tot;
+      uint32_t ex = running + block_excl_scan(v, &tot, s_wave);
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; k++) {
+         const uint32_t i = b0 + threadIdx.x * SCAN_ITEMS + k;
+         if (i < ntiles) tile_cnt[i] = ex;
+         ex += item[k];
+      }
+      running += tot;
+   }
+   if (threadIdx.x == 0) *total_out = running;
+}
+
+template <int W>
+static int run_segments(seeqdev_scan *s)
+{
+   const seeqdev_pattern *pat = s->pat;
+   const int options = s->options, want = s->want;
+   const bool fasta = (options & SEEQDEV_FASTA) != 0;
+   const bool single = (options & SEEQDEV_SINGLELINE) != 0;
+   const int match_opt = options & 3;
+   const bool need_nh = want == SEEQDEV_WANT_COUNTMATCH || (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   const size_t nbytes = s->nbytes;
+   Counters *c = s->d_cnt;
+
+   HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), s->stream), EIO);
+   for (int i = 0; i < 4; i++) s->acc_ms[i] = 0.f;
+
+   int ncu = 256;
+   {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+         ncu = prop.multiProcessorCount;
+   }
+
+   const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
+   if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
+   const size_t nseg = nbytes ? (nbytes + seg_bytes - 1) / seg_bytes : 0;
+   for (size_t sg = 0; sg < nseg; sg++) {
+      ScanArgs a;
+      memset(&a, 0, sizeof a);
+      a.text = (const uint8_t *)s->text;
+      a.nbytes = nbytes;
+      a.seg_base = (uint64_t)sg * seg_bytes;
+      a.seg_len = (uint32_t)((nbytes - a.seg_base) < seg_bytes ? (nbytes - a.seg_base) : seg_bytes);
+      a.first_seg = sg == 0;
+      a.peq = pat->d_peq;
+      a.m = pat->wlen; a.tau = pat->tau; a.options = options; a.want = want;
+      a.line_start = s->line_start; a.cap_lines = (uint32_t)s->cap_lines;
+      a.tile_cnt = s->tile_cnt; a.ntiles = (a.seg_len + TILE - 1) / TILE;
+      a.hitmask = s->hitmask; a.hdrmask = s->hdrmask; a.wave_off = s->wave_off; a.hdr_off = s->hdr_off;
+      a.hitlines = s->hitlines; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
+      a.records = s->records; a.cap_records = s->cap_records;
+      a.cnt = c;
+
+      /* ---- K0: newline index ---- */
+      if (s->prof) HIP_TRY(hipEventRecord(s->ev[0], s->stream), EIO);
+      if (single) {
+         hipLaunchKernelGGL(k_single_line, dim3(1), dim3(1), 0, s->stream, a);
+      } else {
+         hipLaunchKernelGGL(k_nl_count, dim3(a.ntiles), dim3(WG), 0, s->stream, a);
+         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, s->stream, a.tile_cnt, a.ntiles, &c->seg_nlines);
+         hipLaunchKernelGGL(k_index_finalize, dim3(1), dim3(1), 0, s->stream, a);
+         hipLaunchKernelGGL(k_nl_write, dim3(a.ntiles), dim3(WG), 0, s->stream, a);
+      }
+      /* ---- K1: forward scan ---- */
+      if (s->prof) HIP_TRY(hipEventRecord(s->ev[1], s->stream), EIO);
+      const size_t line_blocks = (s->cap_lines + WG - 1) / WG;
+      unsigned grid_lines = (unsigned)(line_blocks < (size_t)ncu * 16 ? line_blocks : (size_t)ncu * 16);
+      if (grid_lines == 0) grid_lines = 1;
+      hipLaunchKernelGGL(k_forward<W>, dim3(grid_lines), dim3(WG), 0, s->stream, a);
+      if (s->prof) HIP_TRY(hipEventRecord(s->ev[2], s->stream), EIO);
+      /* ---- K2: ranks of hit lines (and FASTA headers) ---- */
+      launch_scan<1>(s, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
+      if (fasta) launch_scan<1>(s, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
+      if (want != SEEQDEV_WANT_COUNTLINES) {
+         /* ---- K3: compaction ---- */
+         hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, s->stream, a);
+         hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, s->stream, a);
+         const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
+         unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
+         if (grid_hits == 0) grid_hits = 1;
+         /* ---- K4: hits per hit line ---- */
+         if (need_nh) {
+            hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
+         }
+         /* ---- K5: records ---- */
+         if (want == SEEQDEV_WANT_RECORDS) {
+            hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, s->stream, a);
+            hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+         }
+      }
+      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, need_nh ? 1 : 0);
+      if (s->prof) {
+         HIP_TRY(hipEventRecord(s->ev[3], s->stream), EIO);
+         HIP_TRY(hipEventSynchronize(s->ev[3]), EIO);
+         float t01 = 0, t12 = 0, t23 = 0;
+         (void)hipEventElapsedTime(&t01, s->ev[0], s->ev[1]);
+         (void)hipEventElapsedTime(&t12, s->ev[1], s->ev[2]);
+         (void)hipEventElapsedTime(&t23, s->ev[2], s->ev[3]);
+         s->acc_ms[0] += t01; s->acc_ms[1] += t12; s->acc_ms[2] += t23; s->acc_ms[3] += t01 + t12 + t23;
+      }
+      HIP_TRY(hipGetLastError(), EIO);
+   }
+   HIP_TRY(hipMemcpyAsync(s->h_cnt, c, sizeof(Counters), hipMemcpyDeviceToHost, s->stream), EIO);
+   return 0;
+}
+
+static int dispatch_run(seeqdev_scan *s)
+{
+   const int W = s->pat->words;
+   if (W <= 1) return run_segments<1>(s);
+   if (W <= 2) return run_segments<2>(s);
+   if (W <= 4) return run_segments<4>(s);
+   if (W <= 8) return run_segments<8>(s);
+   return run_segments<16>(s);
+}
+
+extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const void *d_text, size_t nbytes,
+                              int options, int want)
+{
+   seeqerr = 0;
+   if (!s || !pat || (!d_text && nbytes) || want < 0 || want > 2) { errno = EINVAL; return -1; }
+   s->pat = pat; s->text = d_text; s->nbytes = nbytes; s->options = options; s->want = want;
+   s->ran = false;
+   /* Optimistic default workspace: lines average >= 32 bytes, one line in 8 hits, 1 record per hit line.
+      A too-small workspace is detected on the device and fixed by one re-run in seeqdevScanFetch. */
+   const size_t seg = nbytes < s->seg_bytes ? nbytes : s->seg_bytes;
+   size_t want_lines = s->cap_lines, want_hl = s->cap_hitlines, want_rec = s->cap_records;
+   if (!s->user_reserved) {
+      const size_t guess = (options & SEEQDEV_SINGLELINE) ? 1 : seg / 32 + 1024;
+      if (guess > want_lines) want_lines = guess;
+      if (want_lines / 8 + 1024 > want_hl) want_hl = want_lines / 8 + 1024;
+      if (want_hl > want_rec) want_rec = want_hl;
+   }
+   if (reserve_impl(s, nbytes ? nbytes : 1, want_lines, want_hl, want_rec)) return -1;
+   if (dispatch_run(s)) return -1;
+   s->ran = true;
+   return 0;
+}
+
+extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
+{
+   seeqerr = 0;
+   if (!s || !s->ran) { errno = EINVAL; return -1; }
+   for (int attempt = 0; attempt < 3; attempt++) {
+      HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+      const Counters h = *s->h_cnt;
+      if (!h.overflow) {
+         s->counts.nlines = h.lines;
+         s->counts.nmatchlines = h.matchlines;
+         s->counts.nhits = h.hits;
+         s->counts.nrecords = h.records;
+         s->counts.nheaders = h.headers;
+         if (counts) *counts = s->counts;
+         return 0;
+      }
+      /* Grow to what the device reported (plus slack for the parts it could not see) and re-run. */
+      size_t nl = s->cap_lines, nhl = s->cap_hitlines, nrec = s->cap_records;
+      if (h.overflow & 1u) nl = (size_t)h.need_lines + (h.need_lines >> 3) + 64;
+      if (h.overflow & 2u) nhl = (size_t)h.need_hitlines + (h.need_hitlines >> 3) + 64;
+      if (h.overflow & 4u) {
+         /* need_records keeps counting after the overflow, so it is the total of this run. */
+         nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;
+      }
+      if ((h.overflow & 1u) && nhl < nl / 8) nhl = nl / 8 + 64;
+      if (reserve_impl(s, s->nbytes, nl, nhl, nrec)) return -1;
+      if (dispatch_run(s)) return -1;
+   }
+   snprintf(g_last_error, sizeof g_last_error, "workspace did not converge");
+   errno = ENOMEM;
+   return -1;
+}
+
+extern "C" const seeqdev_hit_t *seeqdevScanRecordsDevice(const seeqdev_scan_t *s) { return s ? s->records : NULL; }
+
+extern "C" int seeqdevScanCopyRecords(seeqdev_scan_t *s, seeqdev_hit_t *host_out, size_t first, size_t n)
+{
+   seeqerr = 0;
+   if (!s || (!host_out && n)) { errno = EINVAL; return -1; }
+   if (first + n > s->counts.nrecords) { errno = EINVAL; return -1; }
+   if (n == 0) return 0;
+   HIP_TRY(hipMemcpyAsync(host_out, s->records + first, n * sizeof(seeqdev_hit_t), hipMemcpyDeviceToHost, s->stream),
+           EIO);
+   HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+   return 0;
+}
+
+extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const char *host_text, size_t nbytes,
+                               int options, int want, seeqdev_counts_t *counts)
+{
+   seeqerr = 0;
+   if (!s || !pat || (!host_text && nbytes)) { errno = EINVAL; return -1; }
+   if (nbytes > s->cap_text) {
+      const size_t cap = nbytes + (nbytes >> 2) + 4096;
+      if (ws_alloc((void **)&s->d_text, cap)) return -1;
+      s->cap_text = cap;
+   }
+   if (nbytes) HIP_TRY(hipMemcpyAsync(s->d_text, host_text, nbytes, hipMemcpyHostToDevice, s->stream), EIO);
+   if (seeqdevScanRun(s, pat, s->d_text, nbytes, options, want)) return -1;
+   return seeqdevScanFetch(s, counts);
+}

@@ -1,0 +1,141 @@
+"""Batched device-level scans (include/seeq_amd.h) for Python callers.
+
+`Pattern` is a compiled pattern living in HBM; `Scanner` owns a HIP stream +
+workspace and runs the whole per-file hot path over a text buffer that is
+already in HBM (a torch uint8 CUDA tensor, or any device pointer).
+torch is used only for memory and streams; all compute is in libseeq_amd.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (SQ_ALL, SQ_BEST, SQ_CONVERT, SQ_FAIL, SQ_FIRST, SQ_IGNORE, SEEQDEV_FASTA,  # noqa: F401
+                    WANT_COUNTLINES, WANT_COUNTMATCH, WANT_RECORDS)
+
+
+class SeeqDeviceError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise SeeqDeviceError(_capi.error_text())
+
+
+def device_count():
+    return _capi.lib().seeqdevDeviceCount()
+
+
+def plain_pattern(pattern):
+    """One concrete base per pattern position (first member of a class, 'A' for N):
+    the string the synthetic-read generator plants."""
+    out, i = [], 0
+    while i < len(pattern):
+        c = pattern[i]
+        if c == '[':
+            j = pattern.index(']', i)
+            if j > i + 1:
+                out.append(pattern[i + 1].upper().replace('U', 'T').replace('N', 'A'))
+            i = j + 1
+        else:
+            out.append('A' if c in 'Nn' else c.upper().replace('U', 'T'))
+            i += 1
+    return ''.join(out)
+
+
+class Pattern:
+    def __init__(self, pattern, tau):
+        self._lib = _capi.lib()
+        self.pattern, self.tau = pattern, tau
+        self._sq = self._lib.seeqNew(pattern.encode(), int(tau), 0)
+        if not self._sq:
+            raise SeeqDeviceError("seeqNew(%r, %d): %s" % (pattern, tau, _capi.error_text()))
+        self.wlen = self._sq.contents.wlen
+        self.handle = self._lib.seeqdevPatternOf(self._sq)
+
+    def close(self):
+        sq, self._sq = self._sq, None
+        if sq:
+            self._lib.seeqFree(sq)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scanner:
+    def __init__(self, stream=None):
+        """stream: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        self._lib = _capi.lib()
+        self._h = self._lib.seeqdevScanNew(C.c_void_p(stream) if stream else None)
+        if not self._h:
+            raise SeeqDeviceError("seeqdevScanNew: " + _capi.error_text())
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            self._lib.seeqdevScanFree(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, max_bytes=0, max_lines=0, max_hitlines=0, max_records=0):
+        _check(self._lib.seeqdevScanReserve(self._h, max_bytes, max_lines, max_hitlines, max_records))
+
+    def set_profiling(self, on=True):
+        _check(self._lib.seeqdevScanSetProfiling(self._h, 1 if on else 0))
+
+    def last_times_ms(self):
+        ms = (C.c_float * 4)()
+        _check(self._lib.seeqdevScanLastTimes(self._h, ms))
+        return dict(index=ms[0], forward=ms[1], exact=ms[2], total=ms[3])
+
+    def run(self, pattern, d_ptr, nbytes, options=0, want=WANT_COUNTLINES):
+        """Enqueue the scan (asynchronous)."""
+        _check(self._lib.seeqdevScanRun(self._h, pattern.handle, C.c_void_p(d_ptr), nbytes, options, want))
+
+    def fetch(self):
+        cnt = _capi.seeqdev_counts_t()
+        _check(self._lib.seeqdevScanFetch(self._h, C.byref(cnt)))
+        return dict(nlines=cnt.nlines, nmatchlines=cnt.nmatchlines, nhits=cnt.nhits, nrecords=cnt.nrecords,
+                    nheaders=cnt.nheaders)
+
+    def records(self, n=None, first=0):
+        """Copy hit records to the host -> ndarray [n,4] u32 (line,start,end,dist)."""
+        if n is None:
+            raise ValueError("n required")
+        out = np.zeros((n, 4), dtype=np.uint32)
+        if n:
+            _check(self._lib.seeqdevScanCopyRecords(self._h, out.ctypes.data, first, n))
+        return out
+
+    def records_device_ptr(self):
+        return self._lib.seeqdevScanRecordsDevice(self._h)
+
+    def scan_tensor(self, pattern, t, options=0, want=WANT_COUNTLINES):
+        """t: torch uint8 CUDA tensor (contiguous).  Runs and fetches."""
+        self.run(pattern, t.data_ptr(), t.numel(), options, want)
+        return self.fetch()
+
+    def scan_host(self, pattern, data, options=0, want=WANT_COUNTLINES):
+        """data: bytes.  H2D + scan + fetch (+ records when want == WANT_RECORDS)."""
+        cnt = _capi.seeqdev_counts_t()
+        _check(self._lib.seeqdevScanHost(self._h, pattern.handle, data, len(data), options, want, C.byref(cnt)))
+        res = dict(nlines=cnt.nlines, nmatchlines=cnt.nmatchlines, nhits=cnt.nhits, nrecords=cnt.nrecords,
+                   nheaders=cnt.nheaders)
+        if want == WANT_RECORDS:
+            res["records"] = self.records(cnt.nrecords)
+        return res
+
+
+def synth_reads(d_ptr, first, n, length, pattern_plain, tau, seed=0x5EE92025, stream=None):
+    """Fill device memory with n synthetic reads (length bases + newline each)."""
+    p = pattern_plain.encode() if isinstance(pattern_plain, str) else pattern_plain
+    _check(_capi.lib().seeqdevSynthReads(C.c_void_p(d_ptr), first, n, length, p, len(p), tau, seed,
+                                         C.c_void_p(stream) if stream else None))

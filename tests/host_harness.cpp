@@ -1,0 +1,64 @@
+// tests/host_harness.cpp -- compiles the per-line device functions
+// (seeq_amd/csrc/seeq_kernel_core.h) with g++ so that the CPU-only test suite
+// can fuzz the Myers + acceptance + reverse-scan logic against the oracle
+// before any GPU time is spent.  Test infrastructure: never linked into
+// libseeq_amd.so.
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../seeq_amd/csrc/seeq_kernel_core.h"
+extern "C" {
+#include "../seeq_amd/csrc/seeq_pattern.h"
+}
+
+namespace {
+
+template <int W>
+long run(const uint8_t *text, size_t n, const char *keys, int m, int tau, int options, int mode, uint32_t *out,
+         size_t cap)
+{
+   std::vector<uint32_t> pf(5 * W), pr(5 * W);
+   std::vector<char> rkeys(m);
+   for (int i = 0; i < m; i++) rkeys[i] = keys[m - 1 - i];
+   seeq_build_peq(keys, m, W, pf.data());
+   seeq_build_peq(rkeys.data(), m, W, pr.data());
+   uint8_t lut[256];
+   for (int b = 0; b < 256; b++) lut[b] = sq_class_of((uint32_t)b, options);
+   const uint32_t *f = pf.data(), *r = pr.data();
+   const uint8_t *l = lut;
+   std::vector<sq_hit_t> hits(cap ? cap : 1);
+   uint32_t nh;
+   if (mode == SQ_MODE_ANY)
+      nh = sq_scan_line<W, SQ_MODE_ANY>(text, n, 0, f, r, l, m, tau, options & 3, 1, hits.data(), (uint32_t)cap);
+   else if (mode == SQ_MODE_COUNT)
+      nh = sq_scan_line<W, SQ_MODE_COUNT>(text, n, 0, f, r, l, m, tau, options & 3, 1, hits.data(), (uint32_t)cap);
+   else
+      nh = sq_scan_line<W, SQ_MODE_EMIT>(text, n, 0, f, r, l, m, tau, options & 3, 1, hits.data(), (uint32_t)cap);
+   if (mode == SQ_MODE_EMIT)
+      for (uint32_t k = 0; k < nh && k < cap; k++) {
+         out[3 * k + 0] = hits[k].start;
+         out[3 * k + 1] = hits[k].end;
+         out[3 * k + 2] = hits[k].dist;
+      }
+   return (long)nh;
+}
+
+}  // namespace
+
+// Scans text[0..n) as ONE line (seeqStringMatch semantics).  Hits come back
+// left to right as (start,end,dist) triples.  wforce > 0 forces the word
+// count (to exercise the multi-word carry chain on short patterns).
+extern "C" long harness_scan(const uint8_t *text, size_t n, const char *keys, int m, int tau, int options, int mode,
+                             int wforce, uint32_t *out, size_t cap)
+{
+   int W = wforce > 0 ? wforce : seeq_words_for(m);
+   if (W <= 1) return run<1>(text, n, keys, m, tau, options, mode, out, cap);
+   if (W <= 2) return run<2>(text, n, keys, m, tau, options, mode, out, cap);
+   if (W <= 4) return run<4>(text, n, keys, m, tau, options, mode, out, cap);
+   if (W <= 8) return run<8>(text, n, keys, m, tau, options, mode, out, cap);
+   return run<16>(text, n, keys, m, tau, options, mode, out, cap);
+}
+
+extern "C" int harness_compile(const char *expr, char *keys, int *err) { return seeq_compile_pattern(expr, keys, err); }

@@ -1,0 +1,375 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the oracle and the
+golden vectors.  Bit-exact: (line, start, end, dist) and every count."""
+import ctypes as C
+import hashlib
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import known_answers as KA
+from conftest import GOLDEN, ROOT
+from oracle.pyoracle import SQ_ALL, SQ_BEST, SQ_CONVERT, SQ_COUNT, SQ_FAIL, SQ_FIRST, SQ_IGNORE, SQ_STREAM
+
+pytestmark = pytest.mark.gpu
+MODE = dict(FIRST=SQ_FIRST, BEST=SQ_BEST, ALL=SQ_ALL)
+FOPT = dict(ANY=0, MATCH=1, NOMATCH=2, COUNTLINES=3, COUNTMATCH=4)
+PAT20 = "GATGTAGCGCGATTAGCCTG"
+PAT40 = "GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA"
+
+
+class SQ:
+    """seeqNew/seeqStringMatch of the product library."""
+
+    def __init__(self, capi, pattern, tau):
+        self.L = capi.lib()
+        self.sq = self.L.seeqNew(pattern.encode(), tau, 0)
+        assert self.sq, capi.error_text()
+
+    def match(self, text, opt):
+        n = self.L.seeqStringMatch(text.encode("latin-1"), self.sq, opt)
+        assert n >= 0
+        m = self.sq.contents.match
+        assert self.sq.contents.hits == n
+        return [(m[i].start, m[i].end, m[i].dist) for i in range(n)]
+
+    def close(self):
+        self.L.seeqFree(self.sq)
+
+
+def test_loaded_library_is_the_hip_build(gpu, capi):
+    # the .so that serves these tests is the in-tree HIP library, and it sees the GPU
+    maps = open("/proc/self/maps").read()
+    assert capi.LIB_PATH in maps and "libamdhip64" in maps
+    assert gpu >= 1
+
+
+def test_seeqnew_struct_fields(gpu, capi):
+    L = capi.lib()
+    sq = L.seeqNew(b"ACTGA", 2, 0)                       # testset.c:768-785
+    s = sq.contents
+    assert (s.hits, s.stacksize, s.tau, s.wlen) == (0, 16, 2, 5)
+    assert [s.keys[i][0] for i in range(5)] == [1, 2, 8, 4, 1]
+    assert [s.rkeys[i][0] for i in range(5)] == [1, 4, 8, 2, 1]
+    assert s.dfa and s.rdfa and s.match and not s.string
+    L.seeqFree(sq)
+
+
+def test_string_known_answers(gpu, capi):
+    for pat, tau, text, mo, exp in KA.STRING_MATCH:
+        s = SQ(capi, pat, tau)
+        assert s.match(text, MODE[mo]) == exp, (pat, text, mo)
+        s.close()
+
+
+def test_golden_string_cases(gpu, capi, string_cases):
+    cache = {}
+    for c in string_cases:
+        if "\0" in c["text"]:
+            continue
+        key = (c["pattern"], c["tau"])
+        if key not in cache:
+            cache[key] = SQ(capi, *key)
+        got = cache[key].match(c["text"], c["options"])
+        assert [list(h) for h in got] == c["hits"], c
+    for s in cache.values():
+        s.close()
+
+
+def test_string_fuzz_vs_oracle(gpu, capi, oracle):
+    sys.path.insert(0, GOLDEN)
+    from make_golden import plain, rand_pattern, rand_text
+    rng = random.Random(99)
+    for _ in range(150):
+        pat = rand_pattern(rng)
+        m = len(plain(pat))
+        tau = rng.randint(0, min(m - 1, rng.choice([0, 1, 2, 3, 3, 5, 8])))
+        s = SQ(capi, pat, tau)
+        for _ in range(4):
+            text = rand_text(rng, pat, tau, rng.choice([0, 1, 5, 20, 60, 150, 250, 1000]))
+            opt = rng.choice([SQ_FIRST, SQ_BEST, SQ_ALL, SQ_COUNT]) | rng.choice([SQ_FAIL, SQ_CONVERT, SQ_IGNORE]) \
+                | rng.choice([0, 0, SQ_STREAM])
+            assert s.match(text, opt) == oracle.string_match(pat, tau, text, opt), (pat, tau, text, opt)
+        s.close()
+
+
+def test_long_pattern_words(gpu, capi, oracle):
+    rng = random.Random(5)
+    for m in (33, 64, 65, 128, 129, 300, 512):
+        pat = "".join(rng.choice("ACGT") for _ in range(m))
+        tau = min(10, m - 1)
+        text = "".join(rng.choice("ACGT") for _ in range(200)) + pat[:m // 2] + "T" + pat[m // 2 + 1:] \
+            + "".join(rng.choice("ACGT") for _ in range(50))
+        s = SQ(capi, pat, tau)
+        for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            assert s.match(text, opt) == oracle.string_match(pat, tau, text, opt), m
+        s.close()
+    assert not capi.lib().seeqNew(("A" * 513).encode(), 1, 0)     # documented limit: fails loudly
+
+
+def _scan(capi, pattern, tau, buf, opt, want, fasta=False, env=None):
+    from seeq_amd import device as dev
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner()
+    res = sc.scan_host(pat, bytes(buf), opt | (dev.SEEQDEV_FASTA if fasta else 0), want)
+    sc.close()
+    pat.close()
+    return res
+
+
+@pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
+                                              ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
+                                              ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3)])
+def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau):
+    from seeq_amd import device as dev
+    buf = open(os.path.join(GOLDEN, name), "rb").read()
+    fasta = buf[:1] == b">"
+    for nd in (SQ_FAIL, SQ_CONVERT, SQ_IGNORE):
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = oracle.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
+            got = _scan(capi, pattern, tau, buf, mo | nd, dev.WANT_RECORDS, fasta)
+            assert got["nlines"] == exp["nlines"]
+            assert got["nmatchlines"] == exp["nmatchlines"]
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (name, mo, nd)
+        expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL | nd, fasta=fasta)
+        c1 = _scan(capi, pattern, tau, buf, nd, dev.WANT_COUNTLINES, fasta)
+        c2 = _scan(capi, pattern, tau, buf, nd, dev.WANT_COUNTMATCH, fasta)
+        assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nhits"] == expa["nmatchlines"]
+        assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
+
+
+def test_edge_buffers(gpu, capi, oracle):
+    from seeq_amd import device as dev
+    cases = [b"", b"\n", b"\n\n\n", b"ACGT", b"ACGT\n", b"\nACGT", b"ACGT\n\nACGT\n", b"ACGT\0ACGT\nACGT",
+             b"AC\rGT\r\nACGT\r\n", b"A" * 5000 + b"\n" + b"ACGT" * 3, b"\n" * 70000 + b"ACGT\n", bytes(range(256)) * 3]
+    for buf in cases:
+        for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
+            exp = oracle.buffer_scan("ACGT", 1, buf, opt)
+            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS)
+            assert got["nlines"] == exp["nlines"], (buf[:20], opt)
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (buf[:20], opt)
+
+
+def test_segments_and_workspace_regrowth(gpu, capi, oracle):
+    """Multi-segment scans (segment size forced small) and the overflow -> re-run path."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from oracle.pyoracle import Oracle, SQ_ALL, SQ_BEST
+from seeq_amd import device as dev
+o = Oracle()
+pat = "GATGTAGCGCGATTAGCCTG"
+buf = o.synth_reads(0, 6000, 150, pat, 3).tobytes()
+p = dev.Pattern(pat, 3)
+for opt in (SQ_BEST, SQ_ALL):
+    exp = o.buffer_scan(pat, 3, buf, opt)
+    sc = dev.Scanner()
+    sc.reserve(0, 10, 2, 1)                 # absurdly small: every capacity overflows
+    got = sc.scan_host(p, buf, opt, dev.WANT_RECORDS)
+    assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"]
+    assert np.array_equal(got["records"].astype(np.uint64), exp["records"])
+print("OK")
+''' % ROOT
+    env = dict(os.environ, SEEQ_SEGMENT_BYTES="65536")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_synth_generator_matches_oracle(gpu, capi, oracle):
+    import torch
+    from seeq_amd import device as dev
+    for (pattern, tau, length, first, n) in [(PAT20, 3, 150, 0, 5000), (PAT20, 3, 150, 123456789, 3000),
+                                             (dev.plain_pattern(PAT40), 5, 250, 7, 2000)]:
+        t = torch.empty(n * (length + 1), dtype=torch.uint8, device="cuda")
+        dev.synth_reads(t.data_ptr(), first, n, length, pattern, tau, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), oracle.synth_reads(first, n, length, pattern, tau))
+
+
+def test_device_resident_scan_large_properties(gpu, capi, oracle):
+    """2 M reads resident in HBM: exact parity on a prefix + size-independent properties on the whole."""
+    import torch
+    from seeq_amd import device as dev
+    n, length = 2_000_000, 150
+    t = torch.empty(n * (length + 1), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    dev.synth_reads(t.data_ptr(), 0, n, length, PAT20, 3, stream=stream)
+    pat = dev.Pattern(PAT20, 3)
+    sc = dev.Scanner(stream)
+    whole = sc.scan_tensor(pat, t, SQ_BEST, dev.WANT_RECORDS)
+    rec = sc.records(whole["nrecords"])
+    assert whole["nlines"] == n and whole["nrecords"] == whole["nmatchlines"] == len(rec)
+    # (1) prefix parity against the oracle
+    k = 100_000
+    exp = oracle.buffer_scan(PAT20, 3, t[:k * (length + 1)].cpu().numpy(), SQ_BEST)
+    assert np.array_equal(rec[rec[:, 0] <= k].astype(np.uint64), exp["records"])
+    # (2) additivity: counts of two halves add up; records of the second half are the tail shifted by line base
+    h = (n // 2) * (length + 1)
+    a = sc.scan_tensor(pat, t[:h], SQ_BEST, dev.WANT_RECORDS)
+    b = sc.scan_tensor(pat, t[h:], SQ_BEST, dev.WANT_RECORDS)
+    recb = sc.records(b["nrecords"])
+    assert a["nmatchlines"] + b["nmatchlines"] == whole["nmatchlines"]
+    tail = rec[rec[:, 0] > n // 2].copy()
+    tail[:, 0] -= n // 2
+    assert np.array_equal(tail, recb)
+    # (3) ordering and bounds
+    assert np.all(np.diff(rec[:, 0].astype(np.int64)) > 0)
+    assert np.all(rec[:, 1] <= rec[:, 2]) and np.all(rec[:, 2] <= length) and np.all(rec[:, 3] <= 3)
+    # (4) COUNTLINES == number of BEST records; COUNTMATCH >= COUNTLINES; monotone in tau
+    c1 = sc.scan_tensor(pat, t, 0, dev.WANT_COUNTLINES)
+    c2 = sc.scan_tensor(pat, t, 0, dev.WANT_COUNTMATCH)
+    assert c1["nmatchlines"] == whole["nmatchlines"] and c2["nhits"] >= c1["nmatchlines"]
+    pat2 = dev.Pattern(PAT20, 2)
+    assert sc.scan_tensor(pat2, t, 0, dev.WANT_COUNTLINES)["nmatchlines"] <= c1["nmatchlines"]
+    # (5) every record's distance is what the oracle says for that (line, window)
+    sample = rec[:: max(1, len(rec) // 200)]
+    host = t.cpu().numpy()
+    for line, s, e, d in sample:
+        txt = host[(line - 1) * (length + 1):(line - 1) * (length + 1) + length].tobytes().decode()
+        assert oracle.string_match(PAT20, 3, txt, SQ_BEST) == [(s, e, d)]
+
+
+def _file_match_sequence(capi, path, pattern, tau, calls, fasta=False):
+    L = capi.lib()
+    f = L.seeqOpen(path.encode())
+    sq = L.seeqNew(pattern.encode(), tau, 0)
+    assert f and sq
+    out = []
+    for (mo, fo) in calls:
+        rv = L.seeqFileMatch(f, sq, mo, fo)
+        s = sq.contents
+        hits = []
+        n = s.hits
+        while True:
+            m = L.seeqMatchIter(sq)
+            if not m:
+                break
+            hits.append((m.contents.start, m.contents.end, m.contents.dist))
+        string = C.string_at(s.string).decode("latin-1") if s.string else None
+        out.append((rv, n, f.contents.line, string, hits))
+    L.seeqClose(f)
+    L.seeqFree(sq)
+    return out
+
+
+def test_filematch_known_answers(gpu, capi):
+    path = os.path.join(GOLDEN, "testdata.txt")
+    for pattern, tau, seq in KA.FILE_MATCH:
+        got = _file_match_sequence(capi, path, pattern, tau, [(MODE[a], FOPT[b]) for a, b, *_ in seq])
+        for (mo, fo, rv, nh, line, string, hits), g in zip(seq, got):
+            assert g[0] == rv, (pattern, mo, fo, g)
+            if nh is not None:
+                assert g[1] == nh
+            if line is not None:
+                assert g[2] == line
+            if string is not None:
+                assert g[3] == string
+            if hits is not None:
+                assert g[4] == hits
+    for pattern, tau, kind, exp in KA.FILE_COUNTS:
+        got = _file_match_sequence(capi, path, pattern, tau, [(0, FOPT[kind])])
+        assert got[0][0] == exp
+    L = capi.lib()
+    f = L.seeqOpen(path.encode())                          # testset.c:931-937
+    sq = L.seeqNew(b"ATC", 0, 0)
+    f.contents.fdi = None
+    assert L.seeqFileMatch(f, sq, 0, 0) == -1 and capi.seeqerr() == 10
+    L.seeqFree(sq)
+
+
+def test_filematch_replay_vs_oracle_small_chunks(gpu, capi, oracle):
+    """Every line returned one call at a time (SQ_ANY) with a tiny read-ahead chunk, so that lines
+    straddle chunk boundaries; hits, line numbers and sq->string must match the oracle."""
+    code = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, %r)
+from oracle.pyoracle import Oracle, SQ_ALL
+from seeq_amd import _capi
+o = Oracle(); L = _capi.lib()
+for name, fasta in (("fastq_small.txt", False), ("fasta_small.txt", True)):
+    path = os.path.join(%r, name)
+    buf = open(path, "rb").read()
+    exp = o.buffer_scan("GATGTAGCGCGATTAGCCTG", 3, buf, SQ_ALL, fasta=fasta)
+    lines = [l for l in buf.decode().split("\n")]
+    if lines and lines[-1] == "": lines.pop()
+    if fasta: lines = [l for l in lines if not l.startswith(">")]
+    f = L.seeqOpen(path.encode()); sq = L.seeqNew(b"GATGTAGCGCGATTAGCCTG", 3, 0)
+    rec = []; n = 0
+    while L.seeqFileMatch(f, sq, SQ_ALL, 0) > 0:
+        n += 1
+        assert f.contents.line == n
+        assert C.string_at(sq.contents.string).decode() == lines[n-1], (n,)
+        while True:
+            m = L.seeqMatchIter(sq)
+            if not m: break
+            rec.append((n, m.contents.start, m.contents.end, m.contents.dist))
+    assert n == exp["nlines"], (n, exp["nlines"])
+    assert rec == [tuple(int(x) for x in r) for r in exp["records"]]
+    L.seeqClose(f); L.seeqFree(sq)
+print("OK")
+''' % (ROOT, GOLDEN)
+    env = dict(os.environ, SEEQ_CHUNK_BYTES="1000")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_cli_known_answers(gpu, capi):
+    path = os.path.join(GOLDEN, "testdata.txt")
+    for args, exp in KA.CLI:
+        r = subprocess.run([capi.CLI_PATH] + args + [path], capture_output=True, text=True)
+        assert r.stdout == exp, (args, r.stdout, r.stderr)
+    r = subprocess.run([capi.CLI_PATH, "CACAG[AT", path], capture_output=True, text=True)
+    assert r.returncode == 1 and "missing closing bracket" in r.stderr
+    r = subprocess.run([capi.CLI_PATH, "-d", "7", "CACAGAT", path], capture_output=True, text=True)
+    assert r.returncode == 1 and "larger than matching distance" in r.stderr
+    r = subprocess.run([capi.CLI_PATH, "CACAGAT", "invented.txt"], capture_output=True, text=True)
+    assert r.returncode == 1 and "seeqOpen" in r.stderr
+    # stdin input
+    r = subprocess.run([capi.CLI_PATH, "-f", "-d", "3", "CACAGAT"], input=open(path).read(), capture_output=True,
+                       text=True)
+    assert r.stdout == "1:8-14:0\n2:8-11:3\n"
+
+
+def test_cli_golden_outputs(gpu, capi, cli_cases):
+    """Byte-identical stdout with the reference CLI on the committed input files (135 invocations)."""
+    for c in cli_cases:
+        r = subprocess.run([capi.CLI_PATH] + c["args"] + [os.path.join(GOLDEN, c["file"])], capture_output=True)
+        out = r.stdout.decode("latin-1")
+        if "stdout" in c:
+            assert out == c["stdout"], (c["file"], c["args"])
+        else:
+            assert len(out) == c["nbytes"] and hashlib.sha256(out.encode()).hexdigest() == c["sha256"], \
+                (c["file"], c["args"])
+
+
+def test_python_module_surface(gpu, capi):
+    import seeq_amd as seeq
+    assert seeq.__version__ == "1.2"
+    m = seeq.compile(KA.PY_PATTERN, KA.PY_TAU)
+    assert (m.pattern, m.mismatches) == (KA.PY_PATTERN, KA.PY_TAU)
+    E = KA.PY_EXPECT
+    assert m.matchPrefix(KA.PY_NOMATCH, True) is None and m.matchPrefix(KA.PY_NOMATCH, False) is None
+    assert m.matchSuffix(KA.PY_NOMATCH, True) is None and m.matchSuffix(KA.PY_NOMATCH, False) is None
+    assert m.matchPrefix(KA.PY_MATCH, True) == E["prefix_true"] and m.matchPrefix(KA.PY_MATCH) == E["prefix_true"]
+    assert m.matchPrefix(KA.PY_MATCH, False) == E["prefix_false"]
+    assert m.matchSuffix(KA.PY_MATCH, True) == E["suffix_true"]
+    assert m.matchSuffix(KA.PY_MATCH, False) == E["suffix_false"]
+    r = m.match(KA.PY_MATCH)
+    assert r.matchlist == E["matchlist"] and r.string == KA.PY_MATCH
+    assert r.tokenize() == E["tokenize"] and r.split() == E["split"] and r.matches() == ("CGCTAATAATGGAAT",)
+    assert m.match(KA.PY_NOMATCH) is None and m.matchBest(KA.PY_NOMATCH) is None and m.matchAll("") is None
+    g = seeq.compile("GATC", 1)
+    txt = "TGACTGATGACGTAGTCTACGATCGATCAGTCA"
+    assert g.matchAll(txt).matchlist == [(1, 4, 1), (5, 9, 1), (8, 11, 1), (14, 17, 1), (20, 24, 0), (24, 28, 0),
+                                         (29, 32, 1)]
+    assert g.matchBest(txt).matchlist == [(20, 24, 0)]
+    assert list(g.matchIter(txt)) == ["GAC", "GATG", "GAC", "GTC", "GATC", "GATC", "GTC"]
+    with pytest.raises(seeq.libseeq_exception):
+        seeq.compile("AC[GT", 1)
+    # mode 0 converts non-DNA to N, mode 1 ignores it (seeqmodule.c:1079-1080)
+    assert seeq.compile("CACAGAT", 0, 1).matchAll("RCACAGATCACAGATCACAGRATCAC").matches() == \
+        ("CACAGAT", "CACAGAT", "CACAGRAT")
+    assert seeq.compile("CACAGAT", 0, 0).matchAll("RCACAGATCACAGATCACAGRATCAC").matches() == ("CACAGAT", "CACAGAT")
