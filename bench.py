@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of seeq-mi355x (BASELINE.json):
+lines/s and GB/s scanned, 20 bp pattern, d=3, 150 bp synthetic reads, 1 -> 8 MI355X.
+
+A "step" is one pass of the whole hot path (newline index, forward scan,
+compaction, exact pass with start recovery, ordered records) over one batch of
+reads that is already resident in HBM.  Default workload = BASELINE configs[2]:
+100 M x 150 bp reads per GPU, --best with positions (records bit-exact vs the
+oracle on a prefix).  Multi-GPU: one process per GPU (torch.distributed over
+RCCL), each rank scans its own contiguous range of read indices (weak scaling,
+no data-path collective); the global counts are all-reduced inside the step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATTERN = "GATGTAGCGCGATTAGCCTG"      # SURVEY 8d / reference doc/response.tex:181-183
+TAU = 3
+READ_LEN = 150
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def cpu_baseline(sample_lines, workload):
+    """The reference itself (oracle/_ref/seeq_ref, built from /root/reference in the build
+    container) timed on this box's host cores over a bounded sample of the same workload."""
+    from oracle.pyoracle import Oracle, REF_BIN
+    import multiprocessing
+    orc = Oracle()
+    cores = max(1, multiprocessing.cpu_count() // 2)      # physical cores if SMT-2, else a conservative half
+    try:
+        out = subprocess.run(["lscpu", "-p=CORE,SOCKET"], capture_output=True, text=True).stdout
+        phys = {tuple(l.split(",")) for l in out.splitlines() if l and not l.startswith("#")}
+        sock0 = {c for c, s in phys if s == "0"}
+        if sock0:
+            cores = len(sock0)
+    except Exception:
+        pass
+    cores = min(cores, multiprocessing.cpu_count())
+    data = orc.synth_reads(0, sample_lines, READ_LEN, PATTERN, TAU)
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(tmpdir, "seeq_bench_sample_%d.txt" % os.getpid())
+    data.tofile(path)
+    try:
+        if os.path.exists(REF_BIN):
+            kind = "reference"
+            args = ["-c"] if workload == "count" else ["-b", "-f"]
+            cmd = [REF_BIN, "-d", str(TAU)] + args + [PATTERN, path]
+
+            def run_parallel(p):
+                t0 = time.perf_counter()
+                procs = [subprocess.Popen(cmd, stdout=subprocess.DEVNULL) for _ in range(p)]
+                for q in procs:
+                    q.wait()
+                return time.perf_counter() - t0
+            run_parallel(1)                                   # page cache + DFA warm
+            t1 = min(run_parallel(1) for _ in range(2))
+            tp = min(run_parallel(cores) for _ in range(2)) if cores > 1 else t1
+            one = sample_lines / t1
+            agg = cores * sample_lines / tp
+        else:
+            kind = "port"
+            cores = 1
+            t0 = time.perf_counter()
+            orc.buffer_scan(PATTERN, TAU, data, 1)
+            one = agg = sample_lines / (time.perf_counter() - t0)
+    finally:
+        os.unlink(path)
+    return {"value": agg, "unit": "lines/s", "cores": cores, "kind": kind,
+            "one_core_lines_per_s": one,
+            "sample": "%d synthetic %d bp reads (same generator/seed as the GPU run), %s, "
+                      "%d concurrent single-threaded processes" % (sample_lines, READ_LEN, " ".join(
+                          ["seeq", "-d", str(TAU)] + (["-c"] if workload == "count" else ["-b", "-f"])), cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--workload", choices=["best", "count", "all"], default="best",
+                    help="best = configs[2] (--best, positions); count = configs[1] (-c)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--check-lines", type=int, default=200_000, help="prefix verified against the oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from seeq_amd import device as dev
+    from seeq_amd import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)     # RCCL
+
+    n = args.reads
+    first = rank * n                                           # this rank's read-index range (weak scaling)
+    nbytes = n * (READ_LEN + 1)
+    stream = torch.cuda.current_stream().cuda_stream
+    text = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dev.synth_reads(text.data_ptr(), first, n, READ_LEN, PATTERN, TAU, stream=stream)
+    torch.cuda.synchronize()
+
+    opt, want = {"best": (dev.SQ_BEST, dev.WANT_RECORDS), "count": (0, dev.WANT_COUNTLINES),
+                 "all": (dev.SQ_ALL, dev.WANT_RECORDS)}[args.workload]
+    pat = dev.Pattern(PATTERN, TAU)
+    sc = dev.Scanner(stream)
+    seg = int(os.environ.get("SEEQ_SEGMENT_BYTES", str(1 << 31)))
+    seg_lines = min(n, seg // (READ_LEN + 1) + 2)
+    sc.reserve(nbytes, seg_lines + 64, seg_lines // 8 + 1024, n // 8 + 1024)
+    sc.set_profiling(True)
+
+    def step():
+        sc.run(pat, text.data_ptr(), nbytes, opt, want)
+        cnt = sc.fetch()
+        return shard.reduce_counts(cnt, device=device), cnt
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fwd_ms = 0.0
+    fwd_launches = 0
+    idx_ms = ex_ms = 0.0
+    for _ in range(args.steps):
+        total, local = step()
+        tm = sc.last_times_ms()
+        fwd_ms += tm["forward"]
+        fwd_launches += tm["forward_launches"]
+        idx_ms += tm["index"]
+        ex_ms += tm["exact"]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity spot check (rank 0): prefix of the records against the oracle
+    check = None
+    if rank == 0 and args.check_lines > 0:
+        from oracle.pyoracle import Oracle
+        k = min(args.check_lines, n)
+        host = text[:k * (READ_LEN + 1)].cpu().numpy()
+        exp = Oracle().buffer_scan(PATTERN, TAU, host, opt)
+        if want == dev.WANT_RECORDS:
+            rec = sc.records(local["nrecords"])
+            got = rec[rec[:, 0] <= k].astype(np.uint64)
+            check = bool(np.array_equal(got, exp["records"]))
+        else:
+            c2 = dev.Scanner(stream).scan_tensor(pat, text[:k * (READ_LEN + 1)], opt, want)
+            check = c2["nmatchlines"] == exp["nmatchlines"]
+        assert check, "GPU results differ from the oracle"
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        lines_total = total["nlines"]
+        value = lines_total / (elapsed / args.steps)
+        gbs = value * (READ_LEN + 1) / 1e9
+        # roofline of the dominant kernel (k_forward): algorithmic bytes per launch / mean launch time
+        launches_per_step = fwd_launches / args.steps
+        algo_bytes_launch = (n * (READ_LEN + 1) + 16 * local["nrecords"]) / launches_per_step + 8
+        fwd_avg_ms = fwd_ms / max(1, fwd_launches)
+        achieved = algo_bytes_launch / (fwd_avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_forward_bytes_per_launch.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "lines/s scanned (20 bp pattern, d=3, 150 bp reads; GB/s in gb_per_s)",
+            "value": value, "unit": "lines/s", "gb_per_s": gbs,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": {"best": "BASELINE configs[2]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, "
+                                            "--best with positions (ordered hit records)" % n,
+                                    "count": "BASELINE configs[1]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, "
+                                             "-c count-only" % n,
+                                    "all": "%d x 150 bp reads per GPU, 20 bp pattern, d=3, --all" % n}[args.workload],
+                       "pattern": PATTERN, "distance": TAU, "read_len": READ_LEN, "reads_per_gpu": n,
+                       "parallelism": "line-sharded x%d, RCCL count all-reduce" % world},
+            "results": {"lines": lines_total, "matching_lines": total["nmatchlines"], "hits": total["nhits"],
+                        "oracle_prefix_check": check},
+            "device_ms_per_step": {"newline_index": idx_ms / args.steps, "forward_scan": fwd_ms / args.steps,
+                                   "compaction_exact_records": ex_ms / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "k_forward<1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches_per_step": launches_per_step, "avg_launch_ms": fwd_avg_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "note": "integer-VALU-bound by design (~17 VALU ops per text byte): see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.workload)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

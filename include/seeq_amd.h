@@ -111,12 +111,16 @@ int seeqdevScanCopyRecords(seeqdev_scan_t * scan, seeqdev_hit_t * host_out, size
 int seeqdevScanHost(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * host_text, size_t nbytes,
                     int options, int want, seeqdev_counts_t * counts);
 
-/* Per-kernel device time (ms) of the last fetched scan, measured with HIP
- * events on the scan's stream: [0] newline index, [1] forward scan
- * (the dominant kernel), [2] compaction + exact pass + records, [3] total.
- * Only filled when profiling was enabled with seeqdevScanSetProfiling(1). */
+/* Device time (ms) of the last fetched scan, measured with HIP events recorded
+ * on the scan's stream around each phase of each segment (no extra
+ * synchronisation): [0] newline index, [1] forward scan = the k_forward
+ * launches (the dominant kernel), [2] compaction + exact pass + records,
+ * [3] total.  Sums over the segments; seeqdevScanLastLaunches() returns how
+ * many k_forward launches [1] covers.  Only filled when profiling was enabled
+ * with seeqdevScanSetProfiling(1) before the run. */
 int seeqdevScanSetProfiling(seeqdev_scan_t * scan, int on);
 int seeqdevScanLastTimes(const seeqdev_scan_t * scan, float ms[4]);
+int seeqdevScanLastLaunches(const seeqdev_scan_t * scan);
 
 /* Synthetic shape-R reads written straight into HBM (bench/test input; spec
  * in SURVEY.md section 8d, CPU twin in oracle/seeq_oracle.c): n lines of

@@ -59,7 +59,7 @@ EXPORTS = [
     "seeqdevDeviceCount", "seeqdevSetDevice", "seeqdevLastError", "seeqdevPatternNew", "seeqdevPatternFree",
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
-    "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevSynthReads",
+    "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
 ]
 
 
@@ -74,6 +74,25 @@ def build(verbose=False):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """torch wheels bundle their own libamdhip64.so.7; /opt/rocm has another with the same
+    soname.  One process must use ONE HIP runtime, so when torch is installed its copy is
+    loaded first (without importing torch) and libseeq_amd.so binds to it; C callers such as
+    seeq_amd/bin/seeq simply use /opt/rocm's.  SEEQ_AMD_SYSTEM_HIP=1 disables this."""
+    if os.environ.get("SEEQ_AMD_SYSTEM_HIP") == "1":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libseeq_amd.so (raises OSError with a clear message if it is not built)."""
     global _lib
@@ -82,6 +101,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise OSError("%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C seeq_amd/csrc`; seeq_amd has no fallback matcher" % LIB_PATH)
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     L.seeqNew.argtypes = [C.c_char_p, C.c_int, C.c_size_t]
@@ -137,6 +157,8 @@ def lib():
     L.seeqdevScanSetProfiling.restype = C.c_int
     L.seeqdevScanLastTimes.argtypes = [C.c_void_p, P(C.c_float)]
     L.seeqdevScanLastTimes.restype = C.c_int
+    L.seeqdevScanLastLaunches.argtypes = [C.c_void_p]
+    L.seeqdevScanLastLaunches.restype = C.c_int
     L.seeqdevSynthReads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                     C.c_uint64, C.c_void_p]
     L.seeqdevSynthReads.restype = C.c_int

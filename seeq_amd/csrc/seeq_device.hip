@@ -617,8 +617,11 @@ struct seeqdev_scan {
    seeqdev_counts_t counts;
    /* profiling */
    bool prof;
-   hipEvent_t ev[4];
+   hipEvent_t *ev;             /* 4 events per segment: index start, forward start, forward end, segment end */
+   size_t nev_seg;             /* segments that have events */
+   size_t prof_segs;           /* segments of the last run */
    float acc_ms[4];
+   float fwd_ms_avg;           /* mean k_forward launch duration of the last run */
    size_t seg_bytes;           /* segment size */
    bool user_reserved;         /* caller sized the per-line workspace: trust it */
 };
@@ -650,7 +653,6 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    else { e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking); s->own_stream = true; }
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cnt, sizeof(Counters));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_cnt, sizeof(Counters), hipHostMallocDefault);
-   for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
    if (e != hipSuccess) {
       hip_fail(e, "seeqdevScanNew", EIO);
       seeqdevScanFree(s);
@@ -667,7 +669,8 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
                    s->nh, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
-   for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+   for (size_t i = 0; i < 4 * s->nev_seg; i++) (void)hipEventDestroy(s->ev[i]);
+   free(s->ev);
    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
    free(s);
 }
@@ -792,7 +795,6 @@ static int run_segments(seeqdev_scan *s)
    Counters *c = s->d_cnt;
 
    HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), s->stream), EIO);
-   for (int i = 0; i < 4; i++) s->acc_ms[i] = 0.f;
 
    int ncu = 256;
    {
@@ -805,7 +807,17 @@ static int run_segments(seeqdev_scan *s)
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
    const size_t nseg = nbytes ? (nbytes + seg_bytes - 1) / seg_bytes : 0;
+   s->prof_segs = 0;
+   if (s->prof && nseg > s->nev_seg) {
+      hipEvent_t *g = (hipEvent_t *)realloc(s->ev, 4 * nseg * sizeof(hipEvent_t));
+      if (!g) { seeqerr = 0; errno = ENOMEM; return -1; }
+      s->ev = g;
+      for (size_t i = 4 * s->nev_seg; i < 4 * nseg; i++) HIP_TRY(hipEventCreate(&s->ev[i]), EIO);
+      s->nev_seg = nseg;
+   }
+   if (s->prof) s->prof_segs = nseg;
    for (size_t sg = 0; sg < nseg; sg++) {
+      hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
       ScanArgs a;
       memset(&a, 0, sizeof a);
       a.text = (const uint8_t *)s->text;
@@ -823,7 +835,7 @@ static int run_segments(seeqdev_scan *s)
       a.cnt = c;
 
       /* ---- K0: newline index ---- */
-      if (s->prof) HIP_TRY(hipEventRecord(s->ev[0], s->stream), EIO);
+      if (ev) HIP_TRY(hipEventRecord(ev[0], s->stream), EIO);
       if (single) {
          hipLaunchKernelGGL(k_single_line, dim3(1), dim3(1), 0, s->stream, a);
       } else {
@@ -833,12 +845,12 @@ static int run_segments(seeqdev_scan *s)
          hipLaunchKernelGGL(k_nl_write, dim3(a.ntiles), dim3(WG), 0, s->stream, a);
       }
       /* ---- K1: forward scan ---- */
-      if (s->prof) HIP_TRY(hipEventRecord(s->ev[1], s->stream), EIO);
+      if (ev) HIP_TRY(hipEventRecord(ev[1], s->stream), EIO);
       const size_t line_blocks = (s->cap_lines + WG - 1) / WG;
       unsigned grid_lines = (unsigned)(line_blocks < (size_t)ncu * 16 ? line_blocks : (size_t)ncu * 16);
       if (grid_lines == 0) grid_lines = 1;
       hipLaunchKernelGGL(k_forward<W>, dim3(grid_lines), dim3(WG), 0, s->stream, a);
-      if (s->prof) HIP_TRY(hipEventRecord(s->ev[2], s->stream), EIO);
+      if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
       /* ---- K2: ranks of hit lines (and FASTA headers) ---- */
       launch_scan<1>(s, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
       if (fasta) launch_scan<1>(s, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
@@ -861,15 +873,7 @@ static int run_segments(seeqdev_scan *s)
          }
       }
       hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, need_nh ? 1 : 0);
-      if (s->prof) {
-         HIP_TRY(hipEventRecord(s->ev[3], s->stream), EIO);
-         HIP_TRY(hipEventSynchronize(s->ev[3]), EIO);
-         float t01 = 0, t12 = 0, t23 = 0;
-         (void)hipEventElapsedTime(&t01, s->ev[0], s->ev[1]);
-         (void)hipEventElapsedTime(&t12, s->ev[1], s->ev[2]);
-         (void)hipEventElapsedTime(&t23, s->ev[2], s->ev[3]);
-         s->acc_ms[0] += t01; s->acc_ms[1] += t12; s->acc_ms[2] += t23; s->acc_ms[3] += t01 + t12 + t23;
-      }
+      if (ev) HIP_TRY(hipEventRecord(ev[3], s->stream), EIO);
       HIP_TRY(hipGetLastError(), EIO);
    }
    HIP_TRY(hipMemcpyAsync(s->h_cnt, c, sizeof(Counters), hipMemcpyDeviceToHost, s->stream), EIO);
@@ -923,6 +927,17 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
          s->counts.nrecords = h.records;
          s->counts.nheaders = h.headers;
          if (counts) *counts = s->counts;
+         for (int i = 0; i < 4; i++) s->acc_ms[i] = 0.f;
+         s->fwd_ms_avg = 0.f;
+         for (size_t sg = 0; sg < s->prof_segs; sg++) {
+            hipEvent_t *ev = s->ev + 4 * sg;
+            float t01 = 0, t12 = 0, t23 = 0;
+            (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+            (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+            (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
+            s->acc_ms[0] += t01; s->acc_ms[1] += t12; s->acc_ms[2] += t23; s->acc_ms[3] += t01 + t12 + t23;
+         }
+         if (s->prof_segs) s->fwd_ms_avg = s->acc_ms[1] / (float)s->prof_segs;
          return 0;
       }
       /* Grow to what the device reported (plus slack for the parts it could not see) and re-run. */
@@ -970,3 +985,5 @@ extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, 
    if (seeqdevScanRun(s, pat, s->d_text, nbytes, options, want)) return -1;
    return seeqdevScanFetch(s, counts);
 }
+
+extern "C" int seeqdevScanLastLaunches(const seeqdev_scan_t *s) { return s ? (int)s->prof_segs : 0; }

@@ -94,7 +94,8 @@ class Scanner:
     def last_times_ms(self):
         ms = (C.c_float * 4)()
         _check(self._lib.seeqdevScanLastTimes(self._h, ms))
-        return dict(index=ms[0], forward=ms[1], exact=ms[2], total=ms[3])
+        return dict(index=ms[0], forward=ms[1], exact=ms[2], total=ms[3],
+                    forward_launches=self._lib.seeqdevScanLastLaunches(self._h))
 
     def run(self, pattern, d_ptr, nbytes, options=0, want=WANT_COUNTLINES):
         """Enqueue the scan (asynchronous)."""
