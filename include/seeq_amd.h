@@ -89,6 +89,13 @@ void             seeqdevScanFree(seeqdev_scan_t * scan);
 int seeqdevScanReserve(seeqdev_scan_t * scan, size_t max_bytes, size_t max_lines, size_t max_hitlines,
                        size_t max_records);
 
+/* Optional: average bytes per line (newline included) of the buffers to come; sizes the text
+ * tiles of the fused kernel.  0 (default) = estimate it from a 64 KiB sample of each new buffer. */
+int seeqdevScanSetLineHint(seeqdev_scan_t * scan, double avg_bytes_per_line);
+/* Which device path served the last run: 1 = generic (newline index + k_forward<W>),
+ * 2 = fused (k_fused: one LDS-staged pass, patterns <= 30 positions, read-length lines). */
+int seeqdevScanLastPath(const seeqdev_scan_t * scan);
+
 /* Enqueue (asynchronously, on the context's stream) the whole hot path over
  * d_text[0..nbytes): newline index -> per-line forward scan -> hit-line
  * compaction -> exact pass (acceptance rules + reverse start recovery) ->

@@ -60,6 +60,7 @@ EXPORTS = [
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
+    "seeqdevScanSetLineHint", "seeqdevScanLastPath",
 ]
 
 
@@ -159,6 +160,10 @@ def lib():
     L.seeqdevScanLastTimes.restype = C.c_int
     L.seeqdevScanLastLaunches.argtypes = [C.c_void_p]
     L.seeqdevScanLastLaunches.restype = C.c_int
+    L.seeqdevScanSetLineHint.argtypes = [C.c_void_p, C.c_double]
+    L.seeqdevScanSetLineHint.restype = C.c_int
+    L.seeqdevScanLastPath.argtypes = [C.c_void_p]
+    L.seeqdevScanLastPath.restype = C.c_int
     L.seeqdevSynthReads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                     C.c_uint64, C.c_void_p]
     L.seeqdevSynthReads.restype = C.c_int

@@ -85,7 +85,7 @@ struct Counters {
    uint32_t overflow;       /* bit0 lines, bit1 hitlines, bit2 records */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
-   uint32_t pad;
+   uint32_t seg_tmp_hits;   /* k_fused: hit lines appended so far in this segment */
    uint64_t need_records;   /* total */
 };
 
@@ -103,7 +103,9 @@ struct ScanArgs {
    uint64_t      *hdrmask;
    uint32_t      *wave_off;
    uint32_t      *hdr_off;
-   uint32_t      *hitlines;     uint32_t cap_hitlines;
+   uint32_t      *hit_start;    /* per hit line: segment-relative offset of its first byte */
+   uint32_t      *hit_line;     /* per hit line: 1-based counted line number (reference seeq.c:377) */
+   uint32_t       cap_hitlines;
    uint32_t      *nh;           /* per hit line: hits, then exclusive offsets */
    seeqdev_hit_t *records;      uint64_t cap_records;
    Counters      *cnt;
@@ -111,6 +113,9 @@ struct ScanArgs {
 
 static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
+static constexpr size_t FUSED_MIN_TILE = 4096;   /* smallest text tile of k_fused */
+static constexpr int FUSED_NW = 4;                /* waves per k_fused workgroup */
+static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate the line length */
 
 /* ========================================================================== */
 /* Block-level helpers                                                        */
@@ -354,6 +359,17 @@ __global__ __launch_bounds__(WG) void k_forward(ScanArgs a)
    }
 }
 
+__device__ __forceinline__ uint32_t counted_line_no(const ScanArgs &a, uint32_t idx, bool fasta)
+{
+   /* 1-based index among counted lines of the whole buffer (reference seeq.c:377) */
+   uint64_t n = a.cnt->lines + idx + 1;
+   if (fasta) {
+      const uint32_t chunk = idx >> 6;
+      n -= a.hdr_off[chunk] + (uint32_t)__popcll(a.hdrmask[chunk] & ((1ull << (idx & 63)) - 1));
+   }
+   return (uint32_t)n;
+}
+
 /* ========================================================================== */
 /* K3: ordered compaction of hit lines                                        */
 /* ========================================================================== */
@@ -364,11 +380,16 @@ __global__ __launch_bounds__(WG) void k_compact(ScanArgs a)
    const int lane = threadIdx.x & 63;
    const uint32_t wave = (blockIdx.x * WG + threadIdx.x) >> 6;
    const uint32_t nwaves = (gridDim.x * WG) >> 6;
+   const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
    for (uint32_t chunk = wave; chunk < nchunks; chunk += nwaves) {
       const uint64_t hm = a.hitmask[chunk];
       if ((hm >> lane) & 1) {
          const uint32_t k = a.wave_off[chunk] + (uint32_t)__popcll(hm & ((1ull << lane) - 1));
-         if (k < a.cap_hitlines) a.hitlines[k] = chunk * 64 + lane;
+         if (k < a.cap_hitlines) {
+            const uint32_t idx = chunk * 64 + lane;
+            a.hit_start[k] = a.line_start[idx];
+            a.hit_line[k] = counted_line_no(a, idx, fasta);
+         }
       }
    }
 }
@@ -399,17 +420,6 @@ __global__ void k_rec_check(ScanArgs a)
 /* ========================================================================== */
 /* K4/K5: exact pass over the hit lines                                       */
 /* ========================================================================== */
-__device__ __forceinline__ uint32_t counted_line_no(const ScanArgs &a, uint32_t idx, bool fasta)
-{
-   /* 1-based index among counted lines of the whole buffer (reference seeq.c:377) */
-   uint64_t n = a.cnt->lines + idx + 1;
-   if (fasta) {
-      const uint32_t chunk = idx >> 6;
-      n -= a.hdr_off[chunk] + (uint32_t)__popcll(a.hdrmask[chunk] & ((1ull << (idx & 63)) - 1));
-   }
-   return (uint32_t)n;
-}
-
 template <int W, int MODE>
 __global__ __launch_bounds__(WG) void k_exact(ScanArgs a)
 {
@@ -418,19 +428,17 @@ __global__ __launch_bounds__(WG) void k_exact(ScanArgs a)
    load_tables<W>(a, s_peq, s_lut);
    const Counters *c = a.cnt;
    const uint32_t nhl = c->seg_nhitlines;
-   const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
    const int match_opt = a.options & 3;
    if (MODE == SQ_MODE_EMIT && (c->overflow & 4u)) return;
    const uint32_t stride = gridDim.x * WG;
    for (uint32_t k = blockIdx.x * WG + threadIdx.x; k < nhl; k += stride) {
-      const uint32_t idx = a.hitlines[k];
-      const uint64_t off = a.seg_base + a.line_start[idx];
+      const uint64_t off = a.seg_base + a.hit_start[k];
       if (MODE == SQ_MODE_COUNT) {
          a.nh[k] = sq_scan_line<W, SQ_MODE_COUNT>(a.text, a.nbytes, off, (const uint32_t *)s_peq,
                                                   (const uint32_t *)(s_peq + 5 * W), (const uint8_t *)s_lut, a.m,
                                                   a.tau, match_opt, 0, nullptr, 0);
       } else {
-         const uint32_t line_no = counted_line_no(a, idx, fasta);
+         const uint32_t line_no = a.hit_line[k];
          uint64_t dst;
          uint32_t cap;
          if (match_opt == SQ_ALL) {
@@ -468,6 +476,8 @@ __global__ void k_single_line(ScanArgs a)
    if (a.cnt->need_lines < 1) a.cnt->need_lines = 1;
    a.line_start[0] = 0;
 }
+
+#include "seeq_fused.h"
 
 /* ========================================================================== */
 /* Synthetic reads (bench / test input; CPU twin: oracle/seeq_oracle.c)        */
@@ -604,7 +614,17 @@ struct seeqdev_scan {
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
-   uint32_t *hitlines, *nh;     size_t cap_hitlines;
+   uint32_t *hit_start, *hit_line, *nh; uint4 *tmp; size_t cap_hitlines;
+   /* fused path */
+   uint32_t *tile_cl, *tile_hits; size_t cap_ftiles;
+   uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
+   const seeqdev_pattern *eq_pat; int eq_options;
+   double avg_line;               /* average bytes per line incl. newline (hint or sampled) */
+   double line_hint;              /* caller's hint; 0 = sample the buffer */
+   uint8_t *h_sample;             /* pinned, SAMPLE_BYTES */
+   const void *avg_text; size_t avg_nbytes;
+   int force_path;                /* 0 auto, 1 generic, 2 fused (SEEQ_PATH env / tests) */
+   int last_path;                 /* 1 generic, 2 fused: what the last run used */
    seeqdev_hit_t *records;      size_t cap_records;
    uint32_t *scan_ws;           size_t cap_scan_ws;
    Counters *d_cnt;
@@ -653,6 +673,13 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    else { e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking); s->own_stream = true; }
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cnt, sizeof(Counters));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_cnt, sizeof(Counters), hipHostMallocDefault);
+   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 256 * sizeof(uint32_t), hipHostMallocDefault);
+   if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 256 * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
+   {
+      const char *pe = getenv("SEEQ_PATH");
+      s->force_path = pe ? (!strcmp(pe, "generic") ? 1 : !strcmp(pe, "fused") ? 2 : 0) : 0;
+   }
    if (e != hipSuccess) {
       hip_fail(e, "seeqdevScanNew", EIO);
       seeqdevScanFree(s);
@@ -665,10 +692,13 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
 {
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
-   void *bufs[] = {s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hitlines,
+   void *bufs[] = {s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+                   s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->d_eqtab,
                    s->nh, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
+   if (s->h_eqtab) (void)hipHostFree(s->h_eqtab);
+   if (s->h_sample) (void)hipHostFree(s->h_sample);
    for (size_t i = 0; i < 4 * s->nev_seg; i++) (void)hipEventDestroy(s->ev[i]);
    free(s->ev);
    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -687,6 +717,12 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
          if (ws_alloc((void **)&s->tile_cnt, tiles * sizeof(uint32_t))) return -1;
          s->cap_tiles = tiles;
       }
+      const size_t ftiles = seg / FUSED_MIN_TILE + 2;
+      if (ftiles > s->cap_ftiles) {
+         if (ws_alloc((void **)&s->tile_cl, ftiles * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->tile_hits, ftiles * sizeof(uint32_t))) return -1;
+         s->cap_ftiles = ftiles;
+      }
    }
    if (max_lines > s->cap_lines) {
       const size_t chunks = (max_lines + 63) / 64 + 1;
@@ -699,7 +735,9 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
       s->cap_chunks = chunks;
    }
    if (max_hitlines > s->cap_hitlines) {
-      if (ws_alloc((void **)&s->hitlines, max_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->hit_start, max_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->hit_line, max_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->tmp, max_hitlines * sizeof(uint4))) return -1;
       if (ws_alloc((void **)&s->nh, max_hitlines * sizeof(uint32_t))) return -1;
       s->cap_hitlines = max_hitlines;
    }
@@ -726,6 +764,15 @@ extern "C" int seeqdevScanReserve(seeqdev_scan_t *s, size_t max_bytes, size_t ma
    if (max_lines) s->user_reserved = true;
    return 0;
 }
+
+extern "C" int seeqdevScanSetLineHint(seeqdev_scan_t *s, double avg_bytes_per_line)
+{
+   if (!s || avg_bytes_per_line < 0) { errno = EINVAL; return -1; }
+   s->line_hint = avg_bytes_per_line;
+   return 0;
+}
+
+extern "C" int seeqdevScanLastPath(const seeqdev_scan_t *s) { return s ? s->last_path : 0; }
 
 extern "C" int seeqdevScanSetProfiling(seeqdev_scan_t *s, int on)
 {
@@ -804,6 +851,53 @@ static int run_segments(seeqdev_scan *s)
          ncu = prop.multiProcessorCount;
    }
 
+   const size_t line_blocks = (s->cap_lines + WG - 1) / WG;
+   unsigned grid_lines = (unsigned)(line_blocks < (size_t)ncu * 16 ? line_blocks : (size_t)ncu * 16);
+   if (grid_lines == 0) grid_lines = 1;
+
+   /* Path selection: the fused LDS kernel serves one-word patterns with two spare flag bits on
+      ordinary read-length lines; everything else takes the generic index + k_forward<W> path. */
+   bool use_fused = !single && W == 1 && pat->wlen <= FUSED_MAX_WLEN && s->avg_line <= 600.0 && s->force_path != 1;
+   if (s->force_path == 2 && !single && W == 1 && pat->wlen <= FUSED_MAX_WLEN) use_fused = true;
+   uint32_t tile_bytes = 0;
+   unsigned fused_grid = 1;
+   size_t fused_lds = 0;
+   if (use_fused) {
+      double want_tile = s->avg_line * (64.0 * FUSED_NW - 6.0);
+      const double max_tile = (double)FUSED_MAXR * 64 * FUSED_NW * 16;
+      if (want_tile > max_tile) want_tile = max_tile;
+      if (want_tile > 56.0 * 1024) want_tile = 56.0 * 1024;
+      if (want_tile < (double)FUSED_MIN_TILE) want_tile = (double)FUSED_MIN_TILE;
+      tile_bytes = ((uint32_t)want_tile) & ~15u;
+      const char *te = getenv("SEEQ_TILE_BYTES");
+      if (te && atoi(te) >= (int)FUSED_MIN_TILE && atoi(te) <= (int)max_tile) tile_bytes = (uint32_t)atoi(te) & ~15u;
+      fused_lds = fused_lds_bytes<FUSED_NW>(tile_bytes);
+      HIP_TRY(hipFuncSetAttribute((const void *)k_fused<FUSED_NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)fused_lds), EIO);
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<FUSED_NW>, 64 * FUSED_NW, fused_lds) !=
+             hipSuccess || per_cu < 1)
+         per_cu = 1;
+      fused_grid = (unsigned)(ncu * per_cu);
+      if (s->eq_pat != pat || s->eq_options != options) {
+         /* EQ[byte]: top-aligned Peq word of the byte's class, or a flag (reference seeqcore.h:89-111 folded
+            with the non-DNA option, libseeq.c:223-228,265-270) */
+         uint32_t hpeq[5];
+         const char *keys_unused = NULL; (void)keys_unused;
+         HIP_TRY(hipMemcpyAsync(hpeq, pat->d_peq, sizeof hpeq, hipMemcpyDeviceToHost, s->stream), EIO);
+         HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+         for (int b = 0; b < 256; b++) {
+            const uint8_t cls = sq_class_of((uint32_t)b, options);
+            s->h_eqtab[b] = cls < 5 ? hpeq[cls] << (32 - pat->wlen) : (cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP);
+         }
+         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
+         HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+         s->eq_pat = pat;
+         s->eq_options = options;
+      }
+   }
+   s->last_path = use_fused ? 2 : 1;
+
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
    const size_t nseg = nbytes ? (nbytes + seg_bytes - 1) / seg_bytes : 0;
@@ -830,10 +924,35 @@ static int run_segments(seeqdev_scan *s)
       a.line_start = s->line_start; a.cap_lines = (uint32_t)s->cap_lines;
       a.tile_cnt = s->tile_cnt; a.ntiles = (a.seg_len + TILE - 1) / TILE;
       a.hitmask = s->hitmask; a.hdrmask = s->hdrmask; a.wave_off = s->wave_off; a.hdr_off = s->hdr_off;
-      a.hitlines = s->hitlines; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
+      a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
       a.records = s->records; a.cap_records = s->cap_records;
       a.cnt = c;
 
+      if (use_fused) {
+         /* ---- fused path: newline index + forward scan + per-tile compaction in ONE kernel ---- */
+         FusedArgs f;
+         memset(&f, 0, sizeof f);
+         f.text = a.text; f.nbytes = nbytes; f.seg_base = a.seg_base; f.seg_len = a.seg_len; f.first_seg = a.first_seg;
+         f.tile_bytes = tile_bytes;
+         f.ntiles = (uint32_t)(((uint64_t)a.seg_len + tile_bytes - 1) / tile_bytes);
+         f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
+         f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
+         f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
+         f.cnt = c;
+         if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
+         const unsigned fgrid = f.ntiles < fused_grid ? f.ntiles : fused_grid;
+         hipLaunchKernelGGL(k_fused<FUSED_NW>, dim3(fgrid), dim3(64 * FUSED_NW), fused_lds, s->stream, f);
+         if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
+         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(1), 0, s->stream, f);
+         if (want != SEEQDEV_WANT_COUNTLINES) {
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, s->stream, f.tile_hits, f.ntiles, &c->seg_tmp_hits);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, s->stream, f.tile_cl, f.ntiles, &c->seg_tmp_hits);
+            const size_t hb = (s->cap_hitlines + 255) / 256;
+            const unsigned rg = (unsigned)(hb < (size_t)ncu * 8 ? (hb ? hb : 1) : (size_t)ncu * 8);
+            hipLaunchKernelGGL(k_fused_reorder, dim3(rg), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
+            hipLaunchKernelGGL(k_clear_tmp, dim3(1), dim3(1), 0, s->stream, c);
+         }
+      } else {
       /* ---- K0: newline index ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[0], s->stream), EIO);
       if (single) {
@@ -846,17 +965,15 @@ static int run_segments(seeqdev_scan *s)
       }
       /* ---- K1: forward scan ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[1], s->stream), EIO);
-      const size_t line_blocks = (s->cap_lines + WG - 1) / WG;
-      unsigned grid_lines = (unsigned)(line_blocks < (size_t)ncu * 16 ? line_blocks : (size_t)ncu * 16);
-      if (grid_lines == 0) grid_lines = 1;
       hipLaunchKernelGGL(k_forward<W>, dim3(grid_lines), dim3(WG), 0, s->stream, a);
       if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
       /* ---- K2: ranks of hit lines (and FASTA headers) ---- */
       launch_scan<1>(s, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
       if (fasta) launch_scan<1>(s, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
+      }
       if (want != SEEQDEV_WANT_COUNTLINES) {
          /* ---- K3: compaction ---- */
-         hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, s->stream, a);
+         if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, s->stream, a);
          hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, s->stream, a);
          const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
@@ -908,6 +1025,19 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
       if (want_hl > want_rec) want_rec = want_hl;
    }
    if (reserve_impl(s, nbytes ? nbytes : 1, want_lines, want_hl, want_rec)) return -1;
+   /* Average line length (tile sizing of the fused kernel): caller's hint, else a 64 KiB sample. */
+   if (s->line_hint > 0) {
+      s->avg_line = s->line_hint;
+   } else if (!(options & SEEQDEV_SINGLELINE) && nbytes && (s->avg_text != d_text || s->avg_nbytes != nbytes)) {
+      const size_t n = nbytes < SAMPLE_BYTES ? nbytes : SAMPLE_BYTES;
+      HIP_TRY(hipMemcpyAsync(s->h_sample, d_text, n, hipMemcpyDeviceToHost, s->stream), EIO);
+      HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+      size_t nl = 0;
+      for (size_t i = 0; i < n; i++) nl += s->h_sample[i] == '\n';
+      s->avg_line = nl ? (double)n / (double)nl : 1e9;
+      s->avg_text = d_text;
+      s->avg_nbytes = nbytes;
+   }
    if (dispatch_run(s)) return -1;
    s->ran = true;
    return 0;

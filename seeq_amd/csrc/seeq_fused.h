@@ -1,0 +1,349 @@
+/*
+ * seeq_fused.h -- the hot kernel of seeq-mi355x: k_fused<NW>.
+ *
+ * One pass over the text in HBM does what the reference does per line in
+ * seeq.c:361-380 + libseeq.c:250-275 (getline, newline strip, FASTA header
+ * skip, byte classification, per-character distance) for patterns of up to
+ * 30 positions (one 32-bit Myers word with two spare flag bits):
+ *
+ *   1. a workgroup stages one TILE of text (~64*NW lines) from HBM into LDS
+ *      with coalesced 16-byte loads -- every input byte is fetched from HBM
+ *      exactly once (plus a 1 KiB halo per tile);
+ *   2. it finds the newlines of the tile in LDS (SWAR compare, wave prefix
+ *      sums) -> line starts, in order, in LDS;
+ *   3. one line per lane: the lane walks its line through LDS 16 characters
+ *      at a time.  Each character costs one LDS lookup EQ[byte] (a 256-entry
+ *      table: top-aligned Peq word of the byte's class, or a flag for bytes
+ *      that end the line / are skipped under the non-DNA option) and ~13
+ *      integer VALU ops of the Myers column update; the running minimum of
+ *      D[m][j] tells whether the line has a hit (SQ_COUNTLINES needs nothing
+ *      else; for records the exact pass k_exact re-reads only the hit lines);
+ *   4. hit lines are compacted in line order per tile (wave ballots + popc)
+ *      and appended to a global list with one atomic per tile.
+ *
+ * No MFMA: this is bitwise integer work.  LDS holds the text window, the EQ
+ * table and the line starts; the only HBM traffic is the text itself.
+ */
+#ifndef SEEQ_FUSED_H_
+#define SEEQ_FUSED_H_
+
+#define FUSED_FLAG_TERM 1u      /* byte ends the line                          */
+#define FUSED_FLAG_SKIP 2u      /* byte is skipped but counted in coordinates  */
+#define FUSED_FLAGS     3u
+#define FUSED_MAX_WLEN  30      /* 32-bit word minus the two flag bits         */
+#define FUSED_HALO      1024    /* bytes staged beyond the tile: longest line handled from LDS */
+#define FUSED_CAPL      768     /* line starts kept in LDS per pass            */
+#define FUSED_MAXR      16      /* newline-detection rounds: tile <= MAXR * threads * 16 bytes */
+
+struct FusedArgs {
+   const uint8_t *text;        /* whole buffer                                 */
+   uint64_t       nbytes;
+   uint64_t       seg_base;    /* first byte of the segment                    */
+   uint32_t       seg_len;
+   uint32_t       first_seg;
+   uint32_t       tile_bytes;  /* multiple of 16                               */
+   uint32_t       ntiles;
+   const uint32_t *eqtab;      /* [256] top-aligned Peq word or flag, per byte */
+   const uint32_t *peq;        /* [2][5][1] bottom-aligned (long-line fallback)*/
+   int            m, tau, options, want;
+   uint32_t      *tile_cl;     /* per tile: counted lines (headers excluded)   */
+   uint32_t      *tile_hits;   /* per tile: hit lines                          */
+   uint4         *tmp;         /* unordered hit entries {tile, seq, start, counted rank} */
+   uint32_t       cap_tmp;
+   Counters      *cnt;
+};
+
+template <int NW>
+static size_t fused_lds_bytes(uint32_t tile_bytes)
+{
+   const size_t NT = 64 * NW;
+   return (size_t)tile_bytes + FUSED_HALO + 32 + 256 * 4 + FUSED_CAPL * 4 + FUSED_MAXR * NW * 4 +
+          2 * (FUSED_CAPL / NT + 1) * NW * 8 + 8 * 4 + 12 * 4 + 256;
+}
+
+__global__ void k_clear_tmp(Counters *c) { c->seg_tmp_hits = 0; }
+
+/* One Myers column step on a TOP-aligned pattern (row m = bit 31).  The two
+ * left shifts double as the extraction of the horizontal delta of row m: the
+ * carry out of ph+ph / mh+mh is +1 / -1 on D[m][j]. */
+__device__ __forceinline__ void fused_step(uint32_t eq, uint32_t &pv, uint32_t &mv, uint32_t &score)
+{
+   const uint32_t xv = eq | mv;
+   const uint32_t s = (eq & pv) + pv;
+   const uint32_t ph = mv | ~(s | pv | eq);            /* Xh | Pv == s | Pv | Eq */
+   const uint32_t mh = pv & ((s ^ pv) | eq);
+   uint32_t ph2, mh2;
+   asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+       : "=v"(ph2), "+v"(score) : "v"(ph) : "vcc");
+   asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+       : "=v"(mh2), "+v"(score) : "v"(mh) : "vcc");
+   pv = mh2 | ~(xv | ph2);
+   mv = ph2 & xv;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
+{
+   constexpr int NT = 64 * NW;
+   extern __shared__ __align__(16) uint8_t smem[];
+   const uint32_t TB = a.tile_bytes;
+   const uint32_t WIN = TB + FUSED_HALO;                 /* staged bytes */
+   /* LDS carve-up (all 16-byte aligned) */
+   uint8_t  *s_text = smem;                                              /* WIN + 32 */
+   uint32_t *s_eq = reinterpret_cast<uint32_t *>(smem + WIN + 32);        /* 256 */
+   uint32_t *s_starts = s_eq + 256;                                       /* FUSED_CAPL */
+   uint32_t *s_tot = s_starts + FUSED_CAPL;                               /* FUSED_MAXR * NW */
+   uint64_t *s_hit = reinterpret_cast<uint64_t *>(s_tot + FUSED_MAXR * NW);   /* (CAPL/NT + 1) * NW */
+   uint64_t *s_hdr = s_hit + (FUSED_CAPL / NT + 1) * NW;
+   uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_hdr + (FUSED_CAPL / NT + 1) * NW);   /* 8 */
+   uint32_t *s_peq = s_misc + 8;                                          /* 10 */
+   uint8_t  *s_lut = reinterpret_cast<uint8_t *>(s_peq + 12);             /* 256 */
+
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
+   const uint32_t tau = (uint32_t)a.tau;
+
+   for (int i = tid; i < 256; i += NT) { s_eq[i] = a.eqtab[i]; s_lut[i] = sq_class_of((uint32_t)i, a.options); }
+   if (tid < 10) s_peq[tid] = a.peq[tid];
+
+   for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+      const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;                 /* absolute offset of the tile */
+      const uint32_t tb = (uint32_t)(((uint64_t)a.seg_len - (uint64_t)tile * TB) < TB
+                                     ? ((uint64_t)a.seg_len - (uint64_t)tile * TB) : TB);   /* owned bytes */
+      __syncthreads();                                   /* previous tile fully consumed */
+      /* ---- 1. stage [t0, t0 + WIN) into LDS, zero beyond the buffer ---- */
+      for (uint32_t off = (uint32_t)tid * 16; off < WIN + 32; off += NT * 16) {
+         const uint64_t g = t0 + off;
+         uint4 v;
+         if (off < WIN && g + 16 <= a.nbytes) {
+            __builtin_memcpy(&v, a.text + g, 16);
+         } else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (off < WIN)
+               for (int k = 0; k < 16; k++)
+                  if (g + (uint64_t)k < a.nbytes) w[k >> 2] |= (uint32_t)a.text[g + k] << ((k & 3) * 8);
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+         }
+         *reinterpret_cast<uint4 *>(s_text + off) = v;
+      }
+      __syncthreads();
+      /* ---- 2. newlines of the owned range [0, tb): per-(round, wave) totals ---- */
+      /* A newline at q starts a line at q+1 unless it is the last byte of the buffer.  Piece =
+         16 bytes; round j covers pieces [j*NT, (j+1)*NT); line order = (round, thread, bit). */
+      const uint32_t npieces = (tb + 15) >> 4;
+      auto piece_mask = [&](int j) -> uint32_t {
+         const uint32_t piece = (uint32_t)j * NT + tid;
+         uint32_t m16 = 0;
+         if (piece < npieces) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(s_text + piece * 16);
+            const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
+            m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
+                  ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
+            const uint32_t q0 = piece * 16;
+            if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;                /* q < tb */
+            const uint64_t last = a.nbytes - 1;                              /* q + 1 < nbytes */
+            if (t0 + q0 <= last && last < t0 + q0 + 16) m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
+         }
+         return m16;
+      };
+      const uint32_t nrounds = (npieces + NT - 1) / NT;                     /* <= FUSED_MAXR */
+      for (uint32_t j = 0; j < nrounds; j++) {
+         uint32_t x = (uint32_t)__popc(piece_mask((int)j));
+#pragma unroll
+         for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+         if (lane == 0) s_tot[j * NW + wave] = x;
+      }
+      __syncthreads();
+      const uint32_t extra = (a.first_seg && tile == 0) ? 1u : 0u;          /* the line starting at byte 0 */
+      uint32_t nl_tile = extra;
+      for (uint32_t i = 0; i < nrounds * NW; i++) nl_tile += s_tot[i];      /* raw lines owned by the tile */
+
+      uint32_t tile_hdrs = 0, tile_hits = 0;
+      for (uint32_t r0 = 0; r0 < nl_tile; r0 += FUSED_CAPL) {
+         const uint32_t npass = nl_tile - r0 < FUSED_CAPL ? nl_tile - r0 : FUSED_CAPL;
+         __syncthreads();                                                   /* s_starts / s_hit free */
+         if (extra && r0 == 0 && tid == 0) s_starts[0] = 0;
+         {
+            uint32_t running = extra;
+            for (uint32_t j = 0; j < nrounds; j++) {
+               uint32_t mm = piece_mask((int)j);
+               uint32_t x = (uint32_t)__popc(mm);
+               const uint32_t c = x;
+#pragma unroll
+               for (int d = 1; d < 64; d <<= 1) {
+                  const uint32_t y = __shfl_up(x, d, 64);
+                  if (lane >= d) x += y;
+               }
+               uint32_t r = running + x - c;
+#pragma unroll
+               for (int w = 0; w < NW; w++) {
+                  const uint32_t tw = s_tot[j * NW + w];
+                  if (w < wave) r += tw;
+                  running += tw;
+               }
+               while (mm) {
+                  const uint32_t b = (uint32_t)__builtin_ctz(mm);
+                  mm &= mm - 1;
+                  if (r >= r0 && r < r0 + FUSED_CAPL) s_starts[r - r0] = (j * NT + tid) * 16 + b + 1;
+                  r++;
+               }
+            }
+         }
+         __syncthreads();
+         /* ---- 3. one line per lane ---- */
+         const uint32_t niter = (npass + NT - 1) / NT;
+         for (uint32_t it = 0; it < niter; it++) {
+            const uint32_t rl = it * NT + tid;                              /* rank within the pass */
+            bool active = rl < npass;
+            uint32_t p = active ? s_starts[rl] : 0;                         /* LDS offset of the next chunk */
+            const uint32_t lstart = p;
+            bool hdr = false;
+            if (fasta && active && s_text[p] == '>') { hdr = true; active = false; }
+            uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = (uint32_t)a.m, minscore = (uint32_t)a.m;
+            bool hit = false, toolong = false;
+            while (__any(active)) {
+               if (active && p + 16 > WIN) { toolong = true; active = false; }
+               /* 16 text bytes at arbitrary alignment: 5 aligned dwords + funnel shifts */
+               const uint32_t *src = reinterpret_cast<const uint32_t *>(s_text + (p & ~3u));
+               const uint32_t sh = p & 3u;
+               const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4];
+               uint32_t w[4];
+               w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+               w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+               w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+               w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+               uint32_t eq[16];
+#pragma unroll
+               for (int k = 0; k < 16; k++) eq[k] = s_eq[(w[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+               uint32_t fl[4];
+#pragma unroll
+               for (int g = 0; g < 4; g++) fl[g] = (eq[4 * g] | eq[4 * g + 1] | eq[4 * g + 2] | eq[4 * g + 3]) & FUSED_FLAGS;
+               const uint32_t flall = fl[0] | fl[1] | fl[2] | fl[3];
+               if (!__any(active && flall != 0)) {
+                  /* fast path: no lane of the wave sees a special byte in these 16 */
+#pragma unroll
+                  for (int k = 0; k < 16; k++) {
+                     fused_step(eq[k], pv, mv, score);
+                     minscore = score < minscore ? score : minscore;
+                  }
+                  if (active) p += 16;
+               } else {
+#pragma unroll
+                  for (int g = 0; g < 4; g++) {
+                     if (!__any(active && fl[g] != 0)) {
+#pragma unroll
+                        for (int k = 4 * g; k < 4 * g + 4; k++) {
+                           fused_step(eq[k], pv, mv, score);
+                           minscore = score < minscore ? score : minscore;
+                        }
+                     } else {
+#pragma unroll
+                        for (int k = 4 * g; k < 4 * g + 4; k++) {
+                           if (active) {
+                              const uint32_t e = eq[k];
+                              if ((e & FUSED_FLAGS) == 0) {
+                                 fused_step(e, pv, mv, score);
+                                 minscore = score < minscore ? score : minscore;
+                              } else if (e & FUSED_FLAG_TERM) {
+                                 active = false;                            /* line over: latch the verdict */
+                                 hit = minscore <= tau;
+                              }
+                           }
+                        }
+                     }
+                  }
+                  if (active) p += 16;
+               }
+            }
+            if (toolong) {
+               /* the line leaves the LDS window: scan it from HBM with the generic per-line function */
+               hit = sq_scan_line<1, SQ_MODE_ANY>(a.text, a.nbytes, t0 + lstart, (const uint32_t *)s_peq,
+                                                  (const uint32_t *)(s_peq + 5), (const uint8_t *)s_lut, a.m, a.tau,
+                                                  a.options & 3, 0, nullptr, 0) != 0;
+            }
+            const uint64_t hm = __ballot(hit);
+            const uint64_t dm = __ballot(hdr);
+            if (lane == 0) { s_hit[it * NW + wave] = hm; s_hdr[it * NW + wave] = dm; }
+         }
+         __syncthreads();
+         /* ---- 4. ordered compaction of this pass's hit lines ---- */
+         uint32_t pass_hits = 0, pass_hdrs = 0;
+         uint32_t my_seq[FUSED_CAPL / NT + 1], my_crank[FUSED_CAPL / NT + 1];
+         bool my_hit[FUSED_CAPL / NT + 1];
+#pragma unroll
+         for (int it = 0; it < FUSED_CAPL / NT + 1; it++) {
+            my_hit[it] = false; my_seq[it] = 0; my_crank[it] = 0;
+            if ((uint32_t)it < niter) {
+#pragma unroll
+               for (int w = 0; w < NW; w++) {
+                  const uint64_t hm = s_hit[it * NW + w], dm = s_hdr[it * NW + w];
+                  if (w == wave) {
+                     const uint64_t lt = (1ull << lane) - 1;
+                     my_hit[it] = (hm >> lane) & 1;
+                     my_seq[it] = pass_hits + (uint32_t)__popcll(hm & lt);
+                     /* counted rank inside the tile = raw rank - headers before it */
+                     my_crank[it] = r0 + it * NT + tid - (tile_hdrs + pass_hdrs + (uint32_t)__popcll(dm & lt));
+                  }
+                  pass_hits += (uint32_t)__popcll(hm);
+                  pass_hdrs += (uint32_t)__popcll(dm);
+               }
+            }
+         }
+         if (a.want != SEEQDEV_WANT_COUNTLINES && pass_hits) {
+            if (tid == 0) s_misc[0] = atomicAdd(&a.cnt->seg_tmp_hits, pass_hits);
+            __syncthreads();
+            const uint32_t gbase = s_misc[0];
+            if ((uint64_t)gbase + pass_hits <= a.cap_tmp) {
+#pragma unroll
+               for (int it = 0; it < FUSED_CAPL / NT + 1; it++)
+                  if (my_hit[it]) {
+                     const uint32_t rl = it * NT + tid;
+                     const uint64_t start_seg = (uint64_t)tile * TB + s_starts[rl];      /* segment-relative */
+                     a.tmp[gbase + my_seq[it]] = make_uint4(tile, tile_hits + my_seq[it], (uint32_t)start_seg,
+                                                            my_crank[it]);
+                  }
+            }
+         } else if (pass_hits && tid == 0) {
+            atomicAdd(&a.cnt->seg_tmp_hits, pass_hits);
+         }
+         tile_hits += pass_hits;
+         tile_hdrs += pass_hdrs;
+      }
+      if (tid == 0) {
+         a.tile_cl[tile] = nl_tile - tile_hdrs;
+         a.tile_hits[tile] = tile_hits;
+         if (nl_tile) atomicAdd(&a.cnt->seg_nlines, nl_tile);
+         if (tile_hdrs) atomicAdd(&a.cnt->seg_nheaders, tile_hdrs);
+      }
+   }
+}
+
+/* After k_fused: publish the hit-line count of the segment (or the overflow). */
+__global__ void k_fused_post(FusedArgs a)
+{
+   Counters *c = a.cnt;
+   uint32_t n = c->seg_tmp_hits;
+   if (n > c->need_hitlines) c->need_hitlines = n;
+   if (a.want != SEEQDEV_WANT_COUNTLINES && n > a.cap_tmp) {
+      atomicOr(&c->overflow, 2u);
+      n = 0;
+   }
+   c->seg_nhitlines = n;
+   c->seg_tmp_hits = 0;
+}
+
+/* tmp entries -> ordered (hit_start, hit_line).  tile_hits / tile_cl hold exclusive prefixes by now. */
+__global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line)
+{
+   const Counters *c = a.cnt;
+   const uint32_t n = c->seg_nhitlines;
+   const uint32_t stride = gridDim.x * 256;
+   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      const uint4 e = a.tmp[i];
+      const uint32_t dst = a.tile_hits[e.x] + e.y;
+      hit_start[dst] = e.z;
+      hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[e.x] + e.w + 1);      /* 1-based, reference seeq.c:377 */
+   }
+}
+
+#endif

@@ -91,6 +91,12 @@ class Scanner:
     def set_profiling(self, on=True):
         _check(self._lib.seeqdevScanSetProfiling(self._h, 1 if on else 0))
 
+    def set_line_hint(self, avg_bytes_per_line):
+        _check(self._lib.seeqdevScanSetLineHint(self._h, float(avg_bytes_per_line)))
+
+    def last_path(self):
+        return {1: "generic", 2: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+
     def last_times_ms(self):
         ms = (C.c_float * 4)()
         _check(self._lib.seeqdevScanLastTimes(self._h, ms))

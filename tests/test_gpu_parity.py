@@ -110,47 +110,73 @@ def test_long_pattern_words(gpu, capi, oracle):
     assert not capi.lib().seeqNew(("A" * 513).encode(), 1, 0)     # documented limit: fails loudly
 
 
-def _scan(capi, pattern, tau, buf, opt, want, fasta=False, env=None):
+def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=None):
+    """One batched scan through the device C-ABI.  path: 'generic' (newline index + k_forward<W>),
+    'fused' (k_fused, LDS-staged single pass) or 'auto'; the env knobs are read by seeqdevScanNew."""
     from seeq_amd import device as dev
-    pat = dev.Pattern(pattern, tau)
-    sc = dev.Scanner()
-    res = sc.scan_host(pat, bytes(buf), opt | (dev.SEEQDEV_FASTA if fasta else 0), want)
-    sc.close()
-    pat.close()
+    os.environ["SEEQ_PATH"] = path
+    if tile:
+        os.environ["SEEQ_TILE_BYTES"] = str(tile)
+    try:
+        pat = dev.Pattern(pattern, tau)
+        sc = dev.Scanner()
+        res = sc.scan_host(pat, bytes(buf), opt | (dev.SEEQDEV_FASTA if fasta else 0), want)
+        res["path"] = sc.last_path()
+        sc.close()
+        pat.close()
+    finally:
+        os.environ.pop("SEEQ_PATH", None)
+        os.environ.pop("SEEQ_TILE_BYTES", None)
     return res
 
 
+@pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 4096)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
-                                              ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3)])
-def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau):
+                                              ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3),
+                                              ("reads250_small.txt", "GATGAAGCACGATTAGCCTGAAAATGAGAG", 5)])
+def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile):
     from seeq_amd import device as dev
     buf = open(os.path.join(GOLDEN, name), "rb").read()
     fasta = buf[:1] == b">"
+    fusable = len(dev.plain_pattern(pattern)) <= 30
     for nd in (SQ_FAIL, SQ_CONVERT, SQ_IGNORE):
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
             exp = oracle.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
-            got = _scan(capi, pattern, tau, buf, mo | nd, dev.WANT_RECORDS, fasta)
+            got = _scan(capi, pattern, tau, buf, mo | nd, dev.WANT_RECORDS, fasta, path, tile)
+            assert got["path"] == (path if fusable else "generic")     # the kernel under test really ran
             assert got["nlines"] == exp["nlines"]
             assert got["nmatchlines"] == exp["nmatchlines"]
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (name, mo, nd)
         expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL | nd, fasta=fasta)
-        c1 = _scan(capi, pattern, tau, buf, nd, dev.WANT_COUNTLINES, fasta)
-        c2 = _scan(capi, pattern, tau, buf, nd, dev.WANT_COUNTMATCH, fasta)
+        c1 = _scan(capi, pattern, tau, buf, nd, dev.WANT_COUNTLINES, fasta, path, tile)
+        c2 = _scan(capi, pattern, tau, buf, nd, dev.WANT_COUNTMATCH, fasta, path, tile)
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nhits"] == expa["nmatchlines"]
+        assert c1["nlines"] == expa["nlines"]
         assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
 
 
-def test_edge_buffers(gpu, capi, oracle):
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_edge_buffers(gpu, capi, oracle, path):
+    """Empty / ragged / maximum-ish inputs: no trailing newline, empty lines, NUL and CR bytes, a line longer
+    than the LDS window (fused: falls back to the HBM per-line scan), 70 k empty lines (fused: many passes
+    per tile), every byte value, and lines that straddle tile boundaries at a hit."""
     from seeq_amd import device as dev
+    rng = random.Random(3)
+    ragged = b"".join((b"ACGT" * rng.randint(0, 60))[:rng.randint(0, 200)] + b"\n" for _ in range(3000))
     cases = [b"", b"\n", b"\n\n\n", b"ACGT", b"ACGT\n", b"\nACGT", b"ACGT\n\nACGT\n", b"ACGT\0ACGT\nACGT",
-             b"AC\rGT\r\nACGT\r\n", b"A" * 5000 + b"\n" + b"ACGT" * 3, b"\n" * 70000 + b"ACGT\n", bytes(range(256)) * 3]
+             b"AC\rGT\r\nACGT\r\n", b"A" * 5000 + b"\n" + b"ACGT" * 3, b"\n" * 70000 + b"ACGT\n",
+             bytes(range(256)) * 3, ragged, b"T" * 4090 + b"ACGT\nACGT" + b"T" * 4090 + b"AC\nGT\n",
+             (b"ACGT" * 300 + b"\n") * 40]
     for buf in cases:
         for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
             exp = oracle.buffer_scan("ACGT", 1, buf, opt)
-            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS)
+            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, 4096 if path == "fused" else None)
             assert got["nlines"] == exp["nlines"], (buf[:20], opt)
+            assert got["nmatchlines"] == exp["nmatchlines"], (buf[:20], opt)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (buf[:20], opt)
+            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, 4096 if path == "fused" else None)
+            assert cnt["nmatchlines"] == exp["nmatchlines"] and cnt["nlines"] == exp["nlines"]
 
 
 def test_segments_and_workspace_regrowth(gpu, capi, oracle):
