@@ -864,7 +864,7 @@ static int run_segments(seeqdev_scan *s)
    size_t fused_lds = 0;
    if (use_fused) {
       double want_tile = s->avg_line * (64.0 * FUSED_NW - 6.0);
-      const double max_tile = (double)FUSED_MAXR * 64 * FUSED_NW * 16;
+      const double max_tile = (double)FUSED_MAXS * 64 * FUSED_NW * 16 - FUSED_HALO;
       if (want_tile > max_tile) want_tile = max_tile;
       if (want_tile > 56.0 * 1024) want_tile = 56.0 * 1024;
       if (want_tile < (double)FUSED_MIN_TILE) want_tile = (double)FUSED_MIN_TILE;

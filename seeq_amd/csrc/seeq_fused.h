@@ -34,6 +34,10 @@
 #define FUSED_HALO      1024    /* bytes staged beyond the tile: longest line handled from LDS */
 #define FUSED_CAPL      768     /* line starts kept in LDS per pass            */
 #define FUSED_MAXR      16      /* newline-detection rounds: tile <= MAXR * threads * 16 bytes */
+#define FUSED_MAXS      16      /* staging rounds: tile + halo <= MAXS * threads * 16 bytes        */
+
+typedef unsigned int fused_v4u __attribute__((ext_vector_type(4)));
+typedef fused_v4u fused_v4u_unaligned __attribute__((aligned(1)));   /* the text pointer may have any alignment */
 
 struct FusedArgs {
    const uint8_t *text;        /* whole buffer                                 */
@@ -52,14 +56,6 @@ struct FusedArgs {
    uint32_t       cap_tmp;
    Counters      *cnt;
 };
-
-template <int NW>
-static size_t fused_lds_bytes(uint32_t tile_bytes)
-{
-   const size_t NT = 64 * NW;
-   return (size_t)tile_bytes + FUSED_HALO + 32 + 256 * 4 + FUSED_CAPL * 4 + FUSED_MAXR * NW * 4 +
-          2 * (FUSED_CAPL / NT + 1) * NW * 8 + 8 * 4 + 12 * 4 + 256;
-}
 
 __global__ void k_clear_tmp(Counters *c) { c->seg_tmp_hits = 0; }
 
@@ -81,23 +77,58 @@ __device__ __forceinline__ void fused_step(uint32_t eq, uint32_t &pv, uint32_t &
    mv = ph2 & xv;
 }
 
+/* Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts
+ * (VALU-speed, no LDS crossbar round trips). */
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   /* row_shr:1 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   /* row_shr:2 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   /* row_shr:4 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   /* row_shr:8 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);   /* row_bcast:15 -> rows 1,3 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);   /* row_bcast:31 -> rows 2,3 */
+   return x;
+}
+
+/* LDS layout of k_fused: fixed-size tables first (compile-time offsets), text window last. */
+template <int NW>
+struct FusedLds {
+   static constexpr int NT = 64 * NW;
+   static constexpr int ITERS = FUSED_CAPL / NT + 1;
+   static constexpr uint32_t EQ = 0;                              /* u32[256]              */
+   static constexpr uint32_t STARTS = EQ + 256 * 4;               /* u32[FUSED_CAPL]       */
+   static constexpr uint32_t WTOT = STARTS + FUSED_CAPL * 4;      /* u32[NW] (+pad to 16)  */
+   static constexpr uint32_t HIT = WTOT + 16 * ((NW * 4 + 15) / 16);   /* u64[ITERS*NW]    */
+   static constexpr uint32_t HDR = HIT + ITERS * NW * 8;          /* u64[ITERS*NW]         */
+   static constexpr uint32_t MISC = HDR + ITERS * NW * 8;         /* u32[8]                */
+   static constexpr uint32_t PEQ = MISC + 32;                     /* u32[12]               */
+   static constexpr uint32_t LUT = PEQ + 48;                      /* u8[256]               */
+   static constexpr uint32_t TEXT = (LUT + 256 + 15) & ~15u;      /* u8[WIN + 32]          */
+};
+
+template <int NW>
+static size_t fused_lds_bytes(uint32_t tile_bytes)
+{
+   return (size_t)FusedLds<NW>::TEXT + tile_bytes + FUSED_HALO + 32;
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
 {
+   typedef FusedLds<NW> L;
    constexpr int NT = 64 * NW;
    extern __shared__ __align__(16) uint8_t smem[];
    const uint32_t TB = a.tile_bytes;
    const uint32_t WIN = TB + FUSED_HALO;                 /* staged bytes */
-   /* LDS carve-up (all 16-byte aligned) */
-   uint8_t  *s_text = smem;                                              /* WIN + 32 */
-   uint32_t *s_eq = reinterpret_cast<uint32_t *>(smem + WIN + 32);        /* 256 */
-   uint32_t *s_starts = s_eq + 256;                                       /* FUSED_CAPL */
-   uint32_t *s_tot = s_starts + FUSED_CAPL;                               /* FUSED_MAXR * NW */
-   uint64_t *s_hit = reinterpret_cast<uint64_t *>(s_tot + FUSED_MAXR * NW);   /* (CAPL/NT + 1) * NW */
-   uint64_t *s_hdr = s_hit + (FUSED_CAPL / NT + 1) * NW;
-   uint32_t *s_misc = reinterpret_cast<uint32_t *>(s_hdr + (FUSED_CAPL / NT + 1) * NW);   /* 8 */
-   uint32_t *s_peq = s_misc + 8;                                          /* 10 */
-   uint8_t  *s_lut = reinterpret_cast<uint8_t *>(s_peq + 12);             /* 256 */
+   uint32_t *s_eq = reinterpret_cast<uint32_t *>(smem + L::EQ);
+   uint32_t *s_starts = reinterpret_cast<uint32_t *>(smem + L::STARTS);
+   uint32_t *s_wtot = reinterpret_cast<uint32_t *>(smem + L::WTOT);
+   uint64_t *s_hit = reinterpret_cast<uint64_t *>(smem + L::HIT);
+   uint64_t *s_hdr = reinterpret_cast<uint64_t *>(smem + L::HDR);
+   uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + L::MISC);
+   uint32_t *s_peq = reinterpret_cast<uint32_t *>(smem + L::PEQ);
+   uint8_t  *s_lut = smem + L::LUT;
+   uint8_t  *s_text = smem + L::TEXT;
 
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
@@ -112,51 +143,81 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
                                      ? ((uint64_t)a.seg_len - (uint64_t)tile * TB) : TB);   /* owned bytes */
       __syncthreads();                                   /* previous tile fully consumed */
       /* ---- 1. stage [t0, t0 + WIN) into LDS, zero beyond the buffer ---- */
-      for (uint32_t off = (uint32_t)tid * 16; off < WIN + 32; off += NT * 16) {
-         const uint64_t g = t0 + off;
-         uint4 v;
-         if (off < WIN && g + 16 <= a.nbytes) {
-            __builtin_memcpy(&v, a.text + g, 16);
-         } else {
+      /* All the loads of a thread are issued back to back (independent registers) so that one HBM
+         round trip covers the whole tile; only then are they written to LDS. */
+      if (t0 + WIN + 32 <= a.nbytes) {
+         const uint8_t *src = a.text + t0;
+#pragma unroll
+         for (int r0 = 0; r0 < FUSED_MAXS; r0 += 8) {
+            fused_v4u v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+               const uint32_t off = ((uint32_t)(r0 + r) * NT + tid) * 16;
+               v[r] = off < WIN ? *reinterpret_cast<const fused_v4u_unaligned *>(src + off) : fused_v4u{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+               const uint32_t off = ((uint32_t)(r0 + r) * NT + tid) * 16;
+               if (off < WIN) *reinterpret_cast<fused_v4u *>(s_text + off) = v[r];
+            }
+         }
+         if (tid < 2) *reinterpret_cast<fused_v4u *>(s_text + WIN + tid * 16) = fused_v4u{0, 0, 0, 0};
+      } else {
+         for (uint32_t off = (uint32_t)tid * 16; off < WIN + 32; off += NT * 16) {
+            const uint64_t g = t0 + off;
             uint32_t w[4] = {0, 0, 0, 0};
-            if (off < WIN)
+            if (off < WIN) {
+#pragma unroll
                for (int k = 0; k < 16; k++)
                   if (g + (uint64_t)k < a.nbytes) w[k >> 2] |= (uint32_t)a.text[g + k] << ((k & 3) * 8);
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<fused_v4u *>(s_text + off) = fused_v4u{w[0], w[1], w[2], w[3]};
          }
-         *reinterpret_cast<uint4 *>(s_text + off) = v;
       }
       __syncthreads();
-      /* ---- 2. newlines of the owned range [0, tb): per-(round, wave) totals ---- */
-      /* A newline at q starts a line at q+1 unless it is the last byte of the buffer.  Piece =
-         16 bytes; round j covers pieces [j*NT, (j+1)*NT); line order = (round, thread, bit). */
+      /* ---- 2. newlines of the owned range [0, tb) -> ranks ---- */
+      /* A newline at q starts a line at q+1 unless it is the last byte of the buffer.  Thread t owns
+         the R consecutive 16-byte pieces [t*R, (t+1)*R), so line order = (thread, piece, bit). */
       const uint32_t npieces = (tb + 15) >> 4;
-      auto piece_mask = [&](int j) -> uint32_t {
-         const uint32_t piece = (uint32_t)j * NT + tid;
-         uint32_t m16 = 0;
-         if (piece < npieces) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(s_text + piece * 16);
-            const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
-            m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
-                  ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
-            const uint32_t q0 = piece * 16;
-            if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;                /* q < tb */
-            const uint64_t last = a.nbytes - 1;                              /* q + 1 < nbytes */
-            if (t0 + q0 <= last && last < t0 + q0 + 16) m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
-         }
+      const uint32_t R = (npieces + NT - 1) / NT;                           /* <= FUSED_MAXR */
+      auto exact_mask = [&](uint32_t piece) -> uint32_t {
+         const fused_v4u v = *reinterpret_cast<const fused_v4u *>(s_text + piece * 16);
+         const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
+         uint32_t m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
+                        ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
+         const uint32_t q0 = piece * 16;
+         if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;                   /* q < tb */
+         const uint64_t last = a.nbytes - 1;                                 /* q + 1 < nbytes */
+         if (t0 + q0 <= last && last < t0 + q0 + 16) m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
          return m16;
       };
-      const uint32_t nrounds = (npieces + NT - 1) / NT;                     /* <= FUSED_MAXR */
-      for (uint32_t j = 0; j < nrounds; j++) {
-         uint32_t x = (uint32_t)__popc(piece_mask((int)j));
+      uint32_t pmask = 0, cnt = 0;                                          /* pieces with newlines; their count */
 #pragma unroll
-         for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-         if (lane == 0) s_tot[j * NW + wave] = x;
+      for (int j = 0; j < FUSED_MAXR; j++) {
+         const uint32_t piece = (uint32_t)tid * R + (uint32_t)j;
+         if ((uint32_t)j < R && piece < npieces) {
+            const fused_v4u v = *reinterpret_cast<const fused_v4u *>(s_text + piece * 16);
+            /* cheap superset test (a borrow can flag the byte above a newline), exact mask only then */
+            const uint32_t x0 = v.x ^ 0x0A0A0A0Au, x1 = v.y ^ 0x0A0A0A0Au, x2 = v.z ^ 0x0A0A0A0Au, x3 = v.w ^ 0x0A0A0A0Au;
+            const uint32_t any = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) |
+                                  ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
+            if (any) {
+               const uint32_t m16 = exact_mask(piece);
+               if (m16) { pmask |= 1u << j; cnt += (uint32_t)__popc(m16); }
+            }
+         }
       }
+      const uint32_t incl = wave_incl_scan_u32(cnt);
+      if (lane == 63) s_wtot[wave] = incl;
       __syncthreads();
       const uint32_t extra = (a.first_seg && tile == 0) ? 1u : 0u;          /* the line starting at byte 0 */
-      uint32_t nl_tile = extra;
-      for (uint32_t i = 0; i < nrounds * NW; i++) nl_tile += s_tot[i];      /* raw lines owned by the tile */
+      uint32_t my_base = extra + incl - cnt, nl_tile = extra;
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+         const uint32_t tw = s_wtot[w];
+         if (w < wave) my_base += tw;
+         nl_tile += tw;                                                     /* raw lines owned by the tile */
+      }
 
       uint32_t tile_hdrs = 0, tile_hits = 0;
       for (uint32_t r0 = 0; r0 < nl_tile; r0 += FUSED_CAPL) {
@@ -164,27 +225,16 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
          __syncthreads();                                                   /* s_starts / s_hit free */
          if (extra && r0 == 0 && tid == 0) s_starts[0] = 0;
          {
-            uint32_t running = extra;
-            for (uint32_t j = 0; j < nrounds; j++) {
-               uint32_t mm = piece_mask((int)j);
-               uint32_t x = (uint32_t)__popc(mm);
-               const uint32_t c = x;
-#pragma unroll
-               for (int d = 1; d < 64; d <<= 1) {
-                  const uint32_t y = __shfl_up(x, d, 64);
-                  if (lane >= d) x += y;
-               }
-               uint32_t r = running + x - c;
-#pragma unroll
-               for (int w = 0; w < NW; w++) {
-                  const uint32_t tw = s_tot[j * NW + w];
-                  if (w < wave) r += tw;
-                  running += tw;
-               }
+            uint32_t r = my_base, pm = pmask;
+            while (pm) {
+               const uint32_t j = (uint32_t)__builtin_ctz(pm);
+               pm &= pm - 1;
+               const uint32_t piece = (uint32_t)tid * R + j;
+               uint32_t mm = exact_mask(piece);
                while (mm) {
                   const uint32_t b = (uint32_t)__builtin_ctz(mm);
                   mm &= mm - 1;
-                  if (r >= r0 && r < r0 + FUSED_CAPL) s_starts[r - r0] = (j * NT + tid) * 16 + b + 1;
+                  if (r >= r0 && r < r0 + FUSED_CAPL) s_starts[r - r0] = piece * 16 + b + 1;
                   r++;
                }
             }
@@ -201,6 +251,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
             if (fasta && active && s_text[p] == '>') { hdr = true; active = false; }
             uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = (uint32_t)a.m, minscore = (uint32_t)a.m;
             bool hit = false, toolong = false;
+            const uint32_t two = 2u;
             while (__any(active)) {
                if (active && p + 16 > WIN) { toolong = true; active = false; }
                /* 16 text bytes at arbitrary alignment: 5 aligned dwords + funnel shifts */
@@ -212,9 +263,25 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
                w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
                w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
                w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+               /* EQ[byte]: the table sits at LDS offset 0, so the address is byte << 2 -- one SDWA
+                  instruction per character (byte select + shift) */
                uint32_t eq[16];
 #pragma unroll
-               for (int k = 0; k < 16; k++) eq[k] = s_eq[(w[k >> 2] >> ((k & 3) * 8)) & 0xFFu];
+               for (int k = 0; k < 16; k += 4) {
+                  uint32_t a0, a1, a2, a3;
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+                      : "=v"(a0) : "v"(two), "v"(w[k >> 2]));
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+                      : "=v"(a1) : "v"(two), "v"(w[k >> 2]));
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"
+                      : "=v"(a2) : "v"(two), "v"(w[k >> 2]));
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+                      : "=v"(a3) : "v"(two), "v"(w[k >> 2]));
+                  eq[k + 0] = *reinterpret_cast<const uint32_t *>(smem + a0);
+                  eq[k + 1] = *reinterpret_cast<const uint32_t *>(smem + a1);
+                  eq[k + 2] = *reinterpret_cast<const uint32_t *>(smem + a2);
+                  eq[k + 3] = *reinterpret_cast<const uint32_t *>(smem + a3);
+               }
                uint32_t fl[4];
 #pragma unroll
                for (int g = 0; g < 4; g++) fl[g] = (eq[4 * g] | eq[4 * g + 1] | eq[4 * g + 2] | eq[4 * g + 3]) & FUSED_FLAGS;
@@ -268,10 +335,10 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
          __syncthreads();
          /* ---- 4. ordered compaction of this pass's hit lines ---- */
          uint32_t pass_hits = 0, pass_hdrs = 0;
-         uint32_t my_seq[FUSED_CAPL / NT + 1], my_crank[FUSED_CAPL / NT + 1];
-         bool my_hit[FUSED_CAPL / NT + 1];
+         uint32_t my_seq[L::ITERS], my_crank[L::ITERS];
+         bool my_hit[L::ITERS];
 #pragma unroll
-         for (int it = 0; it < FUSED_CAPL / NT + 1; it++) {
+         for (int it = 0; it < L::ITERS; it++) {
             my_hit[it] = false; my_seq[it] = 0; my_crank[it] = 0;
             if ((uint32_t)it < niter) {
 #pragma unroll
@@ -295,7 +362,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
             const uint32_t gbase = s_misc[0];
             if ((uint64_t)gbase + pass_hits <= a.cap_tmp) {
 #pragma unroll
-               for (int it = 0; it < FUSED_CAPL / NT + 1; it++)
+               for (int it = 0; it < L::ITERS; it++)
                   if (my_hit[it]) {
                      const uint32_t rl = it * NT + tid;
                      const uint64_t start_seg = (uint64_t)tile * TB + s_starts[rl];      /* segment-relative */

@@ -122,6 +122,7 @@ SEEQ_HD sq_chunk16_t sq_load16(const uint8_t *text, uint64_t pos, uint64_t nbyte
       __builtin_memcpy(&c, text + pos, 16);
    } else {
       c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
+#pragma unroll
       for (int k = 0; k < 16; k++)
          if (pos + (uint64_t)k < nbytes) c.w[k >> 2] |= (uint32_t)text[pos + k] << ((k & 3) * 8);
    }
