@@ -64,17 +64,18 @@ __global__ void k_clear_tmp(Counters *c) { c->seg_tmp_hits = 0; }
  * carry out of ph+ph / mh+mh is +1 / -1 on D[m][j]. */
 __device__ __forceinline__ void fused_step(uint32_t eq, uint32_t &pv, uint32_t &mv, uint32_t &score)
 {
-   const uint32_t xv = eq | mv;
+   /* Hyyro's form of the Myers recurrence: D0 = zero-diagonal vector (12 VALU ops with 3-input bitops) */
    const uint32_t s = (eq & pv) + pv;
-   const uint32_t ph = mv | ~(s | pv | eq);            /* Xh | Pv == s | Pv | Eq */
-   const uint32_t mh = pv & ((s ^ pv) | eq);
+   const uint32_t d0 = ((s ^ pv) | eq) | mv;
+   const uint32_t ph = mv | ~(d0 | pv);
+   const uint32_t mh = pv & d0;
    uint32_t ph2, mh2;
    asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
        : "=v"(ph2), "+v"(score) : "v"(ph) : "vcc");
    asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc"
        : "=v"(mh2), "+v"(score) : "v"(mh) : "vcc");
-   pv = mh2 | ~(xv | ph2);
-   mv = ph2 & xv;
+   pv = mh2 | ~(d0 | ph2);
+   mv = ph2 & d0;
 }
 
 /* Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
    uint8_t  *s_text = smem + L::TEXT;
 
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int uwave = __builtin_amdgcn_readfirstlane(wave);             /* same value, provably wave-uniform */
    const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
    const uint32_t tau = (uint32_t)a.tau;
 
@@ -192,10 +194,11 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
          return m16;
       };
       uint32_t pmask = 0, cnt = 0;                                          /* pieces with newlines; their count */
-#pragma unroll
-      for (int j = 0; j < FUSED_MAXR; j++) {
-         const uint32_t piece = (uint32_t)tid * R + (uint32_t)j;
-         if ((uint32_t)j < R && piece < npieces) {
+      {
+         const uint32_t p0 = (uint32_t)tid * R;
+         const uint32_t pend = p0 + R < npieces ? p0 + R : npieces;
+#pragma unroll 2
+         for (uint32_t piece = p0; piece < pend; piece++) {
             const fused_v4u v = *reinterpret_cast<const fused_v4u *>(s_text + piece * 16);
             /* cheap superset test (a borrow can flag the byte above a newline), exact mask only then */
             const uint32_t x0 = v.x ^ 0x0A0A0A0Au, x1 = v.y ^ 0x0A0A0A0Au, x2 = v.z ^ 0x0A0A0A0Au, x3 = v.w ^ 0x0A0A0A0Au;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
                                   ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
             if (any) {
                const uint32_t m16 = exact_mask(piece);
-               if (m16) { pmask |= 1u << j; cnt += (uint32_t)__popc(m16); }
+               if (m16) { pmask |= 1u << (piece - p0); cnt += (uint32_t)__popc(m16); }
             }
          }
       }
@@ -334,44 +337,46 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
          }
          __syncthreads();
          /* ---- 4. ordered compaction of this pass's hit lines ---- */
+         /* Masks are wave-uniform: totals and prefixes are scalar work (readfirstlane + s_bcnt1). */
+         auto uni64 = [](uint64_t v) -> uint64_t {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+            return ((uint64_t)hi << 32) | lo;
+         };
          uint32_t pass_hits = 0, pass_hdrs = 0;
-         uint32_t my_seq[L::ITERS], my_crank[L::ITERS];
-         bool my_hit[L::ITERS];
-#pragma unroll
-         for (int it = 0; it < L::ITERS; it++) {
-            my_hit[it] = false; my_seq[it] = 0; my_crank[it] = 0;
-            if ((uint32_t)it < niter) {
-#pragma unroll
-               for (int w = 0; w < NW; w++) {
-                  const uint64_t hm = s_hit[it * NW + w], dm = s_hdr[it * NW + w];
-                  if (w == wave) {
-                     const uint64_t lt = (1ull << lane) - 1;
-                     my_hit[it] = (hm >> lane) & 1;
-                     my_seq[it] = pass_hits + (uint32_t)__popcll(hm & lt);
-                     /* counted rank inside the tile = raw rank - headers before it */
-                     my_crank[it] = r0 + it * NT + tid - (tile_hdrs + pass_hdrs + (uint32_t)__popcll(dm & lt));
+         for (uint32_t i = 0; i < niter * NW; i++) {
+            pass_hits += (uint32_t)__popcll(uni64(s_hit[i]));
+            pass_hdrs += (uint32_t)__popcll(uni64(s_hdr[i]));
+         }
+         const bool keep = a.want != SEEQDEV_WANT_COUNTLINES;
+         if (pass_hits) {
+            if (tid == 0) s_misc[0] = atomicAdd(&a.cnt->seg_tmp_hits, pass_hits);
+            if (keep) {
+               __syncthreads();
+               const uint32_t gbase = s_misc[0];
+               if ((uint64_t)gbase + pass_hits <= a.cap_tmp) {
+                  uint32_t hb = 0, db = 0;                                  /* hits / headers before (it, wave) */
+                  for (uint32_t it = 0; it < niter; it++) {
+                     for (int w = 0; w < NW; w++) {
+                        const uint64_t hm = uni64(s_hit[it * NW + w]), dm = uni64(s_hdr[it * NW + w]);
+                        if (w == uwave && ((hm >> lane) & 1)) {
+                           const uint32_t below_h = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0));
+                           const uint32_t below_d = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0));
+                           const uint32_t rl = it * NT + tid;
+                           const uint32_t seq = hb + below_h;
+                           /* counted rank inside the tile = raw rank - headers before it */
+                           const uint32_t crank = r0 + rl - (tile_hdrs + db + below_d);
+                           const uint64_t start_seg = (uint64_t)tile * TB + s_starts[rl];   /* segment-relative */
+                           a.tmp[gbase + seq] = make_uint4(tile, tile_hits + seq, (uint32_t)start_seg, crank);
+                        }
+                        hb += (uint32_t)__popcll(hm);
+                        db += (uint32_t)__popcll(dm);
+                     }
                   }
-                  pass_hits += (uint32_t)__popcll(hm);
-                  pass_hdrs += (uint32_t)__popcll(dm);
                }
             }
-         }
-         if (a.want != SEEQDEV_WANT_COUNTLINES && pass_hits) {
-            if (tid == 0) s_misc[0] = atomicAdd(&a.cnt->seg_tmp_hits, pass_hits);
-            __syncthreads();
-            const uint32_t gbase = s_misc[0];
-            if ((uint64_t)gbase + pass_hits <= a.cap_tmp) {
-#pragma unroll
-               for (int it = 0; it < L::ITERS; it++)
-                  if (my_hit[it]) {
-                     const uint32_t rl = it * NT + tid;
-                     const uint64_t start_seg = (uint64_t)tile * TB + s_starts[rl];      /* segment-relative */
-                     a.tmp[gbase + my_seq[it]] = make_uint4(tile, tile_hits + my_seq[it], (uint32_t)start_seg,
-                                                            my_crank[it]);
-                  }
-            }
-         } else if (pass_hits && tid == 0) {
-            atomicAdd(&a.cnt->seg_tmp_hits, pass_hits);
          }
          tile_hits += pass_hits;
          tile_hdrs += pass_hdrs;
