@@ -113,8 +113,8 @@ struct ScanArgs {
 
 static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
-static constexpr size_t FUSED_MIN_TILE = 4096;   /* smallest text tile of k_fused */
-static constexpr int FUSED_NW = 4;                /* waves per k_fused workgroup */
+static constexpr size_t FUSED_MIN_TILE = 2048;   /* smallest text tile of k_fused */
+static constexpr int FUSED_NW_DEFAULT = 2;        /* waves per k_fused workgroup (SEEQ_FUSED_NW=1|2|4) */
 static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate the line length */
 
 /* ========================================================================== */
@@ -862,22 +862,33 @@ static int run_segments(seeqdev_scan *s)
    uint32_t tile_bytes = 0;
    unsigned fused_grid = 1;
    size_t fused_lds = 0;
+   int nw = FUSED_NW_DEFAULT;
+   uint32_t halo = 0;
    if (use_fused) {
-      double want_tile = s->avg_line * (64.0 * FUSED_NW - 6.0);
-      const double max_tile = (double)FUSED_MAXS * 64 * FUSED_NW * 16 - FUSED_HALO;
+      const char *ne = getenv("SEEQ_FUSED_NW");
+      if (ne && (atoi(ne) == 1 || atoi(ne) == 2 || atoi(ne) == 4)) nw = atoi(ne);
+      double want_tile = s->avg_line * (64.0 * nw - 2.0 - nw);
+      double hl = 4.0 * s->avg_line;
+      if (hl < 256) hl = 256;
+      if (hl > FUSED_HALO_MAX) hl = FUSED_HALO_MAX;
+      halo = ((uint32_t)hl + 15u) & ~15u;
+      double max_tile = (double)FUSED_MAXS * 64 * nw * 16 - halo;
+      if (max_tile > (double)FUSED_MAXR * 64 * nw * 16) max_tile = (double)FUSED_MAXR * 64 * nw * 16;
       if (want_tile > max_tile) want_tile = max_tile;
       if (want_tile > 56.0 * 1024) want_tile = 56.0 * 1024;
       if (want_tile < (double)FUSED_MIN_TILE) want_tile = (double)FUSED_MIN_TILE;
       tile_bytes = ((uint32_t)want_tile) & ~15u;
       const char *te = getenv("SEEQ_TILE_BYTES");
       if (te && atoi(te) >= (int)FUSED_MIN_TILE && atoi(te) <= (int)max_tile) tile_bytes = (uint32_t)atoi(te) & ~15u;
-      fused_lds = fused_lds_bytes<FUSED_NW>(tile_bytes);
-      HIP_TRY(hipFuncSetAttribute((const void *)k_fused<FUSED_NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)fused_lds), EIO);
+      const void *kfn = nw == 1 ? (const void *)k_fused<1> : nw == 2 ? (const void *)k_fused<2> : (const void *)k_fused<4>;
+      fused_lds = nw == 1 ? fused_lds_bytes<1>(tile_bytes, halo) : nw == 2 ? fused_lds_bytes<2>(tile_bytes, halo)
+                                                                          : fused_lds_bytes<4>(tile_bytes, halo);
+      HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds), EIO);
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<FUSED_NW>, 64 * FUSED_NW, fused_lds) !=
-             hipSuccess || per_cu < 1)
-         per_cu = 1;
+      hipError_t oe = nw == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<1>, 64, fused_lds)
+                    : nw == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<2>, 128, fused_lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<4>, 256, fused_lds);
+      if (oe != hipSuccess || per_cu < 1) per_cu = 1;
       fused_grid = (unsigned)(ncu * per_cu);
       if (s->eq_pat != pat || s->eq_options != options) {
          /* EQ[byte]: top-aligned Peq word of the byte's class, or a flag (reference seeqcore.h:89-111 folded
@@ -934,6 +945,7 @@ static int run_segments(seeqdev_scan *s)
          memset(&f, 0, sizeof f);
          f.text = a.text; f.nbytes = nbytes; f.seg_base = a.seg_base; f.seg_len = a.seg_len; f.first_seg = a.first_seg;
          f.tile_bytes = tile_bytes;
+         f.halo = halo;
          f.ntiles = (uint32_t)(((uint64_t)a.seg_len + tile_bytes - 1) / tile_bytes);
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
@@ -941,7 +953,9 @@ static int run_segments(seeqdev_scan *s)
          f.cnt = c;
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
          const unsigned fgrid = f.ntiles < fused_grid ? f.ntiles : fused_grid;
-         hipLaunchKernelGGL(k_fused<FUSED_NW>, dim3(fgrid), dim3(64 * FUSED_NW), fused_lds, s->stream, f);
+         if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
+         else if (nw == 2) hipLaunchKernelGGL(k_fused<2>, dim3(fgrid), dim3(128), fused_lds, s->stream, f);
+         else hipLaunchKernelGGL(k_fused<4>, dim3(fgrid), dim3(256), fused_lds, s->stream, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
          hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(1), 0, s->stream, f);
          if (want != SEEQDEV_WANT_COUNTLINES) {

@@ -31,8 +31,8 @@
 #define FUSED_FLAG_SKIP 2u      /* byte is skipped but counted in coordinates  */
 #define FUSED_FLAGS     3u
 #define FUSED_MAX_WLEN  30      /* 32-bit word minus the two flag bits         */
-#define FUSED_HALO      1024    /* bytes staged beyond the tile: longest line handled from LDS */
-#define FUSED_CAPL      768     /* line starts kept in LDS per pass            */
+#define FUSED_HALO_MAX  1024    /* bytes staged beyond the tile (runtime, <= this): longest line handled from LDS */
+#define FUSED_CAPL_PER_THREAD 4 /* line starts kept in LDS per pass = this * threads */
 #define FUSED_MAXR      16      /* newline-detection rounds: tile <= MAXR * threads * 16 bytes */
 #define FUSED_MAXS      16      /* staging rounds: tile + halo <= MAXS * threads * 16 bytes        */
 
@@ -46,6 +46,7 @@ struct FusedArgs {
    uint32_t       seg_len;
    uint32_t       first_seg;
    uint32_t       tile_bytes;  /* multiple of 16                               */
+   uint32_t       halo;        /* multiple of 16, <= FUSED_HALO_MAX            */
    uint32_t       ntiles;
    const uint32_t *eqtab;      /* [256] top-aligned Peq word or flag, per byte */
    const uint32_t *peq;        /* [2][5][1] bottom-aligned (long-line fallback)*/
@@ -95,10 +96,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 template <int NW>
 struct FusedLds {
    static constexpr int NT = 64 * NW;
-   static constexpr int ITERS = FUSED_CAPL / NT + 1;
+   static constexpr int CAPL = FUSED_CAPL_PER_THREAD * NT;
+   static constexpr int ITERS = FUSED_CAPL_PER_THREAD;
    static constexpr uint32_t EQ = 0;                              /* u32[256]              */
-   static constexpr uint32_t STARTS = EQ + 256 * 4;               /* u32[FUSED_CAPL]       */
-   static constexpr uint32_t WTOT = STARTS + FUSED_CAPL * 4;      /* u32[NW] (+pad to 16)  */
+   static constexpr uint32_t STARTS = EQ + 256 * 4;               /* u32[CAPL]             */
+   static constexpr uint32_t WTOT = STARTS + CAPL * 4;      /* u32[NW] (+pad to 16)  */
    static constexpr uint32_t HIT = WTOT + 16 * ((NW * 4 + 15) / 16);   /* u64[ITERS*NW]    */
    static constexpr uint32_t HDR = HIT + ITERS * NW * 8;          /* u64[ITERS*NW]         */
    static constexpr uint32_t MISC = HDR + ITERS * NW * 8;         /* u32[8]                */
@@ -108,9 +110,9 @@ struct FusedLds {
 };
 
 template <int NW>
-static size_t fused_lds_bytes(uint32_t tile_bytes)
+static size_t fused_lds_bytes(uint32_t tile_bytes, uint32_t halo)
 {
-   return (size_t)FusedLds<NW>::TEXT + tile_bytes + FUSED_HALO + 32;
+   return (size_t)FusedLds<NW>::TEXT + tile_bytes + halo + 32;
 }
 
 template <int NW>
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
    constexpr int NT = 64 * NW;
    extern __shared__ __align__(16) uint8_t smem[];
    const uint32_t TB = a.tile_bytes;
-   const uint32_t WIN = TB + FUSED_HALO;                 /* staged bytes */
+   const uint32_t WIN = TB + a.halo;                     /* staged bytes */
+   constexpr uint32_t CAPL = L::CAPL;
    uint32_t *s_eq = reinterpret_cast<uint32_t *>(smem + L::EQ);
    uint32_t *s_starts = reinterpret_cast<uint32_t *>(smem + L::STARTS);
    uint32_t *s_wtot = reinterpret_cast<uint32_t *>(smem + L::WTOT);
@@ -223,8 +226,8 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
       }
 
       uint32_t tile_hdrs = 0, tile_hits = 0;
-      for (uint32_t r0 = 0; r0 < nl_tile; r0 += FUSED_CAPL) {
-         const uint32_t npass = nl_tile - r0 < FUSED_CAPL ? nl_tile - r0 : FUSED_CAPL;
+      for (uint32_t r0 = 0; r0 < nl_tile; r0 += CAPL) {
+         const uint32_t npass = nl_tile - r0 < CAPL ? nl_tile - r0 : CAPL;
          __syncthreads();                                                   /* s_starts / s_hit free */
          if (extra && r0 == 0 && tid == 0) s_starts[0] = 0;
          {
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
                while (mm) {
                   const uint32_t b = (uint32_t)__builtin_ctz(mm);
                   mm &= mm - 1;
-                  if (r >= r0 && r < r0 + FUSED_CAPL) s_starts[r - r0] = piece * 16 + b + 1;
+                  if (r >= r0 && r < r0 + CAPL) s_starts[r - r0] = piece * 16 + b + 1;
                   r++;
                }
             }
