@@ -85,7 +85,9 @@ struct Counters {
    uint32_t overflow;       /* bit0 lines, bit1 hitlines, bit2 records */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
-   uint32_t seg_tmp_hits;   /* k_fused: hit lines appended so far in this segment */
+   uint32_t seg_tmp_hits;   /* k_fused: hit lines of this segment (summed per workgroup) */
+   uint32_t need_slice;     /* k_fused: largest per-workgroup hit count of this segment */
+   uint32_t pad2;
    uint64_t need_records;   /* total */
 };
 
@@ -115,6 +117,7 @@ static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
 static constexpr size_t FUSED_MIN_TILE = 2048;   /* smallest text tile of k_fused */
 static constexpr int FUSED_NW_DEFAULT = 2;        /* waves per k_fused workgroup (SEEQ_FUSED_NW=1|2|4) */
+static constexpr size_t MAX_FUSED_GRID = 16384;   /* upper bound of the persistent k_fused grid */
 static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate the line length */
 
 /* ========================================================================== */
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(WG) void k_scan_reduce(const void *in, uint32_t *bs
                                                     uint32_t shift)
 {
    __shared__ uint32_t s_wave[4];
-   const uint32_t n = (*n_ptr + add) >> shift;
+   const uint32_t n = n_ptr ? (*n_ptr + add) >> shift : add;
    const uint32_t base = blockIdx.x * SCAN_BLOCK;
    if (base >= n) return;
    uint32_t v = 0;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(WG) void k_scan_top(uint32_t *bsum, const uint32_t 
                                                  uint32_t *total_out)
 {
    __shared__ uint32_t s_wave[4];
-   const uint32_t n = (*n_ptr + add) >> shift;
+   const uint32_t n = n_ptr ? (*n_ptr + add) >> shift : add;
    const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
    uint32_t running = 0;
    for (uint32_t b0 = 0; b0 < nb; b0 += WG) {
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(WG) void k_scan_apply(const void *in, uint32_t *out
                                                    const uint32_t *n_ptr, uint32_t add, uint32_t shift)
 {
    __shared__ uint32_t s_wave[4];
-   const uint32_t n = (*n_ptr + add) >> shift;
+   const uint32_t n = n_ptr ? (*n_ptr + add) >> shift : add;
    const uint32_t base = blockIdx.x * SCAN_BLOCK;
    if (base >= n) return;
    uint32_t item[SCAN_ITEMS];
@@ -617,6 +620,7 @@ struct seeqdev_scan {
    uint32_t *hit_start, *hit_line, *nh; uint4 *tmp; size_t cap_hitlines;
    /* fused path */
    uint32_t *tile_cl, *tile_hits; size_t cap_ftiles;
+   uint32_t *wg_hits;             /* [MAX_FUSED_GRID] */
    uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
    const seeqdev_pattern *eq_pat; int eq_options;
    double avg_line;               /* average bytes per line incl. newline (hint or sampled) */
@@ -676,6 +680,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 256 * sizeof(uint32_t), hipHostMallocDefault);
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 256 * sizeof(uint32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
+   if (e == hipSuccess) e = hipMalloc((void **)&s->wg_hits, MAX_FUSED_GRID * sizeof(uint32_t));
    {
       const char *pe = getenv("SEEQ_PATH");
       s->force_path = pe ? (!strcmp(pe, "generic") ? 1 : !strcmp(pe, "fused") ? 2 : 0) : 0;
@@ -692,7 +697,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
 {
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
-   void *bufs[] = {s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+   void *bufs[] = {s->wg_hits, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->d_eqtab,
                    s->nh, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
@@ -749,6 +754,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
    size_t largest = s->cap_tiles;
    if (s->cap_chunks > largest) largest = s->cap_chunks;
    if (s->cap_hitlines > largest) largest = s->cap_hitlines;
+   if (s->cap_ftiles > largest) largest = s->cap_ftiles;
    const size_t nb = largest / SCAN_BLOCK + 2;
    if (nb > s->cap_scan_ws) {
       if (ws_alloc((void **)&s->scan_ws, nb * sizeof(uint32_t))) return -1;
@@ -890,6 +896,7 @@ static int run_segments(seeqdev_scan *s)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<4>, 256, fused_lds);
       if (oe != hipSuccess || per_cu < 1) per_cu = 1;
       fused_grid = (unsigned)(ncu * per_cu);
+      if (fused_grid > MAX_FUSED_GRID) fused_grid = MAX_FUSED_GRID;
       if (s->eq_pat != pat || s->eq_options != options) {
          /* EQ[byte]: top-aligned Peq word of the byte's class, or a flag (reference seeqcore.h:89-111 folded
             with the non-DNA option, libseeq.c:223-228,265-270) */
@@ -950,20 +957,20 @@ static int run_segments(seeqdev_scan *s)
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
+         f.wg_hits = s->wg_hits;
          f.cnt = c;
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
          const unsigned fgrid = f.ntiles < fused_grid ? f.ntiles : fused_grid;
+         f.slice_cap = f.cap_tmp / fgrid;
          if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
          else if (nw == 2) hipLaunchKernelGGL(k_fused<2>, dim3(fgrid), dim3(128), fused_lds, s->stream, f);
          else hipLaunchKernelGGL(k_fused<4>, dim3(fgrid), dim3(256), fused_lds, s->stream, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
-         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(1), 0, s->stream, f);
+         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(1), 0, s->stream, f, (uint32_t)fgrid);
          if (want != SEEQDEV_WANT_COUNTLINES) {
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, s->stream, f.tile_hits, f.ntiles, &c->seg_tmp_hits);
-            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, s->stream, f.tile_cl, f.ntiles, &c->seg_tmp_hits);
-            const size_t hb = (s->cap_hitlines + 255) / 256;
-            const unsigned rg = (unsigned)(hb < (size_t)ncu * 8 ? (hb ? hb : 1) : (size_t)ncu * 8);
-            hipLaunchKernelGGL(k_fused_reorder, dim3(rg), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
+            launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
+            launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
+            hipLaunchKernelGGL(k_fused_reorder, dim3(fgrid), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
             hipLaunchKernelGGL(k_clear_tmp, dim3(1), dim3(1), 0, s->stream, c);
          }
       } else {

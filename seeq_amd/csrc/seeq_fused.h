@@ -53,8 +53,10 @@ struct FusedArgs {
    int            m, tau, options, want;
    uint32_t      *tile_cl;     /* per tile: counted lines (headers excluded)   */
    uint32_t      *tile_hits;   /* per tile: hit lines                          */
-   uint4         *tmp;         /* unordered hit entries {tile, seq, start, counted rank} */
-   uint32_t       cap_tmp;
+   uint4         *tmp;         /* hit entries {tile, seq, start, counted rank}: one slice per workgroup */
+   uint32_t       cap_tmp;     /* total entries                                */
+   uint32_t       slice_cap;   /* entries per workgroup slice = cap_tmp / grid  */
+   uint32_t      *wg_hits;     /* per workgroup: entries stored in its slice   */
    Counters      *cnt;
 };
 
@@ -141,6 +143,11 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
 
    for (int i = tid; i < 256; i += NT) { s_eq[i] = a.eqtab[i]; s_lut[i] = sq_class_of((uint32_t)i, a.options); }
    if (tid < 10) s_peq[tid] = a.peq[tid];
+
+   /* Per-workgroup accumulators: no global atomics inside the tile loop (same-address atomics serialise
+      at ~100/us chip-wide, which would cap the whole kernel at a few hundred thousand tiles per ms). */
+   uint32_t wg_lines = 0, wg_hdrs = 0, wg_hitlines = 0, slice_pos = 0;
+   bool wg_overflow = false;
 
    for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
       const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;                 /* absolute offset of the tile */
@@ -352,33 +359,32 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
             pass_hdrs += (uint32_t)__popcll(uni64(s_hdr[i]));
          }
          const bool keep = a.want != SEEQDEV_WANT_COUNTLINES;
-         if (pass_hits) {
-            if (tid == 0) s_misc[0] = atomicAdd(&a.cnt->seg_tmp_hits, pass_hits);
-            if (keep) {
-               __syncthreads();
-               const uint32_t gbase = s_misc[0];
-               if ((uint64_t)gbase + pass_hits <= a.cap_tmp) {
-                  uint32_t hb = 0, db = 0;                                  /* hits / headers before (it, wave) */
-                  for (uint32_t it = 0; it < niter; it++) {
-                     for (int w = 0; w < NW; w++) {
-                        const uint64_t hm = uni64(s_hit[it * NW + w]), dm = uni64(s_hdr[it * NW + w]);
-                        if (w == uwave && ((hm >> lane) & 1)) {
-                           const uint32_t below_h = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0));
-                           const uint32_t below_d = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0));
-                           const uint32_t rl = it * NT + tid;
-                           const uint32_t seq = hb + below_h;
-                           /* counted rank inside the tile = raw rank - headers before it */
-                           const uint32_t crank = r0 + rl - (tile_hdrs + db + below_d);
-                           const uint64_t start_seg = (uint64_t)tile * TB + s_starts[rl];   /* segment-relative */
-                           a.tmp[gbase + seq] = make_uint4(tile, tile_hits + seq, (uint32_t)start_seg, crank);
-                        }
-                        hb += (uint32_t)__popcll(hm);
-                        db += (uint32_t)__popcll(dm);
+         if (pass_hits && keep) {
+            if (slice_pos + pass_hits <= a.slice_cap) {
+               uint4 *slice = a.tmp + (size_t)blockIdx.x * a.slice_cap + slice_pos;
+               uint32_t hb = 0, db = 0;                                     /* hits / headers before (it, wave) */
+               for (uint32_t it = 0; it < niter; it++) {
+                  for (int w = 0; w < NW; w++) {
+                     const uint64_t hm = uni64(s_hit[it * NW + w]), dm = uni64(s_hdr[it * NW + w]);
+                     if (w == uwave && ((hm >> lane) & 1)) {
+                        const uint32_t below_h = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0));
+                        const uint32_t below_d = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0));
+                        const uint32_t rl = it * NT + tid;
+                        const uint32_t seq = hb + below_h;
+                        /* counted rank inside the tile = raw rank - headers before it */
+                        const uint32_t crank = r0 + rl - (tile_hdrs + db + below_d);
+                        const uint64_t start_seg = (uint64_t)tile * TB + s_starts[rl];      /* segment-relative */
+                        slice[seq] = make_uint4(tile, tile_hits + seq, (uint32_t)start_seg, crank);
                      }
+                     hb += (uint32_t)__popcll(hm);
+                     db += (uint32_t)__popcll(dm);
                   }
                }
+               slice_pos += pass_hits;
+            } else {
+               wg_overflow = true;
             }
          }
          tile_hits += pass_hits;
@@ -387,34 +393,45 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
       if (tid == 0) {
          a.tile_cl[tile] = nl_tile - tile_hdrs;
          a.tile_hits[tile] = tile_hits;
-         if (nl_tile) atomicAdd(&a.cnt->seg_nlines, nl_tile);
-         if (tile_hdrs) atomicAdd(&a.cnt->seg_nheaders, tile_hdrs);
       }
+      wg_lines += nl_tile;
+      wg_hdrs += tile_hdrs;
+      wg_hitlines += tile_hits;
+   }
+   if (tid == 0) {
+      if (wg_lines) atomicAdd(&a.cnt->seg_nlines, wg_lines);
+      if (wg_hdrs) atomicAdd(&a.cnt->seg_nheaders, wg_hdrs);
+      if (wg_hitlines) atomicAdd(&a.cnt->seg_tmp_hits, wg_hitlines);
+      atomicMax(&a.cnt->need_slice, wg_hitlines);
+      if (wg_overflow) atomicOr(&a.cnt->overflow, 2u);
+      a.wg_hits[blockIdx.x] = wg_overflow ? 0u : slice_pos;
    }
 }
 
 /* After k_fused: publish the hit-line count of the segment (or the overflow). */
-__global__ void k_fused_post(FusedArgs a)
+__global__ void k_fused_post(FusedArgs a, uint32_t grid)
 {
    Counters *c = a.cnt;
    uint32_t n = c->seg_tmp_hits;
-   if (n > c->need_hitlines) c->need_hitlines = n;
-   if (a.want != SEEQDEV_WANT_COUNTLINES && n > a.cap_tmp) {
-      atomicOr(&c->overflow, 2u);
-      n = 0;
-   }
+   /* capacity wanted next time: every slice as large as the fullest one, plus slack */
+   const uint64_t need = (uint64_t)c->need_slice * grid + (uint64_t)grid * 64;
+   if (need > c->need_hitlines) c->need_hitlines = need > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need;
+   if (c->overflow & 2u) n = 0;
    c->seg_nhitlines = n;
    c->seg_tmp_hits = 0;
+   c->need_slice = 0;
 }
 
-/* tmp entries -> ordered (hit_start, hit_line).  tile_hits / tile_cl hold exclusive prefixes by now. */
+/* Slices -> ordered (hit_start, hit_line).  tile_hits / tile_cl hold exclusive prefixes by now.
+   One workgroup per k_fused workgroup slice. */
 __global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line)
 {
    const Counters *c = a.cnt;
-   const uint32_t n = c->seg_nhitlines;
-   const uint32_t stride = gridDim.x * 256;
-   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-      const uint4 e = a.tmp[i];
+   if (c->overflow & 2u) return;
+   const uint32_t n = a.wg_hits[blockIdx.x];
+   const uint4 *slice = a.tmp + (size_t)blockIdx.x * a.slice_cap;
+   for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      const uint4 e = slice[i];
       const uint32_t dst = a.tile_hits[e.x] + e.y;
       hit_start[dst] = e.z;
       hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[e.x] + e.w + 1);      /* 1-based, reference seeq.c:377 */
