@@ -958,6 +958,7 @@ static int run_segments(seeqdev_scan *s)
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
          f.wg_hits = s->wg_hits;
+         { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
          const unsigned fgrid = f.ntiles < fused_grid ? f.ntiles : fused_grid;

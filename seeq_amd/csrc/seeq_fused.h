@@ -34,7 +34,7 @@
 #define FUSED_HALO_MAX  1024    /* bytes staged beyond the tile (runtime, <= this): longest line handled from LDS */
 #define FUSED_CAPL_PER_THREAD 4 /* line starts kept in LDS per pass = this * threads */
 #define FUSED_MAXR      16      /* newline-detection rounds: tile <= MAXR * threads * 16 bytes */
-#define FUSED_MAXS      16      /* staging rounds: tile + halo <= MAXS * threads * 16 bytes        */
+#define FUSED_MAXS      12      /* staging rounds: tile + halo <= MAXS * threads * 16 bytes        */
 
 typedef unsigned int fused_v4u __attribute__((ext_vector_type(4)));
 typedef fused_v4u fused_v4u_unaligned __attribute__((aligned(1)));   /* the text pointer may have any alignment */
@@ -57,6 +57,7 @@ struct FusedArgs {
    uint32_t       cap_tmp;     /* total entries                                */
    uint32_t       slice_cap;   /* entries per workgroup slice = cap_tmp / grid  */
    uint32_t      *wg_hits;     /* per workgroup: entries stored in its slice   */
+   uint32_t       debug;       /* profiling experiments only (SEEQ_FUSED_DEBUG): 1 = skip the per-line scan */
    Counters      *cnt;
 };
 
@@ -149,32 +150,40 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
    uint32_t wg_lines = 0, wg_hdrs = 0, wg_hitlines = 0, slice_pos = 0;
    bool wg_overflow = false;
 
+   /* Software pipeline over tiles: the global loads of tile t+1 are issued (into registers) before the
+      per-line scan of tile t and only written to LDS when tile t is done, so the HBM round trip hides
+      behind ~10 us of VALU work instead of stalling all waves of the workgroup. */
+   fused_v4u pre[FUSED_MAXS];
+   bool pre_valid = false;                                /* pre[] holds the window of the tile about to start */
+   auto prefetch = [&](uint32_t tl) {
+      const uint64_t p0 = a.seg_base + (uint64_t)tl * TB;
+      pre_valid = tl < a.ntiles && p0 + WIN + 32 <= a.nbytes;          /* interior tiles only */
+      if (pre_valid) {
+         const uint8_t *src = a.text + p0;
+#pragma unroll
+         for (int r = 0; r < FUSED_MAXS; r++) {
+            const uint32_t off = ((uint32_t)r * NT + tid) * 16;
+            if (off < WIN) pre[r] = *reinterpret_cast<const fused_v4u_unaligned *>(src + off);
+         }
+      }
+   };
+   prefetch(blockIdx.x);
+
    for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
       const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;                 /* absolute offset of the tile */
       const uint32_t tb = (uint32_t)(((uint64_t)a.seg_len - (uint64_t)tile * TB) < TB
                                      ? ((uint64_t)a.seg_len - (uint64_t)tile * TB) : TB);   /* owned bytes */
       __syncthreads();                                   /* previous tile fully consumed */
       /* ---- 1. stage [t0, t0 + WIN) into LDS, zero beyond the buffer ---- */
-      /* All the loads of a thread are issued back to back (independent registers) so that one HBM
-         round trip covers the whole tile; only then are they written to LDS. */
-      if (t0 + WIN + 32 <= a.nbytes) {
-         const uint8_t *src = a.text + t0;
+      if (pre_valid) {
 #pragma unroll
-         for (int r0 = 0; r0 < FUSED_MAXS; r0 += 8) {
-            fused_v4u v[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-               const uint32_t off = ((uint32_t)(r0 + r) * NT + tid) * 16;
-               v[r] = off < WIN ? *reinterpret_cast<const fused_v4u_unaligned *>(src + off) : fused_v4u{0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-               const uint32_t off = ((uint32_t)(r0 + r) * NT + tid) * 16;
-               if (off < WIN) *reinterpret_cast<fused_v4u *>(s_text + off) = v[r];
-            }
+         for (int r = 0; r < FUSED_MAXS; r++) {
+            const uint32_t off = ((uint32_t)r * NT + tid) * 16;
+            if (off < WIN) *reinterpret_cast<fused_v4u *>(s_text + off) = pre[r];
          }
          if (tid < 2) *reinterpret_cast<fused_v4u *>(s_text + WIN + tid * 16) = fused_v4u{0, 0, 0, 0};
       } else {
+         /* last tile(s) of the buffer: bounds-checked byte loads */
          for (uint32_t off = (uint32_t)tid * 16; off < WIN + 32; off += NT * 16) {
             const uint64_t g = t0 + off;
             uint32_t w[4] = {0, 0, 0, 0};
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
             *reinterpret_cast<fused_v4u *>(s_text + off) = fused_v4u{w[0], w[1], w[2], w[3]};
          }
       }
+      prefetch(tile + gridDim.x);                        /* in flight during everything below */
       __syncthreads();
       /* ---- 2. newlines of the owned range [0, tb) -> ranks ---- */
       /* A newline at q starts a line at q+1 unless it is the last byte of the buffer.  Thread t owns
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
             uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = (uint32_t)a.m, minscore = (uint32_t)a.m;
             bool hit = false, toolong = false;
             const uint32_t two = 2u;
+            if (a.debug & 1u) active = false;
             while (__any(active)) {
                if (active && p + 16 > WIN) { toolong = true; active = false; }
                /* 16 text bytes at arbitrary alignment: 5 aligned dwords + funnel shifts */
