@@ -10,14 +10,14 @@ __global__ __launch_bounds__(256) void k_chain(uint32_t *out, int iters, uint32_
    uint32_t x[ILP];
 #pragma unroll
    for (int i = 0; i < ILP; i++) x[i] = seed + threadIdx.x * 7 + i;
-   uint32_t y = seed ^ 0x9E3779B9u;
+   uint32_t y = seed ^ 0x9E3779B9u, z = seed * 3u + threadIdx.x;
    for (int it = 0; it < iters; it++) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
 #pragma unroll
          for (int i = 0; i < ILP; i++) {
             // one dependent op per chain per step; bitop-like mix so nothing folds
-            asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x[i]) : "v"(y), "v"(x[(i + 1) % ILP]));
+            asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x[i]) : "v"(y), "v"(z));   // chains are independent
          }
       }
    }
@@ -55,7 +55,7 @@ int main()
    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
    const int ncu = p.multiProcessorCount;
    printf("%s  CUs=%d clock=%d kHz\n", p.name, ncu, p.clockRate);
-   for (int b : {1, 2, 4, 8}) {
+   for (int b : {1, 2, 3, 4, 8}) {
       run<1>("dependent chain (ILP=1)", b, ncu);
       run<2>("2 chains (ILP=2)", b, ncu);
       run<4>("4 chains (ILP=4)", b, ncu);

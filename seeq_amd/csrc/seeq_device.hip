@@ -86,7 +86,7 @@ struct Counters {
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
    uint32_t seg_tmp_hits;   /* k_fused: hit lines of this segment (summed per workgroup) */
-   uint32_t need_slice;     /* k_fused: largest per-workgroup hit count of this segment */
+   uint32_t pad1;
    uint32_t pad2;
    uint64_t need_records;   /* total */
 };
@@ -481,6 +481,7 @@ __global__ void k_single_line(ScanArgs a)
 }
 
 #include "seeq_fused.h"
+#include "seeq_direct.h"
 
 /* ========================================================================== */
 /* Synthetic reads (bench / test input; CPU twin: oracle/seeq_oracle.c)        */
@@ -621,6 +622,7 @@ struct seeqdev_scan {
    /* fused path */
    uint32_t *tile_cl, *tile_hits; size_t cap_ftiles;
    uint32_t *wg_hits;             /* [MAX_FUSED_GRID] */
+   uint32_t *wg_part;             /* [3 * MAX_FUSED_GRID] */
    uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
    const seeqdev_pattern *eq_pat; int eq_options;
    double avg_line;               /* average bytes per line incl. newline (hint or sampled) */
@@ -681,6 +683,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 256 * sizeof(uint32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
    if (e == hipSuccess) e = hipMalloc((void **)&s->wg_hits, MAX_FUSED_GRID * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipMalloc((void **)&s->wg_part, 3 * MAX_FUSED_GRID * sizeof(uint32_t));
    {
       const char *pe = getenv("SEEQ_PATH");
       s->force_path = pe ? (!strcmp(pe, "generic") ? 1 : !strcmp(pe, "fused") ? 2 : 0) : 0;
@@ -697,7 +700,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
 {
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
-   void *bufs[] = {s->wg_hits, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+   void *bufs[] = {s->wg_hits, s->wg_part, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->d_eqtab,
                    s->nh, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
@@ -870,7 +873,26 @@ static int run_segments(seeqdev_scan *s)
    size_t fused_lds = 0;
    int nw = FUSED_NW_DEFAULT;
    uint32_t halo = 0;
+   unsigned nslices = 1;                      /* hit slices: one per k_fused workgroup / per k_direct wave */
+   bool use_direct = false;
    if (use_fused) {
+      const char *ke = getenv("SEEQ_FUSED_KERNEL");
+      use_direct = !(ke && !strcmp(ke, "lds"));                   /* default: k_direct (text in registers) */
+      if (use_direct && s->avg_line * 62.0 > 16.0 * 1024 - 64) use_direct = false;   /* regions are <= 16 KiB */
+      const char *te = getenv("SEEQ_TILE_BYTES");
+      if (use_direct) {
+         nw = 4;
+         double want = s->avg_line * 62.0;
+         if (want < 512) want = 512;
+         tile_bytes = ((uint32_t)want) & ~15u;
+         if (te && atoi(te) >= 512 && atoi(te) <= DIRECT_MAXRR * 1024) tile_bytes = (uint32_t)atoi(te) & ~15u;
+         int per_cu = 0;
+         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+         fused_grid = (unsigned)(ncu * per_cu);
+         if ((size_t)fused_grid * 4 > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / 4);
+         nslices = fused_grid * 4;
+      } else {
       const char *ne = getenv("SEEQ_FUSED_NW");
       if (ne && (atoi(ne) == 1 || atoi(ne) == 2 || atoi(ne) == 4)) nw = atoi(ne);
       double want_tile = s->avg_line * (64.0 * nw - 2.0 - nw);
@@ -884,7 +906,6 @@ static int run_segments(seeqdev_scan *s)
       if (want_tile > 56.0 * 1024) want_tile = 56.0 * 1024;
       if (want_tile < (double)FUSED_MIN_TILE) want_tile = (double)FUSED_MIN_TILE;
       tile_bytes = ((uint32_t)want_tile) & ~15u;
-      const char *te = getenv("SEEQ_TILE_BYTES");
       if (te && atoi(te) >= (int)FUSED_MIN_TILE && atoi(te) <= (int)max_tile) tile_bytes = (uint32_t)atoi(te) & ~15u;
       const void *kfn = nw == 1 ? (const void *)k_fused<1> : nw == 2 ? (const void *)k_fused<2> : (const void *)k_fused<4>;
       fused_lds = nw == 1 ? fused_lds_bytes<1>(tile_bytes, halo) : nw == 2 ? fused_lds_bytes<2>(tile_bytes, halo)
@@ -897,6 +918,8 @@ static int run_segments(seeqdev_scan *s)
       if (oe != hipSuccess || per_cu < 1) per_cu = 1;
       fused_grid = (unsigned)(ncu * per_cu);
       if (fused_grid > MAX_FUSED_GRID) fused_grid = MAX_FUSED_GRID;
+      nslices = fused_grid;
+      }
       if (s->eq_pat != pat || s->eq_options != options) {
          /* EQ[byte]: top-aligned Peq word of the byte's class, or a flag (reference seeqcore.h:89-111 folded
             with the non-DNA option, libseeq.c:223-228,265-270) */
@@ -914,7 +937,7 @@ static int run_segments(seeqdev_scan *s)
          s->eq_options = options;
       }
    }
-   s->last_path = use_fused ? 2 : 1;
+   s->last_path = use_fused ? (use_direct ? 3 : 2) : 1;
 
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
@@ -957,21 +980,22 @@ static int run_segments(seeqdev_scan *s)
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
-         f.wg_hits = s->wg_hits;
+         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part;
          { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
-         const unsigned fgrid = f.ntiles < fused_grid ? f.ntiles : fused_grid;
-         f.slice_cap = f.cap_tmp / fgrid;
-         if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
+         const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */
+         f.slice_cap = f.cap_tmp / nslices;
+         if (use_direct) hipLaunchKernelGGL(k_direct<4>, dim3(fgrid), dim3(256), 0, s->stream, f);
+         else if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
          else if (nw == 2) hipLaunchKernelGGL(k_fused<2>, dim3(fgrid), dim3(128), fused_lds, s->stream, f);
          else hipLaunchKernelGGL(k_fused<4>, dim3(fgrid), dim3(256), fused_lds, s->stream, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
-         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(1), 0, s->stream, f, (uint32_t)fgrid);
+         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, s->stream, f, (uint32_t)nslices);
          if (want != SEEQDEV_WANT_COUNTLINES) {
             launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
-            hipLaunchKernelGGL(k_fused_reorder, dim3(fgrid), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
+            hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
             hipLaunchKernelGGL(k_clear_tmp, dim3(1), dim3(1), 0, s->stream, c);
          }
       } else {

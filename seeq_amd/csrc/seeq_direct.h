@@ -1,0 +1,271 @@
+/*
+ * seeq_direct.h -- k_direct: the register-resident variant of the fused hot kernel.
+ *
+ * Same job and same outputs as k_fused (seeq_fused.h): newline index + per-line Myers filter +
+ * ordered hit-line compaction in ONE pass over the text (reference seeq.c:361-380 +
+ * libseeq.c:250-275), patterns of <= 30 positions.  What differs is where a lane's text lives:
+ *
+ *   k_fused  : a ~250-line tile per workgroup is staged in LDS and stays there while the lanes
+ *              walk their lines -> the number of lines resident per CU (hence waves per SIMD: 3)
+ *              is capped by the 160 KB of LDS;
+ *   k_direct : every WAVE works alone on a ~62-line region.  It reads the region once with
+ *              coalesced 16-byte loads (HBM) only to find the newlines (SWAR test + DPP wave scans,
+ *              all in registers), then every lane loads ITS OWN line straight into VGPRs, 160
+ *              characters (10 x dwordx4, all in flight together; L2 hits, the bytes were just
+  LDS only holds the
+ *              256-entry EQ table and 64..256 line starts per wave, so occupancy is bounded by
+ *              VGPRs (~100 -> 5 waves/SIMD) and the ~10-cycle dependent-issue latency of the
+ *              integer pipe is covered.  No workgroup barriers, no atomics.
+ *
+ * Lines of any length are handled by the same loop (one 160-character window after the other).
+ */
+#ifndef SEEQ_DIRECT_H_
+#define SEEQ_DIRECT_H_
+
+#define DIRECT_MAXRR   16      /* coalesced rounds of 1 KiB per region: region <= 16 KiB       */
+#define DIRECT_SCAP    128     /* line starts kept in LDS per wave and pass                    */
+
+/* 16 bytes at an arbitrary address; bytes at or beyond `nbytes` read as NUL.  The guarded branch only
+ * runs for the last few lines of a buffer: a rolled byte loop keeps it small (no unrolled byte loads to
+ * inflate the register budget of the hot path). */
+__device__ __forceinline__ fused_v4u direct_load16(const uint8_t *text, uint64_t off, uint64_t nbytes)
+{
+   if (off + 16 <= nbytes) return *reinterpret_cast<const fused_v4u_unaligned *>(text + off);
+   uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll 1
+   for (int k = 15; k >= 0; k--) {
+      const uint32_t b = off + (uint64_t)k < nbytes ? (uint32_t)text[off + k] : 0u;
+      w3 = (w3 << 8) | (w2 >> 24);
+      w2 = (w2 << 8) | (w1 >> 24);
+      w1 = (w1 << 8) | (w0 >> 24);
+      w0 = (w0 << 8) | b;
+   }
+   return fused_v4u{w0, w1, w2, w3};
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
+{
+   __shared__ uint32_t s_eq[256];
+   __shared__ uint32_t s_starts_all[NW][DIRECT_SCAP];
+
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   uint32_t *s_starts = s_starts_all[wave];
+   const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
+   const uint32_t tau = (uint32_t)a.tau;
+   const uint32_t TB = a.tile_bytes;
+   const uint32_t two = 2u;
+
+   for (int i = tid; i < 256; i += 64 * NW) s_eq[i] = a.eqtab[i];
+   __syncthreads();                                       /* the only barrier: tables are read-only from here */
+   typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+   const uint32_t eq_base = (uint32_t)(uintptr_t)(lds_cu32 *)s_eq;   /* LDS byte offset of the table */
+
+   const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
+   uint32_t wv_lines = 0, wv_hdrs = 0, wv_hitlines = 0, slice_pos = 0;
+   bool wv_overflow = false;
+   uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
+   const uint64_t last = a.nbytes - 1;
+
+   for (uint32_t region = gwave; region < a.ntiles; region += nwaves) {
+      const uint64_t t0 = a.seg_base + (uint64_t)region * TB;
+      const uint32_t tb = (uint32_t)(((uint64_t)a.seg_len - (uint64_t)region * TB) < TB
+                                     ? ((uint64_t)a.seg_len - (uint64_t)region * TB) : TB);
+      /* ---- 1. coalesced read of the region; newline masks; ranks ---- */
+      const uint32_t rr = (tb + 1023) >> 10;                                /* <= DIRECT_MAXRR */
+      uint32_t packed[DIRECT_MAXRR / 2];                                    /* 16-bit newline mask per round */
+      uint32_t myrank[DIRECT_MAXRR / 2];                                    /* rank of my first newline, 16 bits per round */
+      uint32_t running = (a.first_seg && region == 0) ? 1u : 0u;            /* the line starting at byte 0 */
+      const uint32_t extra = running;
+#pragma unroll
+      for (int rb = 0; rb < DIRECT_MAXRR; rb += 8) {
+         fused_v4u pre[8];                                                  /* 8 KiB of the region in flight per wave */
+         if ((uint32_t)rb < rr) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+               const uint32_t q0 = ((uint32_t)(rb + i) * 64 + lane) * 16;
+               pre[i] = fused_v4u{0, 0, 0, 0};
+               if ((uint32_t)(rb + i) < rr && q0 < tb) pre[i] = direct_load16(a.text, t0 + q0, a.nbytes);
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < 8; i++) {
+            const int r = rb + i;
+            uint32_t m16 = 0;
+            const uint32_t q0 = ((uint32_t)r * 64 + lane) * 16;
+            if ((uint32_t)r < rr) {                                         /* wave-uniform */
+               const fused_v4u v = pre[i];
+               const uint32_t x0 = v.x ^ 0x0A0A0A0Au, x1 = v.y ^ 0x0A0A0A0Au, x2 = v.z ^ 0x0A0A0A0Au, x3 = v.w ^ 0x0A0A0A0Au;
+               const uint32_t any = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) |
+                                     ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
+               if (any && q0 < tb) {
+                  const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
+                  m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
+                        ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
+                  if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;          /* newline must be owned: q < tb   */
+                  if (t0 + q0 <= last && last < t0 + q0 + 16)               /* ... and not the last byte       */
+                     m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
+               }
+               const uint32_t c = (uint32_t)__popc(m16);
+               const uint32_t incl = wave_incl_scan_u32(c);
+               const uint32_t first = running + incl - c;                   /* rank of my first newline */
+               running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+               if (r & 1) { packed[r >> 1] |= m16 << 16; myrank[r >> 1] |= first << 16; }
+               else       { packed[r >> 1] = m16;        myrank[r >> 1] = first & 0xFFFFu; }
+            } else if (!(r & 1)) {
+               packed[r >> 1] = 0; myrank[r >> 1] = 0;
+            }
+         }
+      }
+      const uint32_t nl = running;                                          /* raw lines owned by the region */
+      /* ranks are kept in 16 bits: a 16 KiB region owns at most 16 K lines */
+
+      uint32_t reg_hdrs = 0, reg_hits = 0;
+      for (uint32_t p0 = 0; p0 < nl; p0 += DIRECT_SCAP) {
+         const uint32_t npass = nl - p0 < DIRECT_SCAP ? nl - p0 : DIRECT_SCAP;
+         /* ---- 2. line starts of this pass -> LDS (per wave) ---- */
+         if (extra && p0 == 0 && lane == 0) s_starts[0] = 0;
+#pragma unroll
+         for (int r = 0; r < DIRECT_MAXRR; r++) {
+            uint32_t mm = (packed[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+            uint32_t rk = (myrank[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+            while (mm) {
+               const uint32_t b = (uint32_t)__builtin_ctz(mm);
+               mm &= mm - 1;
+               if (rk >= p0 && rk < p0 + DIRECT_SCAP) s_starts[rk - p0] = ((uint32_t)r * 64 + lane) * 16 + b + 1;
+               rk++;
+            }
+         }
+         __builtin_amdgcn_wave_barrier();
+         /* ---- 3. one line per lane, text in registers ---- */
+         for (uint32_t b0 = 0; b0 < npass; b0 += 64) {
+            const uint32_t rl = b0 + lane;
+            bool active = rl < npass;
+            const uint32_t lstart = active ? s_starts[rl] : 0;             /* offset of the line inside the region */
+            const uint64_t lbase = t0 + lstart;                            /* absolute offset */
+            uint32_t ahead = 0;                                            /* bytes of my line requested so far */
+            uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = (uint32_t)a.m, minscore = (uint32_t)a.m;
+            bool hit = false, hdr = false;
+            if (a.debug & 1u) active = false;
+            /* next 16 bytes of my line; lanes that are done keep re-reading their last (cached) chunk */
+            auto next_chunk = [&]() -> fused_v4u {
+               const uint64_t o = lbase + ahead;
+               fused_v4u v;
+               if (!__any(o + 16 > a.nbytes)) v = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + o);
+               else v = direct_load16(a.text, o, a.nbytes);
+               if (active) ahead += 16;
+               return v;
+            };
+            /* one 16-character chunk from registers: EQ lookups, flag test, 16 Myers steps */
+            auto process = [&](const fused_v4u &q) {
+               uint32_t eq[16];
+#pragma unroll
+               for (int k = 0; k < 16; k += 4) {
+                  const uint32_t word = k == 0 ? q.x : k == 4 ? q.y : k == 8 ? q.z : q.w;
+                  uint32_t a0, a1, a2, a3;
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+                      : "=v"(a0) : "v"(two), "v"(word));
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+                      : "=v"(a1) : "v"(two), "v"(word));
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"
+                      : "=v"(a2) : "v"(two), "v"(word));
+                  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+                      : "=v"(a3) : "v"(two), "v"(word));
+                  eq[k + 0] = *(lds_cu32 *)(uintptr_t)(eq_base + a0);
+                  eq[k + 1] = *(lds_cu32 *)(uintptr_t)(eq_base + a1);
+                  eq[k + 2] = *(lds_cu32 *)(uintptr_t)(eq_base + a2);
+                  eq[k + 3] = *(lds_cu32 *)(uintptr_t)(eq_base + a3);
+               }
+               uint32_t fl[4];
+#pragma unroll
+               for (int g = 0; g < 4; g++)
+                  fl[g] = (eq[4 * g] | eq[4 * g + 1] | eq[4 * g + 2] | eq[4 * g + 3]) & FUSED_FLAGS;
+               const uint32_t flall = fl[0] | fl[1] | fl[2] | fl[3];
+               if (!__any(active && flall != 0)) {
+#pragma unroll
+                  for (int k = 0; k < 16; k++) {
+                     fused_step(eq[k], pv, mv, score);
+                     minscore = score < minscore ? score : minscore;
+                  }
+               } else {
+#pragma unroll
+                  for (int g = 0; g < 4; g++) {
+                     if (!__any(active && fl[g] != 0)) {
+#pragma unroll
+                        for (int k = 4 * g; k < 4 * g + 4; k++) {
+                           fused_step(eq[k], pv, mv, score);
+                           minscore = score < minscore ? score : minscore;
+                        }
+                     } else {
+#pragma unroll
+                        for (int k = 4 * g; k < 4 * g + 4; k++) {
+                           if (active) {
+                              const uint32_t e = eq[k];
+                              if ((e & FUSED_FLAGS) == 0) {
+                                 fused_step(e, pv, mv, score);
+                                 minscore = score < minscore ? score : minscore;
+                              } else if (e & FUSED_FLAG_TERM) {
+                                 active = false;                            /* line over: latch the verdict */
+                                 hit = minscore <= tau;
+                              }
+                           }
+                        }
+                     }
+                  }
+               }
+            };
+            /* software pipeline: two chunks always in flight ahead of the one being computed */
+            fused_v4u q0 = next_chunk(), q1 = next_chunk(), q2;
+            if (fasta && active && (q0.x & 0xFFu) == '>') { hdr = true; active = false; }
+            while (__any(active)) {
+               q2 = next_chunk();
+               process(q0);
+               if (!__any(active)) break;
+               q0 = next_chunk();
+               process(q1);
+               if (!__any(active)) break;
+               q1 = next_chunk();
+               process(q2);
+            }
+            /* ---- 4. ordered compaction: per-wave slice, no atomics ---- */
+            const uint64_t hm = __ballot(hit), dm = __ballot(hdr);
+            const uint32_t nh = (uint32_t)__popcll(hm);
+            if (nh && a.want != SEEQDEV_WANT_COUNTLINES) {
+               if (slice_pos + nh <= a.slice_cap) {
+                  if (hit) {
+                     const uint32_t below_h = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0));
+                     const uint32_t below_d = __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0));
+                     const uint32_t crank = p0 + rl - (reg_hdrs + below_d);  /* counted rank inside the region */
+                     const uint64_t start_seg = (uint64_t)region * TB + lstart;
+                     slice[slice_pos + below_h] = make_uint4(region, reg_hits + below_h, (uint32_t)start_seg, crank);
+                  }
+                  slice_pos += nh;
+               } else {
+                  wv_overflow = true;
+               }
+            }
+            reg_hits += nh;
+            reg_hdrs += (uint32_t)__popcll(dm);
+         }
+         __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) {
+         a.tile_cl[region] = nl - reg_hdrs;
+         a.tile_hits[region] = reg_hits;
+      }
+      wv_lines += nl;
+      wv_hdrs += reg_hdrs;
+      wv_hitlines += reg_hits;
+   }
+   if (lane == 0) {
+      a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
+      a.wg_part[3 * gwave + 0] = wv_lines;
+      a.wg_part[3 * gwave + 1] = wv_hdrs;
+      a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
+   }
+}
+
+#endif

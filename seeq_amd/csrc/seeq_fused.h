@@ -56,7 +56,8 @@ struct FusedArgs {
    uint4         *tmp;         /* hit entries {tile, seq, start, counted rank}: one slice per workgroup */
    uint32_t       cap_tmp;     /* total entries                                */
    uint32_t       slice_cap;   /* entries per workgroup slice = cap_tmp / grid  */
-   uint32_t      *wg_hits;     /* per workgroup: entries stored in its slice   */
+   uint32_t      *wg_hits;     /* per slice (workgroup of k_fused / wave of k_direct): entries stored */
+   uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31}               */
    uint32_t       debug;       /* profiling experiments only (SEEQ_FUSED_DEBUG): 1 = skip the per-line scan */
    Counters      *cnt;
 };
@@ -410,27 +411,57 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
       wg_hitlines += tile_hits;
    }
    if (tid == 0) {
-      if (wg_lines) atomicAdd(&a.cnt->seg_nlines, wg_lines);
-      if (wg_hdrs) atomicAdd(&a.cnt->seg_nheaders, wg_hdrs);
-      if (wg_hitlines) atomicAdd(&a.cnt->seg_tmp_hits, wg_hitlines);
-      atomicMax(&a.cnt->need_slice, wg_hitlines);
-      if (wg_overflow) atomicOr(&a.cnt->overflow, 2u);
       a.wg_hits[blockIdx.x] = wg_overflow ? 0u : slice_pos;
+      a.wg_part[3 * blockIdx.x + 0] = wg_lines;
+      a.wg_part[3 * blockIdx.x + 1] = wg_hdrs;
+      a.wg_part[3 * blockIdx.x + 2] = wg_overflow ? (wg_hitlines | 0x80000000u) : wg_hitlines;
    }
 }
 
-/* After k_fused: publish the hit-line count of the segment (or the overflow). */
-__global__ void k_fused_post(FusedArgs a, uint32_t grid)
+/* After k_fused / k_direct: reduce the per-slice partial counts (no atomics in the hot kernels)
+   and publish the hit-line count of the segment, or the overflow. */
+__global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslices)
 {
-   Counters *c = a.cnt;
-   uint32_t n = c->seg_tmp_hits;
-   /* capacity wanted next time: every slice as large as the fullest one, plus slack */
-   const uint64_t need = (uint64_t)c->need_slice * grid + (uint64_t)grid * 64;
-   if (need > c->need_hitlines) c->need_hitlines = need > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need;
-   if (c->overflow & 2u) n = 0;
-   c->seg_nhitlines = n;
-   c->seg_tmp_hits = 0;
-   c->need_slice = 0;
+   __shared__ uint32_t s_red[4][4];
+   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0;
+   for (uint32_t i = threadIdx.x; i < nslices; i += 256) {
+      lines += a.wg_part[3 * i + 0];
+      hdrs += a.wg_part[3 * i + 1];
+      const uint32_t h = a.wg_part[3 * i + 2];
+      hits += h & 0x7FFFFFFFu;
+      mx = (h & 0x7FFFFFFFu) > mx ? (h & 0x7FFFFFFFu) : mx;
+      ovf |= h >> 31;
+   }
+#pragma unroll
+   for (int d = 32; d >= 1; d >>= 1) {
+      lines += __shfl_xor(lines, d, 64);
+      hdrs += __shfl_xor(hdrs, d, 64);
+      hits += __shfl_xor(hits, d, 64);
+      const uint32_t o = __shfl_xor(mx, d, 64);
+      mx = o > mx ? o : mx;
+      ovf |= __shfl_xor(ovf, d, 64);
+   }
+   const int w = threadIdx.x >> 6;
+   if ((threadIdx.x & 63) == 0) { s_red[w][0] = lines; s_red[w][1] = hdrs; s_red[w][2] = hits; s_red[w][3] = mx | (ovf << 31); }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      lines = hdrs = hits = mx = ovf = 0;
+      for (int k = 0; k < 4; k++) {
+         lines += s_red[k][0]; hdrs += s_red[k][1]; hits += s_red[k][2];
+         const uint32_t m = s_red[k][3] & 0x7FFFFFFFu;
+         mx = m > mx ? m : mx;
+         ovf |= s_red[k][3] >> 31;
+      }
+      Counters *c = a.cnt;
+      c->seg_nlines = lines;
+      c->seg_nheaders = hdrs;
+      /* capacity wanted next time: every slice as large as the fullest one, plus slack */
+      const uint64_t need = (uint64_t)mx * nslices + (uint64_t)nslices * 64;
+      if (need > c->need_hitlines) c->need_hitlines = need > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need;
+      if (ovf) { atomicOr(&c->overflow, 2u); hits = 0; }
+      c->seg_nhitlines = hits;
+      c->seg_tmp_hits = 0;
+   }
 }
 
 /* Slices -> ordered (hit_start, hit_line).  tile_hits / tile_cl hold exclusive prefixes by now.

@@ -112,8 +112,11 @@ def test_long_pattern_words(gpu, capi, oracle):
 
 def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=None):
     """One batched scan through the device C-ABI.  path: 'generic' (newline index + k_forward<W>),
-    'fused' (k_fused, LDS-staged single pass) or 'auto'; the env knobs are read by seeqdevScanNew."""
+    'fused' = k_direct (text in registers), 'fused-lds' = k_fused (text tiles in LDS), or 'auto';
+    the env knobs are read by the library when the scan runs."""
     from seeq_amd import device as dev
+    os.environ["SEEQ_FUSED_KERNEL"] = "lds" if path == "fused-lds" else "direct"
+    path = "fused" if path == "fused-lds" else path
     os.environ["SEEQ_PATH"] = path
     if tile:
         os.environ["SEEQ_TILE_BYTES"] = str(tile)
@@ -127,10 +130,12 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
     finally:
         os.environ.pop("SEEQ_PATH", None)
         os.environ.pop("SEEQ_TILE_BYTES", None)
+        os.environ.pop("SEEQ_FUSED_KERNEL", None)
     return res
 
 
-@pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 4096)])
+@pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024), ("fused-lds", None),
+                                       ("fused-lds", 4096)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
                                               ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3),
@@ -144,7 +149,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
             exp = oracle.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
             got = _scan(capi, pattern, tau, buf, mo | nd, dev.WANT_RECORDS, fasta, path, tile)
-            assert got["path"] == (path if fusable else "generic")     # the kernel under test really ran
+            assert got["path"] == (path.split("-")[0] if fusable else "generic")     # the kernel under test really ran
             assert got["nlines"] == exp["nlines"]
             assert got["nmatchlines"] == exp["nmatchlines"]
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (name, mo, nd)
@@ -156,7 +161,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
         assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
 
 
-@pytest.mark.parametrize("path", ["generic", "fused"])
+@pytest.mark.parametrize("path", ["generic", "fused", "fused-lds"])
 def test_edge_buffers(gpu, capi, oracle, path):
     """Empty / ragged / maximum-ish inputs: no trailing newline, empty lines, NUL and CR bytes, a line longer
     than the LDS window (fused: falls back to the HBM per-line scan), 70 k empty lines (fused: many passes
@@ -171,11 +176,11 @@ def test_edge_buffers(gpu, capi, oracle, path):
     for buf in cases:
         for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
             exp = oracle.buffer_scan("ACGT", 1, buf, opt)
-            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, 4096 if path == "fused" else None)
+            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, {"fused": 1024, "fused-lds": 4096}.get(path))
             assert got["nlines"] == exp["nlines"], (buf[:20], opt)
             assert got["nmatchlines"] == exp["nmatchlines"], (buf[:20], opt)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (buf[:20], opt)
-            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, 4096 if path == "fused" else None)
+            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, {"fused": 1024, "fused-lds": 4096}.get(path))
             assert cnt["nmatchlines"] == exp["nmatchlines"] and cnt["nlines"] == exp["nlines"]
 
 
