@@ -44,7 +44,7 @@ __device__ __forceinline__ fused_v4u direct_load16(const uint8_t *text, uint64_t
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
+__global__ __launch_bounds__(64 * NW, 6) void k_direct(FusedArgs a)
 {
    __shared__ uint32_t s_eq[256];
    __shared__ uint32_t s_starts_all[NW][DIRECT_SCAP];
@@ -72,71 +72,65 @@ __global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
       const uint64_t t0 = a.seg_base + (uint64_t)region * TB;
       const uint32_t tb = (uint32_t)(((uint64_t)a.seg_len - (uint64_t)region * TB) < TB
                                      ? ((uint64_t)a.seg_len - (uint64_t)region * TB) : TB);
-      /* ---- 1. coalesced read of the region; newline masks; ranks ---- */
+      /* ---- 1+2. coalesced read of the region; newline masks; ranks; line starts -> LDS ---- */
+      /* One pass keeps DIRECT_SCAP starts; a region with more lines (very short lines) simply runs the
+         pass again for the next window of ranks (the region is in L2 by then).  Nothing per lane has to
+         stay in registers across the per-line scan. */
       const uint32_t rr = (tb + 1023) >> 10;                                /* <= DIRECT_MAXRR */
-      uint32_t packed[DIRECT_MAXRR / 2];                                    /* 16-bit newline mask per round */
-      uint32_t myrank[DIRECT_MAXRR / 2];                                    /* rank of my first newline, 16 bits per round */
-      uint32_t running = (a.first_seg && region == 0) ? 1u : 0u;            /* the line starting at byte 0 */
-      const uint32_t extra = running;
-#pragma unroll
-      for (int rb = 0; rb < DIRECT_MAXRR; rb += 8) {
-         fused_v4u pre[8];                                                  /* 8 KiB of the region in flight per wave */
-         if ((uint32_t)rb < rr) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-               const uint32_t q0 = ((uint32_t)(rb + i) * 64 + lane) * 16;
-               pre[i] = fused_v4u{0, 0, 0, 0};
-               if ((uint32_t)(rb + i) < rr && q0 < tb) pre[i] = direct_load16(a.text, t0 + q0, a.nbytes);
-            }
-         }
-#pragma unroll
-         for (int i = 0; i < 8; i++) {
-            const int r = rb + i;
-            uint32_t m16 = 0;
-            const uint32_t q0 = ((uint32_t)r * 64 + lane) * 16;
-            if ((uint32_t)r < rr) {                                         /* wave-uniform */
-               const fused_v4u v = pre[i];
-               const uint32_t x0 = v.x ^ 0x0A0A0A0Au, x1 = v.y ^ 0x0A0A0A0Au, x2 = v.z ^ 0x0A0A0A0Au, x3 = v.w ^ 0x0A0A0A0Au;
-               const uint32_t any = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) |
-                                     ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
-               if (any && q0 < tb) {
-                  const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
-                  m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
-                        ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
-                  if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;          /* newline must be owned: q < tb   */
-                  if (t0 + q0 <= last && last < t0 + q0 + 16)               /* ... and not the last byte       */
-                     m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
-               }
-               const uint32_t c = (uint32_t)__popc(m16);
-               const uint32_t incl = wave_incl_scan_u32(c);
-               const uint32_t first = running + incl - c;                   /* rank of my first newline */
-               running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-               if (r & 1) { packed[r >> 1] |= m16 << 16; myrank[r >> 1] |= first << 16; }
-               else       { packed[r >> 1] = m16;        myrank[r >> 1] = first & 0xFFFFu; }
-            } else if (!(r & 1)) {
-               packed[r >> 1] = 0; myrank[r >> 1] = 0;
-            }
-         }
-      }
-      const uint32_t nl = running;                                          /* raw lines owned by the region */
-      /* ranks are kept in 16 bits: a 16 KiB region owns at most 16 K lines */
-
-      uint32_t reg_hdrs = 0, reg_hits = 0;
-      for (uint32_t p0 = 0; p0 < nl; p0 += DIRECT_SCAP) {
-         const uint32_t npass = nl - p0 < DIRECT_SCAP ? nl - p0 : DIRECT_SCAP;
-         /* ---- 2. line starts of this pass -> LDS (per wave) ---- */
+      const uint32_t extra = (a.first_seg && region == 0) ? 1u : 0u;        /* the line starting at byte 0 */
+      const bool region_safe = t0 + (uint64_t)DIRECT_MAXRR * 1024 + 16 <= a.nbytes;   /* wave-uniform */
+      uint32_t nl = 0, reg_hdrs = 0, reg_hits = 0;
+      /* opaque per iteration: keeps the compiler from hoisting 16 rounds of per-lane 64-bit addresses out
+         of the region loop (loop-invariant code motion there costs ~60 VGPRs and forces spills) */
+      for (uint32_t p0 = 0; p0 == 0 || p0 < nl; p0 += DIRECT_SCAP) {
+         uint32_t lane16 = (uint32_t)lane * 16;
+         asm volatile("" : "+v"(lane16));
+         uint32_t running = extra;
          if (extra && p0 == 0 && lane == 0) s_starts[0] = 0;
 #pragma unroll
-         for (int r = 0; r < DIRECT_MAXRR; r++) {
-            uint32_t mm = (packed[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
-            uint32_t rk = (myrank[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
-            while (mm) {
-               const uint32_t b = (uint32_t)__builtin_ctz(mm);
-               mm &= mm - 1;
-               if (rk >= p0 && rk < p0 + DIRECT_SCAP) s_starts[rk - p0] = ((uint32_t)r * 64 + lane) * 16 + b + 1;
-               rk++;
+         for (int rb = 0; rb < DIRECT_MAXRR; rb += 8) {
+            if ((uint32_t)rb < rr) {                                        /* wave-uniform */
+               fused_v4u pre[8];                                            /* 8 KiB of the region in flight per wave */
+#pragma unroll
+               for (int i = 0; i < 8; i++) {
+                  const uint32_t q0 = (uint32_t)(rb + i) * 1024 + lane16;
+                  if (region_safe) pre[i] = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 + q0);
+                  else pre[i] = direct_load16(a.text, t0 + q0, a.nbytes);
+               }
+#pragma unroll
+               for (int i = 0; i < 8; i++) {
+                  const uint32_t r = (uint32_t)(rb + i);
+                  const uint32_t q0 = r * 1024 + lane16;
+                  if (r < rr) {                                             /* wave-uniform */
+                     const fused_v4u v = pre[i];
+                     const uint32_t x0 = v.x ^ 0x0A0A0A0Au, x1 = v.y ^ 0x0A0A0A0Au, x2 = v.z ^ 0x0A0A0A0Au, x3 = v.w ^ 0x0A0A0A0Au;
+                     const uint32_t any = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) |
+                                           ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
+                     uint32_t m16 = 0;
+                     if (any && q0 < tb) {
+                        const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
+                        m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
+                              ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
+                        if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;    /* newline must be owned: q < tb   */
+                        if (t0 + q0 <= last && last < t0 + q0 + 16)         /* ... and not the last byte       */
+                           m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
+                     }
+                     const uint32_t c = (uint32_t)__popc(m16);
+                     const uint32_t incl = wave_incl_scan_u32(c);
+                     uint32_t rk = running + incl - c;                      /* rank of my first newline */
+                     running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                     while (m16) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(m16);
+                        m16 &= m16 - 1;
+                        if (rk >= p0 && rk < p0 + DIRECT_SCAP) s_starts[rk - p0] = q0 + b + 1;
+                        rk++;
+                     }
+                  }
+               }
             }
          }
+         nl = running;                                                      /* raw lines owned by the region */
+         const uint32_t npass = nl - p0 < DIRECT_SCAP ? nl - p0 : DIRECT_SCAP;
          __builtin_amdgcn_wave_barrier();
          /* ---- 3. one line per lane, text in registers ---- */
          for (uint32_t b0 = 0; b0 < npass; b0 += 64) {
@@ -221,12 +215,8 @@ __global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
             while (__any(active)) {
                q2 = next_chunk();
                process(q0);
-               if (!__any(active)) break;
-               q0 = next_chunk();
-               process(q1);
-               if (!__any(active)) break;
-               q1 = next_chunk();
-               process(q2);
+               q0 = q1;                                                     /* rotate: 8 moves per 16 characters */
+               q1 = q2;
             }
             /* ---- 4. ordered compaction: per-wave slice, no atomics ---- */
             const uint64_t hm = __ballot(hit), dm = __ballot(hdr);
