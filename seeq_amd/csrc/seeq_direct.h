@@ -44,7 +44,7 @@ __device__ __forceinline__ fused_v4u direct_load16(const uint8_t *text, uint64_t
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 6) void k_direct(FusedArgs a)
+__global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
 {
    __shared__ uint32_t s_eq[256];
    __shared__ uint32_t s_starts_all[NW][DIRECT_SCAP];
@@ -142,14 +142,21 @@ __global__ __launch_bounds__(64 * NW, 6) void k_direct(FusedArgs a)
             uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = (uint32_t)a.m, minscore = (uint32_t)a.m;
             bool hit = false, hdr = false;
             if (a.debug & 1u) active = false;
-            /* next 16 bytes of my line; lanes that are done keep re-reading their last (cached) chunk */
-            auto next_chunk = [&]() -> fused_v4u {
+            /* next 64 bytes of my line as four back-to-back 16-byte loads: they fall into one or two
+               cache lines, so L1 merges them into one L2 request per line (a lane-strided stream of
+               single 16-byte loads would fetch every line from L2 eight times).  Lanes that are done keep
+               re-reading their last (cached) position. */
+            auto next_block = [&](fused_v4u (&v)[4]) {
                const uint64_t o = lbase + ahead;
-               fused_v4u v;
-               if (!__any(o + 16 > a.nbytes)) v = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + o);
-               else v = direct_load16(a.text, o, a.nbytes);
-               if (active) ahead += 16;
-               return v;
+               if (!__any(o + 64 > a.nbytes)) {
+                  const uint8_t *p = a.text + o;
+#pragma unroll
+                  for (int c = 0; c < 4; c++) v[c] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * c);
+               } else {
+#pragma unroll
+                  for (int c = 0; c < 4; c++) v[c] = direct_load16(a.text, o + 16 * c, a.nbytes);
+               }
+               if (active) ahead += 64;
             };
             /* one 16-character chunk from registers: EQ lookups, flag test, 16 Myers steps */
             auto process = [&](const fused_v4u &q) {
@@ -209,14 +216,17 @@ __global__ __launch_bounds__(64 * NW, 6) void k_direct(FusedArgs a)
                   }
                }
             };
-            /* software pipeline: two chunks always in flight ahead of the one being computed */
-            fused_v4u q0 = next_chunk(), q1 = next_chunk(), q2;
-            if (fasta && active && (q0.x & 0xFFu) == '>') { hdr = true; active = false; }
+            /* software pipeline: the next 64 bytes are in flight while the current 64 are computed */
+            fused_v4u cur[4], nxt[4];
+            next_block(cur);
+            if (fasta && active && (cur[0].x & 0xFFu) == '>') { hdr = true; active = false; }
             while (__any(active)) {
-               q2 = next_chunk();
-               process(q0);
-               q0 = q1;                                                     /* rotate: 8 moves per 16 characters */
-               q1 = q2;
+               next_block(nxt);
+#pragma unroll
+               for (int c = 0; c < 4; c++)
+                  if (__any(active)) process(cur[c]);
+#pragma unroll
+               for (int c = 0; c < 4; c++) cur[c] = nxt[c];
             }
             /* ---- 4. ordered compaction: per-wave slice, no atomics ---- */
             const uint64_t hm = __ballot(hit), dm = __ballot(hdr);

@@ -32,9 +32,9 @@
 #define FUSED_FLAGS     3u
 #define FUSED_MAX_WLEN  30      /* 32-bit word minus the two flag bits         */
 #define FUSED_HALO_MAX  1024    /* bytes staged beyond the tile (runtime, <= this): longest line handled from LDS */
-#define FUSED_CAPL_PER_THREAD 4 /* line starts kept in LDS per pass = this * threads */
+#define FUSED_CAPL_PER_THREAD 2 /* line starts kept in LDS per pass = this * threads */
 #define FUSED_MAXR      16      /* newline-detection rounds: tile <= MAXR * threads * 16 bytes */
-#define FUSED_MAXS      12      /* staging rounds: tile + halo <= MAXS * threads * 16 bytes        */
+#define FUSED_MAXS      10      /* staging rounds: tile + halo <= MAXS * threads * 16 bytes        */
 
 typedef unsigned int fused_v4u __attribute__((ext_vector_type(4)));
 typedef fused_v4u fused_v4u_unaligned __attribute__((aligned(1)));   /* the text pointer may have any alignment */
