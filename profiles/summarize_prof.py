@@ -31,7 +31,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_sq2"):
             k = r.get("Kernel_Name", "")[:48]
             agg[k][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
 for k in sorted(agg):
-    if not any(s in k for s in ("k_forward", "k_nl_", "k_exact", "k_fused", "k_scan", "k_compact")):
+    if not any(s in k for s in ("k_forward", "k_nl_", "k_exact", "k_fused", "k_direct", "k_scan", "k_compact")):
         continue
     print(k)
     for c in sorted(agg[k]):

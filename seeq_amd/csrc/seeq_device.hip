@@ -882,7 +882,7 @@ static int run_segments(seeqdev_scan *s)
       const char *te = getenv("SEEQ_TILE_BYTES");
       if (use_direct) {
          nw = 4;
-         double want = s->avg_line * 62.0;
+         double want = s->avg_line * 63.5;                /* <= 64 lines per region: one per lane */
          if (want < 512) want = 512;
          tile_bytes = ((uint32_t)want) & ~15u;
          if (te && atoi(te) >= 512 && atoi(te) <= DIRECT_MAXRR * 1024) tile_bytes = (uint32_t)atoi(te) & ~15u;

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
       const uint32_t rr = (tb + 1023) >> 10;                                /* <= DIRECT_MAXRR */
       const uint32_t extra = (a.first_seg && region == 0) ? 1u : 0u;        /* the line starting at byte 0 */
       const bool region_safe = t0 + (uint64_t)DIRECT_MAXRR * 1024 + 16 <= a.nbytes;   /* wave-uniform */
+      const bool region_plain = region_safe && t0 + (uint64_t)tb <= last;              /* no owned byte is the last one */
       uint32_t nl = 0, reg_hdrs = 0, reg_hits = 0;
       /* opaque per iteration: keeps the compiler from hoisting 16 rounds of per-lane 64-bit addresses out
          of the region loop (loop-invariant code motion there costs ~60 VGPRs and forces spills) */
@@ -107,11 +108,14 @@ __global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
                      const uint32_t any = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) |
                                            ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
                      uint32_t m16 = 0;
-                     if (any && q0 < tb) {
+                     if (any) {                                             /* cheap superset test, exact mask only then */
                         const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
                         m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
                               ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
-                        if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;    /* newline must be owned: q < tb   */
+                     }
+                     if (!region_plain || (r + 1) * 1024 > tb) {            /* wave-uniform: edges of the owned range */
+                        if (q0 >= tb) m16 = 0;
+                        else if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;   /* a newline must be owned: q < tb */
                         if (t0 + q0 <= last && last < t0 + q0 + 16)         /* ... and not the last byte       */
                            m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
                      }
