@@ -116,7 +116,7 @@ struct ScanArgs {
 static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
 static constexpr size_t FUSED_MIN_TILE = 2048;   /* smallest text tile of k_fused */
-static constexpr int FUSED_NW_DEFAULT = 2;        /* waves per k_fused workgroup (SEEQ_FUSED_NW=1|2|4) */
+static constexpr int FUSED_NW_DEFAULT = 4;        /* waves per k_fused workgroup (SEEQ_FUSED_NW=1|2|4) */
 static constexpr size_t MAX_FUSED_GRID = 16384;   /* upper bound of the persistent k_fused grid */
 static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate the line length */
 
@@ -906,6 +906,12 @@ static int run_segments(seeqdev_scan *s)
       if (want_tile > 56.0 * 1024) want_tile = 56.0 * 1024;
       if (want_tile < (double)FUSED_MIN_TILE) want_tile = (double)FUSED_MIN_TILE;
       tile_bytes = ((uint32_t)want_tile) & ~15u;
+      if (nw == 4) {
+         /* four workgroups per CU (16 waves) beat three slightly larger tiles: keep the tile inside a
+            quarter of the 160 KiB LDS */
+         const uint32_t budget = (uint32_t)(40960 - FusedLds<4>::TEXT - halo - 32) & ~15u;
+         if (tile_bytes > budget) tile_bytes = budget;
+      }
       if (te && atoi(te) >= (int)FUSED_MIN_TILE && atoi(te) <= (int)max_tile) tile_bytes = (uint32_t)atoi(te) & ~15u;
       const void *kfn = nw == 1 ? (const void *)k_fused<1> : nw == 2 ? (const void *)k_fused<2> : (const void *)k_fused<4>;
       fused_lds = nw == 1 ? fused_lds_bytes<1>(tile_bytes, halo) : nw == 2 ? fused_lds_bytes<2>(tile_bytes, halo)

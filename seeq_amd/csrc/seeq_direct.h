@@ -23,6 +23,7 @@
 #define SEEQ_DIRECT_H_
 
 #define DIRECT_MAXRR   16      /* coalesced rounds of 1 KiB per region: region <= 16 KiB       */
+#define DIRECT_WIN     10      /* 16-byte chunks of a line loaded into registers at once      */
 #define DIRECT_SCAP    128     /* line starts kept in LDS per wave and pass                    */
 
 /* 16 bytes at an arbitrary address; bytes at or beyond `nbytes` read as NUL.  The guarded branch only
@@ -44,7 +45,7 @@ __device__ __forceinline__ fused_v4u direct_load16(const uint8_t *text, uint64_t
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
+__global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
 {
    __shared__ uint32_t s_eq[256];
    __shared__ uint32_t s_starts_all[NW][DIRECT_SCAP];
@@ -146,21 +147,17 @@ __global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
             uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = (uint32_t)a.m, minscore = (uint32_t)a.m;
             bool hit = false, hdr = false;
             if (a.debug & 1u) active = false;
-            /* next 64 bytes of my line as four back-to-back 16-byte loads: they fall into one or two
-               cache lines, so L1 merges them into one L2 request per line (a lane-strided stream of
-               single 16-byte loads would fetch every line from L2 eight times).  Lanes that are done keep
-               re-reading their last (cached) position. */
-            auto next_block = [&](fused_v4u (&v)[4]) {
+            auto next_window = [&](fused_v4u (&v)[DIRECT_WIN]) {
                const uint64_t o = lbase + ahead;
-               if (!__any(o + 64 > a.nbytes)) {
+               if (!__any(o + 16 * DIRECT_WIN > a.nbytes)) {
                   const uint8_t *p = a.text + o;
 #pragma unroll
-                  for (int c = 0; c < 4; c++) v[c] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * c);
+                  for (int c = 0; c < DIRECT_WIN; c++) v[c] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * c);
                } else {
 #pragma unroll
-                  for (int c = 0; c < 4; c++) v[c] = direct_load16(a.text, o + 16 * c, a.nbytes);
+                  for (int c = 0; c < DIRECT_WIN; c++) v[c] = direct_load16(a.text, o + 16 * c, a.nbytes);
                }
-               if (active) ahead += 64;
+               if (active) ahead += 16 * DIRECT_WIN;
             };
             /* one 16-character chunk from registers: EQ lookups, flag test, 16 Myers steps */
             auto process = [&](const fused_v4u &q) {
@@ -220,17 +217,20 @@ __global__ __launch_bounds__(64 * NW, 5) void k_direct(FusedArgs a)
                   }
                }
             };
-            /* software pipeline: the next 64 bytes are in flight while the current 64 are computed */
-            fused_v4u cur[4], nxt[4];
-            next_block(cur);
-            if (fasta && active && (cur[0].x & 0xFFu) == '>') { hdr = true; active = false; }
+            /* The next DIRECT_WIN x 16 characters of my line, all loads issued back to back right after the
+               coalesced read of the region: they hit L2 (the lines were fetched microseconds ago) and L1
+               merges the loads that fall into one cache line. */
+            fused_v4u win[DIRECT_WIN];
+            bool first_window = true;
             while (__any(active)) {
-               next_block(nxt);
+               next_window(win);
+               if (first_window) {
+                  if (fasta && active && (win[0].x & 0xFFu) == '>') { hdr = true; active = false; }
+                  first_window = false;
+               }
 #pragma unroll
-               for (int c = 0; c < 4; c++)
-                  if (__any(active)) process(cur[c]);
-#pragma unroll
-               for (int c = 0; c < 4; c++) cur[c] = nxt[c];
+               for (int c = 0; c < DIRECT_WIN; c++)
+                  if (__any(active)) process(win[c]);
             }
             /* ---- 4. ordered compaction: per-wave slice, no atomics ---- */
             const uint64_t hm = __ballot(hit), dm = __ballot(hdr);
