@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_sq2.log" 2>&1
 cd "$REPO"
-python3 profiles/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 profiles/summarize_prof.py "$OUT" ${TEXT_BYTES_TOTAL:-} > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # keep only small files
 find "$OUT" -name "*.csv" -size +8M -delete

@@ -7,6 +7,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+# optional: text bytes scanned by ALL profiled steps together (warm-up included) -> traffic per text byte
+text_bytes_total = float(sys.argv[2]) if len(sys.argv) > 2 else None
 
 
 def find(sub, pat):
@@ -37,3 +39,25 @@ for k in sorted(agg):
     for c in sorted(agg[k]):
         v = agg[k][c]
         print("    %-28s n=%-5d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+
+# Traffic of the dominant scan kernel, priced as MI355X_MICROARCH.md section HBM prescribes:
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
+# (16 B/lane) streaming read, so it is doubled.  The counters sit on the L2's fabric side, so
+# Infinity-Cache hits are included.
+import json
+scan = [k for k in agg if ("k_direct" in k or "k_fused<" in k or "k_forward" in k) and "FETCH_SIZE" in agg[k]]
+if scan:
+    k = max(scan, key=lambda x: sum(agg[x]["FETCH_SIZE"]))
+    f, w = agg[k]["FETCH_SIZE"], agg[k].get("WRITE_SIZE", [0.0])
+    hbm_total = 2.0 * sum(f) * 1024.0 + (sum(w) * 1024.0 * len(f) / max(1, len(w)))
+    res = {"kernel": k.split("(")[0].replace("void ", "").split("<")[0], "dispatches": len(f),
+           "fetch_size_kib_mean": sum(f) / len(f), "write_size_kib_mean": sum(w) / max(1, len(w)),
+           "hbm_bytes_per_launch_mean": hbm_total / len(f),
+           "correction": "2 x FETCH_SIZE (gfx950 wide-read under-count) + WRITE_SIZE, KiB -> bytes"}
+    if text_bytes_total:
+        res["hbm_bytes_per_text_byte"] = hbm_total / text_bytes_total
+    print()
+    print("== scan-kernel traffic ==")
+    print(json.dumps(res, indent=1))
+    with open(os.path.join(out, "pmc_scan_kernel.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
