@@ -482,6 +482,7 @@ __global__ void k_single_line(ScanArgs a)
 
 #include "seeq_fused.h"
 #include "seeq_direct.h"
+#include "seeq_exact1.h"
 
 /* ========================================================================== */
 /* Synthetic reads (bench / test input; CPU twin: oracle/seeq_oracle.c)        */
@@ -679,8 +680,8 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    else { e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking); s->own_stream = true; }
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cnt, sizeof(Counters));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_cnt, sizeof(Counters), hipHostMallocDefault);
-   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 256 * sizeof(uint32_t), hipHostMallocDefault);
-   if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 256 * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 512 * sizeof(uint32_t), hipHostMallocDefault);
+   if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 512 * sizeof(uint32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
    if (e == hipSuccess) e = hipMalloc((void **)&s->wg_hits, MAX_FUSED_GRID * sizeof(uint32_t));
    if (e == hipSuccess) e = hipMalloc((void **)&s->wg_part, 3 * MAX_FUSED_GRID * sizeof(uint32_t));
@@ -929,21 +930,23 @@ static int run_segments(seeqdev_scan *s)
       if (s->eq_pat != pat || s->eq_options != options) {
          /* EQ[byte]: top-aligned Peq word of the byte's class, or a flag (reference seeqcore.h:89-111 folded
             with the non-DNA option, libseeq.c:223-228,265-270) */
-         uint32_t hpeq[5];
-         const char *keys_unused = NULL; (void)keys_unused;
+         uint32_t hpeq[10];                               /* forward [5], reversed pattern [5] (one word each) */
          HIP_TRY(hipMemcpyAsync(hpeq, pat->d_peq, sizeof hpeq, hipMemcpyDeviceToHost, s->stream), EIO);
          HIP_TRY(hipStreamSynchronize(s->stream), EIO);
          for (int b = 0; b < 256; b++) {
             const uint8_t cls = sq_class_of((uint32_t)b, options);
-            s->h_eqtab[b] = cls < 5 ? hpeq[cls] << (32 - pat->wlen) : (cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP);
+            const uint32_t flag = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
+            s->h_eqtab[b] = cls < 5 ? hpeq[cls] << (32 - pat->wlen) : flag;
+            s->h_eqtab[256 + b] = cls < 5 ? hpeq[5 + cls] << (32 - pat->wlen) : flag;
          }
-         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
+         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
          HIP_TRY(hipStreamSynchronize(s->stream), EIO);
          s->eq_pat = pat;
          s->eq_options = options;
       }
    }
    s->last_path = use_fused ? (use_direct ? 3 : 2) : 1;
+   const bool generic_exact = getenv("SEEQ_EXACT") && !strcmp(getenv("SEEQ_EXACT"), "generic");   /* A/B knob */
 
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
@@ -1032,13 +1035,15 @@ static int run_segments(seeqdev_scan *s)
          if (grid_hits == 0) grid_hits = 1;
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
-            hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */
          if (want == SEEQDEV_WANT_RECORDS) {
             hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, s->stream, a);
-            hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            else hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
          }
       }
       hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, need_nh ? 1 : 0);
