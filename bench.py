@@ -45,7 +45,8 @@ def cpu_baseline(sample_lines, workload):
     except Exception:
         pass
     cores = min(cores, multiprocessing.cpu_count())
-    data = orc.synth_reads(0, sample_lines, READ_LEN, PATTERN, TAU)
+    from seeq_amd.device import plain_pattern
+    data = orc.synth_reads(0, sample_lines, READ_LEN, plain_pattern(PATTERN), TAU)
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(tmpdir, "seeq_bench_sample_%d.txt" % os.getpid())
     data.tofile(path)
@@ -89,10 +90,15 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
     ap.add_argument("--workload", choices=["best", "count", "all"], default="best",
                     help="best = configs[2] (--best, positions); count = configs[1] (-c)")
+    ap.add_argument("--pattern", default=globals()["PATTERN"], help="non-default patterns are for experiments (config names them)")
+    ap.add_argument("--distance", type=int, default=globals()["TAU"])
+    ap.add_argument("--read-len", type=int, default=globals()["READ_LEN"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--check-lines", type=int, default=200_000, help="prefix verified against the oracle")
     args = ap.parse_args()
+    PATTERN, TAU, READ_LEN = args.pattern, args.distance, args.read_len
+    globals().update(PATTERN=PATTERN, TAU=TAU, READ_LEN=READ_LEN)      # cpu_baseline() reads the module globals
 
     import numpy as np
     import torch
@@ -115,7 +121,7 @@ def main():
     nbytes = n * (READ_LEN + 1)
     stream = torch.cuda.current_stream().cuda_stream
     text = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    dev.synth_reads(text.data_ptr(), first, n, READ_LEN, PATTERN, TAU, stream=stream)
+    dev.synth_reads(text.data_ptr(), first, n, READ_LEN, dev.plain_pattern(PATTERN), TAU, stream=stream)
     torch.cuda.synchronize()
 
     opt, want = {"best": (dev.SQ_BEST, dev.WANT_RECORDS), "count": (0, dev.WANT_COUNTLINES),
