@@ -113,6 +113,13 @@ int seeqdevScanFetch(seeqdev_scan_t * scan, seeqdev_counts_t * counts);
 /* Hit records of the last fetched scan: device pointer / copy to host. */
 const seeqdev_hit_t * seeqdevScanRecordsDevice(const seeqdev_scan_t * scan);
 int seeqdevScanCopyRecords(seeqdev_scan_t * scan, seeqdev_hit_t * host_out, size_t first, size_t n);
+/* Per record, the byte offset (within the scanned buffer) of the first byte of its line: lets a caller that
+ * holds the text go from hit to hit without walking the lines in between. */
+int seeqdevScanCopyOffsets(seeqdev_scan_t * scan, uint64_t * host_out, size_t first, size_t n);
+
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for buffers handed to seeqdevScanHost. */
+void * seeqdevHostAlloc(size_t bytes);
+void   seeqdevHostFree(void * p);
 
 /* Convenience: host buffer in, counts (+ records) out.  Stages through the
  * context's pinned buffer, H2D, ScanRun, ScanFetch. */

@@ -60,7 +60,7 @@ EXPORTS = [
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
-    "seeqdevScanSetLineHint", "seeqdevScanLastPath",
+    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanCopyOffsets", "seeqdevHostAlloc", "seeqdevHostFree",
 ]
 
 
@@ -151,6 +151,8 @@ def lib():
     L.seeqdevScanRecordsDevice.restype = C.c_void_p
     L.seeqdevScanCopyRecords.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
     L.seeqdevScanCopyRecords.restype = C.c_int
+    L.seeqdevScanCopyOffsets.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.seeqdevScanCopyOffsets.restype = C.c_int
     L.seeqdevScanHost.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int,
                                   P(seeqdev_counts_t)]
     L.seeqdevScanHost.restype = C.c_int

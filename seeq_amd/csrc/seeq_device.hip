@@ -110,6 +110,7 @@ struct ScanArgs {
    uint32_t       cap_hitlines;
    uint32_t      *nh;           /* per hit line: hits, then exclusive offsets */
    seeqdev_hit_t *records;      uint64_t cap_records;
+   uint64_t      *rec_off;      /* per record: byte offset (in the whole buffer) of the line it belongs to */
    Counters      *cnt;
 };
 
@@ -458,6 +459,26 @@ __global__ __launch_bounds__(WG) void k_exact(ScanArgs a)
    }
 }
 
+/* Per record: where its line starts in the buffer (lets the host jump from hit to hit instead of
+   walking every line: the replay of seeqFileMatch, seeq.c:361-386, becomes O(hits)). */
+__global__ __launch_bounds__(WG) void k_rec_offsets(ScanArgs a)
+{
+   const Counters *c = a.cnt;
+   if (c->overflow & 4u) return;
+   const uint32_t nhl = c->seg_nhitlines;
+   const bool all = (a.options & 3) == SQ_ALL;
+   const uint32_t stride = gridDim.x * WG;
+   for (uint32_t k = blockIdx.x * WG + threadIdx.x; k < nhl; k += stride) {
+      const uint64_t off = a.seg_base + a.hit_start[k];
+      if (all) {
+         const uint32_t lo = a.nh[k], hi = k + 1 < nhl ? a.nh[k + 1] : c->seg_nrec;
+         for (uint32_t r = lo; r < hi; r++) a.rec_off[c->records + r] = off;
+      } else {
+         a.rec_off[c->records + k] = off;
+      }
+   }
+}
+
 /* End of segment: fold the segment into the running totals. */
 __global__ void k_seg_end(ScanArgs a, int hits_from_nh)
 {
@@ -632,7 +653,7 @@ struct seeqdev_scan {
    const void *avg_text; size_t avg_nbytes;
    int force_path;                /* 0 auto, 1 generic, 2 fused (SEEQ_PATH env / tests) */
    int last_path;                 /* 1 generic, 2 fused: what the last run used */
-   seeqdev_hit_t *records;      size_t cap_records;
+   seeqdev_hit_t *records; uint64_t *rec_off; size_t cap_records;
    uint32_t *scan_ws;           size_t cap_scan_ws;
    Counters *d_cnt;
    Counters *h_cnt;            /* pinned */
@@ -701,7 +722,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
 {
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
-   void *bufs[] = {s->wg_hits, s->wg_part, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+   void *bufs[] = {s->rec_off, s->wg_hits, s->wg_part, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->d_eqtab,
                    s->nh, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
@@ -752,6 +773,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
    }
    if (max_records > s->cap_records) {
       if (ws_alloc((void **)&s->records, max_records * sizeof(seeqdev_hit_t))) return -1;
+      if (ws_alloc((void **)&s->rec_off, max_records * sizeof(uint64_t))) return -1;
       s->cap_records = max_records;
    }
    /* block sums for the two-level scans: the largest scanned array */
@@ -975,7 +997,7 @@ static int run_segments(seeqdev_scan *s)
       a.tile_cnt = s->tile_cnt; a.ntiles = (a.seg_len + TILE - 1) / TILE;
       a.hitmask = s->hitmask; a.hdrmask = s->hdrmask; a.wave_off = s->wave_off; a.hdr_off = s->hdr_off;
       a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
-      a.records = s->records; a.cap_records = s->cap_records;
+      a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
       a.cnt = c;
 
       if (use_fused) {
@@ -1044,6 +1066,7 @@ static int run_segments(seeqdev_scan *s)
             hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, s->stream, a);
             if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, s->stream, a);
          }
       }
       hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, need_nh ? 1 : 0);
@@ -1154,6 +1177,32 @@ extern "C" int seeqdevScanCopyRecords(seeqdev_scan_t *s, seeqdev_hit_t *host_out
    if (n == 0) return 0;
    HIP_TRY(hipMemcpyAsync(host_out, s->records + first, n * sizeof(seeqdev_hit_t), hipMemcpyDeviceToHost, s->stream),
            EIO);
+   HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+   return 0;
+}
+
+/* Page-locked host memory for staging buffers (H2D at link speed instead of through a bounce buffer). */
+extern "C" void *seeqdevHostAlloc(size_t bytes)
+{
+   void *p = NULL;
+   seeqerr = 0;
+   hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+   if (e != hipSuccess) { hip_fail(e, "hipHostMalloc", ENOMEM); return NULL; }
+   return p;
+}
+
+extern "C" void seeqdevHostFree(void *p)
+{
+   if (p) (void)hipHostFree(p);
+}
+
+extern "C" int seeqdevScanCopyOffsets(seeqdev_scan_t *s, uint64_t *host_out, size_t first, size_t n)
+{
+   seeqerr = 0;
+   if (!s || (!host_out && n)) { errno = EINVAL; return -1; }
+   if (first + n > s->counts.nrecords) { errno = EINVAL; return -1; }
+   if (n == 0) return 0;
+   HIP_TRY(hipMemcpyAsync(host_out, s->rec_off + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream), EIO);
    HIP_TRY(hipStreamSynchronize(s->stream), EIO);
    return 0;
 }

@@ -45,7 +45,10 @@ typedef struct fstate_t {
    int              opt_key;
    size_t           counted;   /* counted lines replayed since scan_from */
    seeqdev_hit_t   *rec;
+   uint64_t        *rec_off;   /* per record: offset of its line, relative to scan_from */
    size_t           rec_cap, nrec, rec_pos;
+   size_t           scan_from; /* where in buf the cached scan started */
+   size_t           scan_lines;/* counted lines in the cached scan */
 } fstate_t;
 
 static fstate_t *g_states = NULL;
@@ -79,8 +82,9 @@ static void state_drop(seeqfile_t *f)
       if ((*pp)->key == f) {
          fstate_t *s = *pp;
          *pp = s->next;
-         free(s->buf);
+         seeqdevHostFree(s->buf);
          free(s->rec);
+         free(s->rec_off);
          free(s);
          return;
       }
@@ -99,13 +103,15 @@ static int refill(fstate_t *s, FILE *fdi)
    s->have = 0;
    if (!s->buf) {
       s->cap = chunk_bytes();
-      s->buf = malloc(s->cap);
+      s->buf = seeqdevHostAlloc(s->cap);            /* page-locked: H2D at link speed */
       if (!s->buf) return -1;
    }
    for (;;) {
       if (s->len == s->cap) {           /* one line longer than the chunk: grow */
-         char *g = realloc(s->buf, 2 * s->cap);
+         char *g = seeqdevHostAlloc(2 * s->cap);
          if (!g) return -1;
+         memcpy(g, s->buf, s->len);
+         seeqdevHostFree(s->buf);
          s->buf = g;
          s->cap *= 2;
       }
@@ -199,12 +205,39 @@ static int scan_chunk(fstate_t *s, seeq_engine_t *eng, int dev_opt, int want, se
       seeqdev_hit_t *g = realloc(s->rec, cnt->nrecords * sizeof *g);
       if (!g) { seeqerr = 0; return -1; }
       s->rec = g;
+      uint64_t *o = realloc(s->rec_off, cnt->nrecords * sizeof *o);
+      if (!o) { seeqerr = 0; return -1; }
+      s->rec_off = o;
       s->rec_cap = cnt->nrecords;
    }
    if (seeqdevScanCopyRecords(scan, s->rec, 0, cnt->nrecords)) return -1;
+   if (seeqdevScanCopyOffsets(scan, s->rec_off, 0, cnt->nrecords)) return -1;
+   s->scan_from = s->pos;
+   s->scan_lines = cnt->nlines;
    s->nrec = cnt->nrecords;
    s->rec_pos = 0;
    s->counted = 0;
+   return 0;
+}
+
+/* FASTA: remember the last header line ('>' first) that starts inside buf[lo, hi) (seeq.c:367-374). */
+static int last_header(seeqfile_t *f, const char *buf, size_t lo, size_t hi)
+{
+   size_t q = hi;
+   while (q > lo) {
+      const char *g = memrchr(buf + lo, '>', q - lo);
+      if (!g) return 0;
+      const size_t at = (size_t)(g - buf);
+      if (at == 0 || buf[at - 1] == '\n') {                       /* a line starts here */
+         const char *nl = memchr(g, '\n', hi - at);
+         const size_t n = nl ? (size_t)(nl - g) : hi - at;
+         char *dup = strndup(g, n);
+         if (!dup) { seeqerr = 666; return -1; }
+         f->info = dup;                                            /* the reference does not free the old one either */
+         return 0;
+      }
+      q = at;
+   }
    return 0;
 }
 
@@ -278,13 +311,48 @@ long seeqFileMatch(seeqfile_t *sqfile, seeq_t *sq, int match_opt, int file_opt)
          s->eng_id = eng->id;
          s->opt_key = key;
       }
-      /* Replay one line (seeq.c:361-386). */
+      if (file_opt == SQ_MATCH) {
+         /* Jump from hit to hit: every line in between has 0 hits, so the reference's loop (seeq.c:361-386)
+            would just count it (and remember FASTA headers).  The device gave us each record's line offset. */
+         if (s->rec_pos < s->nrec) {
+            const seeqdev_hit_t *r = s->rec + s->rec_pos;
+            const size_t lo = s->scan_from + (size_t)s->rec_off[s->rec_pos];
+            size_t k = 1;
+            while (s->rec_pos + k < s->nrec && r[k].line == r->line) k++;
+            const char *line = s->buf + lo;
+            const char *nl = memchr(line, '\n', s->avail - lo);
+            const size_t n = nl ? (size_t)(nl - line) : s->avail - lo;
+            if (fasta && last_header(sqfile, s->buf, s->pos, lo)) return -1;
+            sqfile->line += r->line - s->counted;                  /* seeq.c:377, for all the lines skipped */
+            s->counted = r->line;
+            s->pos = lo + n + (nl ? 1 : 0);
+            if (set_string(sq, line, n)) { seeqerr = 0; return -1; }
+            if (seeq_store_hits(sq, r, k)) return -1;
+            s->rec_pos += k;
+            return 1;                                               /* count = k > 0: seeq.c:385-386 */
+         }
+         /* no hit left in this chunk: consume the rest */
+         if (fasta && last_header(sqfile, s->buf, s->pos, s->avail)) return -1;
+         sqfile->line += s->scan_lines - s->counted;
+         s->counted = s->scan_lines;
+         if (s->avail > s->pos) {                                   /* the last line read stays in sq->string */
+            size_t e = s->avail;
+            if (s->buf[e - 1] == '\n') e--;
+            const char *b = e > s->pos ? memrchr(s->buf + s->pos, '\n', e - s->pos) : NULL;
+            const size_t ls = b ? (size_t)(b - s->buf) + 1 : s->pos;
+            if (set_string(sq, s->buf + ls, e - ls)) { seeqerr = 0; return -1; }   /* headers too: getline put them there */
+            sq->hits = 0;
+         }
+         s->pos = s->avail;
+         continue;
+      }
+      /* SQ_ANY / SQ_NOMATCH: replay line by line (seeq.c:361-386). */
       const char *line = s->buf + s->pos;
       const char *nl = memchr(line, '\n', s->avail - s->pos);
       const size_t n = nl ? (size_t)(nl - line) : s->avail - s->pos;
       s->pos += n + (nl ? 1 : 0);
-      if (set_string(sq, line, n)) { seeqerr = 0; return -1; }
       if (fasta && n > 0 && line[0] == '>') {                     /* seeq.c:367-374 */
+         if (set_string(sq, line, n)) { seeqerr = 0; return -1; }
          sqfile->info = strdup(sq->string);
          if (!sqfile->info) { seeqerr = 666; return -1; }
          continue;
@@ -293,12 +361,16 @@ long seeqFileMatch(seeqfile_t *sqfile, seeq_t *sq, int match_opt, int file_opt)
       s->counted++;
       size_t k = 0;
       while (s->rec_pos + k < s->nrec && s->rec[s->rec_pos + k].line == s->counted) k++;
-      if (seeq_store_hits(sq, s->rec + s->rec_pos, k)) return -1;
-      s->rec_pos += k;
       const long rval = (long)k;
+      const int stop = file_opt == SQ_ANY || (rval == 0 && file_opt == SQ_NOMATCH);
+      /* sq->string / sq->match only matter for the line a call returns on, or the last line of the file */
+      if (stop || s->pos >= s->avail) {
+         if (set_string(sq, line, n)) { seeqerr = 0; return -1; }
+         if (seeq_store_hits(sq, s->rec + s->rec_pos, k)) return -1;
+      }
+      s->rec_pos += k;
       count += rval;
-      if (file_opt == SQ_ANY || (count > 0 && file_opt == SQ_MATCH) || (rval == 0 && file_opt == SQ_NOMATCH))
-         return 1;                                                /* seeq.c:385-386 */
+      if (stop) return 1;                                         /* seeq.c:385-386 */
    }
    return sqfile->line == startline ? 0 : count;                  /* seeq.c:390-391 */
 }

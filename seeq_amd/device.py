@@ -125,6 +125,13 @@ class Scanner:
             _check(self._lib.seeqdevScanCopyRecords(self._h, out.ctypes.data, first, n))
         return out
 
+    def record_offsets(self, n, first=0):
+        """Per record: byte offset of its line in the scanned buffer -> ndarray [n] u64."""
+        out = np.zeros(n, dtype=np.uint64)
+        if n:
+            _check(self._lib.seeqdevScanCopyOffsets(self._h, out.ctypes.data, first, n))
+        return out
+
     def records_device_ptr(self):
         return self._lib.seeqdevScanRecordsDevice(self._h)
 
