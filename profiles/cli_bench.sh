@@ -15,7 +15,7 @@ with open("$F", "wb") as f:
 PY
 ls -la $F
 P=GATGTAGCGCGATTAGCCTG
-t() { local s=$(date +%s.%N); "$@" > /tmp/cli_out.$$ ; local e=$(date +%s.%N); echo "$(echo "$e - $s" | bc) s  $(md5sum < /tmp/cli_out.$$ | cut -c1-12)  $*"; }
+t() { local s=$(date +%s%N); "$@" > /tmp/cli_out.$$ ; local e=$(date +%s%N); echo "$(( (e - s) / 1000000 )) ms  $(md5sum < /tmp/cli_out.$$ | cut -c1-12)  $*"; }
 cat $F > /dev/null
 for args in "-c -d 3" "-d 3 -b -f" "-d 3 -a -f" "-d 3 -i -l"; do
   t seeq_amd/bin/seeq $args $P $F

@@ -105,30 +105,53 @@ __global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
                   const uint32_t q0 = r * 1024 + lane16;
                   if (r < rr) {                                             /* wave-uniform */
                      const fused_v4u v = pre[i];
+                     /* 0x80 in every byte that is '\n' -- plus, possibly, in the byte right above one (borrow):
+                        the LOWEST flag of a word is always a true newline */
                      const uint32_t x0 = v.x ^ 0x0A0A0A0Au, x1 = v.y ^ 0x0A0A0A0Au, x2 = v.z ^ 0x0A0A0A0Au, x3 = v.w ^ 0x0A0A0A0Au;
-                     const uint32_t any = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) |
-                                           ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
-                     uint32_t m16 = 0;
-                     if (any) {                                             /* cheap superset test, exact mask only then */
-                        const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
-                        m16 = (((f0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((f1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
-                              ((((f2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((f3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
-                     }
-                     if (!region_plain || (r + 1) * 1024 > tb) {            /* wave-uniform: edges of the owned range */
-                        if (q0 >= tb) m16 = 0;
-                        else if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;   /* a newline must be owned: q < tb */
-                        if (t0 + q0 <= last && last < t0 + q0 + 16)         /* ... and not the last byte       */
-                           m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
-                     }
-                     const uint32_t c = (uint32_t)__popc(m16);
-                     const uint32_t incl = wave_incl_scan_u32(c);
-                     uint32_t rk = running + incl - c;                      /* rank of my first newline */
-                     running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                     while (m16) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(m16);
-                        m16 &= m16 - 1;
-                        if (rk >= p0 && rk < p0 + DIRECT_SCAP) s_starts[rk - p0] = q0 + b + 1;
-                        rk++;
+                     const uint32_t f0 = (x0 - 0x01010101u) & ~x0 & 0x80808080u, f1 = (x1 - 0x01010101u) & ~x1 & 0x80808080u;
+                     const uint32_t f2 = (x2 - 0x01010101u) & ~x2 & 0x80808080u, f3 = (x3 - 0x01010101u) & ~x3 & 0x80808080u;
+                     const uint32_t cflag = (uint32_t)__popc(f0) + (uint32_t)__popc(f1) + (uint32_t)__popc(f2) + (uint32_t)__popc(f3);
+                     const bool edge = !region_plain || (r + 1) * 1024 > tb;  /* wave-uniform */
+                     if (!edge && !__any(cflag > 1)) {
+                        /* common case: at most one newline per 16-byte piece in the whole wave -> a ballot ranks them */
+                        const bool has = cflag != 0;
+                        const uint64_t bm = __ballot(has);
+                        if (has) {
+                           const uint32_t rk = running + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0));
+                           /* bit index of the single flag among the 128 bits (ffbl of an empty word = 0xFFFFFFFF) */
+                           const uint32_t b0 = (uint32_t)__builtin_ctz(f0 | 0x80000000u) | (f0 ? 0u : 0xFFFFFF00u);
+                           const uint32_t b1 = (32u + (uint32_t)__builtin_ctz(f1 | 0x80000000u)) | (f1 ? 0u : 0xFFFFFF00u);
+                           const uint32_t b2 = (64u + (uint32_t)__builtin_ctz(f2 | 0x80000000u)) | (f2 ? 0u : 0xFFFFFF00u);
+                           const uint32_t b3 = (96u + (uint32_t)__builtin_ctz(f3 | 0x80000000u)) | (f3 ? 0u : 0xFFFFFF00u);
+                           const uint32_t bl = b0 < b1 ? b0 : b1, bh = b2 < b3 ? b2 : b3;
+                           const uint32_t bit = bl < bh ? bl : bh;
+                           if (rk >= p0 && rk < p0 + DIRECT_SCAP) s_starts[rk - p0] = q0 + (bit >> 3) + 1;
+                        }
+                        running += (uint32_t)__popcll(bm);
+                     } else {
+                        uint32_t m16 = 0;
+                        if (cflag) {                                        /* exact per-byte mask */
+                           const uint32_t g0 = nl_flags(v.x), g1 = nl_flags(v.y), g2 = nl_flags(v.z), g3 = nl_flags(v.w);
+                           m16 = (((g0 >> 7) * 0x00204081u >> 21) & 0xFu) | ((((g1 >> 7) * 0x00204081u >> 21) & 0xFu) << 4) |
+                                 ((((g2 >> 7) * 0x00204081u >> 21) & 0xFu) << 8) | ((((g3 >> 7) * 0x00204081u >> 21) & 0xFu) << 12);
+                        }
+                        if (edge) {                                         /* edges of the owned range */
+                           if (q0 >= tb) m16 = 0;
+                           else if (q0 + 16 > tb) m16 &= (1u << (tb - q0)) - 1u;   /* a newline must be owned: q < tb */
+                           if (t0 + q0 <= last && last < t0 + q0 + 16)      /* ... and not the last byte       */
+                              m16 &= ~(1u << (uint32_t)(last - (t0 + q0)));
+                        }
+                        const uint32_t c = (uint32_t)__popc(m16);
+                        const uint32_t incl = wave_incl_scan_u32(c);
+                        uint32_t rk = running + incl - c;                   /* rank of my first newline */
+                        running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        while (m16) {
+                           const uint32_t b = (uint32_t)__builtin_ctz(m16);
+                           m16 &= m16 - 1;
+                           if (rk >= p0 && rk < p0 + DIRECT_SCAP) s_starts[rk - p0] = q0 + b + 1;
+                           rk++;
+                        }
                      }
                   }
                }
