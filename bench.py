@@ -82,6 +82,16 @@ def cpu_baseline(sample_lines, workload):
                           ["seeq", "-d", str(TAU)] + (["-c"] if workload == "count" else ["-b", "-f"])), cores)}
 
 
+def seeq_scan_host_ptr(scanner, pat, host_ptr, nbytes, opt, want):
+    """seeqdevScanHost on a raw host pointer (pinned torch tensor)."""
+    import ctypes as C
+    from seeq_amd import _capi
+    cnt = _capi.seeqdev_counts_t()
+    rc = _capi.lib().seeqdevScanHost(scanner._h, pat.handle, C.cast(host_ptr, C.c_char_p), nbytes, opt, want, C.byref(cnt))
+    assert rc == 0, _capi.error_text()
+    return dict(nlines=cnt.nlines, nmatchlines=cnt.nmatchlines, nhits=cnt.nhits, nrecords=cnt.nrecords)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +104,7 @@ def main():
     ap.add_argument("--distance", type=int, default=globals()["TAU"])
     ap.add_argument("--read-len", type=int, default=globals()["READ_LEN"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-memory end-to-end measurement")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--check-lines", type=int, default=200_000, help="prefix verified against the oracle")
     args = ap.parse_args()
@@ -222,6 +233,24 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "one-pass scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte), HBM traffic ~1x: see DESIGN.md"},
         }
+        if world == 1 and not args.no_e2e:
+            # Timed region (ii) of SURVEY 8d: same path fed from page-locked HOST memory (H2D + scan + D2H of the
+            # records), on a 10 M-line sample.  PCIe-bound; reported beside, never as, `value`.
+            ne = min(n, 10_000_000)
+            hostbuf = text[:ne * (READ_LEN + 1)].cpu().pin_memory()
+            sc2 = dev.Scanner()
+            import ctypes
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                cnt2 = seeq_scan_host_ptr(sc2, pat, hostbuf.data_ptr(), hostbuf.numel(), opt, want)
+                if want == dev.WANT_RECORDS:
+                    sc2.records(cnt2["nrecords"])
+                dt = time.perf_counter() - t1
+                best = dt if best is None else min(best, dt)
+            out["end_to_end_pinned_host"] = {"lines": ne, "seconds": best, "lines_per_s": ne / best,
+                                             "gb_per_s": ne * (READ_LEN + 1) / best / 1e9,
+                                             "note": "H2D over PCIe + scan + D2H records; best of 3"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.workload)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

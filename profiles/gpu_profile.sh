@@ -3,7 +3,7 @@
 # Usage: profiles/gpu_profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:---reads 20000000 --steps 2 --warmup 1 --no-cpu-baseline --check-lines 0}
+ARGS=${@:---reads 20000000 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --check-lines 0}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -169,6 +169,38 @@ class SeeqObject:
     def matchIter(self, string):
         return SeeqIter(self, string, 1)
 
+    # ---- batched extension (not in the reference module): one GPU scan for many strings ----
+    def _batch(self, strings, match_opt):
+        """strings: iterable of str without newlines/NULs.  Returns a list with, per string, the list of
+        (start, end, dist) hits in left-to-right order ([] when nothing matches).  The whole batch is one
+        device scan (seeqdevScanHost over the newline-joined strings) instead of one GPU round trip per
+        string."""
+        from . import device as dev
+        data = [_utf8(x) for x in strings]
+        for b in data:
+            if b"\n" in b:
+                raise ValueError("batched matching takes one string per line: no embedded newlines")
+        if not data:
+            return []
+        buf = b"\n".join(data) + b"\n"
+        if not hasattr(self, "_scanner"):
+            self._scanner = dev.Scanner()
+            self._devpat = type("P", (), {"handle": self._lib.seeqdevPatternOf(self._sq)})()
+        res = self._scanner.scan_host(self._devpat, buf, match_opt | self._options, dev.WANT_RECORDS)
+        out = [[] for _ in data]
+        for line, s, e, d in res["records"]:
+            out[int(line) - 1].append((int(s), int(e), int(d)))
+        return out
+
+    def matchBatch(self, strings):
+        return self._batch(strings, _capi.SQ_FIRST)
+
+    def matchBestBatch(self, strings):
+        return self._batch(strings, _capi.SQ_BEST)
+
+    def matchAllBatch(self, strings):
+        return self._batch(strings, _capi.SQ_ALL)
+
     def _best0(self, string):
         data = _utf8(string)
         n = self._lib.seeqStringMatch(data, self._sq, _capi.SQ_BEST | self._options)

@@ -404,3 +404,23 @@ def test_python_module_surface(gpu, capi):
     assert seeq.compile("CACAGAT", 0, 1).matchAll("RCACAGATCACAGATCACAGRATCAC").matches() == \
         ("CACAGAT", "CACAGAT", "CACAGRAT")
     assert seeq.compile("CACAGAT", 0, 0).matchAll("RCACAGATCACAGATCACAGRATCAC").matches() == ("CACAGAT", "CACAGAT")
+
+
+def test_python_batched_api(gpu, capi, oracle):
+    """matchBestBatch / matchAllBatch (one device scan for a list of strings) == per-string oracle results."""
+    import seeq_amd as seeq
+    sys.path.insert(0, GOLDEN)
+    from make_golden import rand_text
+    rng = random.Random(17)
+    pat, tau = "GATGTAGCGCGATTAGCCTG", 3
+    texts = [rand_text(rng, pat, tau, rng.choice([0, 5, 60, 150, 400])).replace("\n", "N").replace("\0", "N")
+             for _ in range(3000)]
+    m = seeq.compile(pat, tau)                       # mode 0 = SQ_CONVERT, as the reference module
+    for fn, opt in ((m.matchBatch, SQ_FIRST), (m.matchBestBatch, SQ_BEST), (m.matchAllBatch, SQ_ALL)):
+        got = fn(texts)
+        assert len(got) == len(texts)
+        for tx, g in zip(texts, got):
+            assert g == oracle.string_match(pat, tau, tx, opt | SQ_CONVERT)[::-1], (tx, opt)
+    assert m.matchBestBatch([]) == []
+    with pytest.raises(ValueError):
+        m.matchBestBatch(["AC\nGT"])
