@@ -701,8 +701,8 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    else { e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking); s->own_stream = true; }
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cnt, sizeof(Counters));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_cnt, sizeof(Counters), hipHostMallocDefault);
-   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 512 * sizeof(uint32_t), hipHostMallocDefault);
-   if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 512 * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 1024 * sizeof(uint32_t), hipHostMallocDefault);
+   if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 1024 * sizeof(uint32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
    if (e == hipSuccess) e = hipMalloc((void **)&s->wg_hits, MAX_FUSED_GRID * sizeof(uint32_t));
    if (e == hipSuccess) e = hipMalloc((void **)&s->wg_part, 3 * MAX_FUSED_GRID * sizeof(uint32_t));
@@ -889,8 +889,11 @@ static int run_segments(seeqdev_scan *s)
 
    /* Path selection: the fused LDS kernel serves one-word patterns with two spare flag bits on
       ordinary read-length lines; everything else takes the generic index + k_forward<W> path. */
-   bool use_fused = !single && W == 1 && pat->wlen <= FUSED_MAX_WLEN && s->avg_line <= 600.0 && s->force_path != 1;
-   if (s->force_path == 2 && !single && W == 1 && pat->wlen <= FUSED_MAX_WLEN) use_fused = true;
+   /* fw = words of the fused kernels' column: 1 for <= 30 positions, 2 for 31..62 (two flag bits needed) */
+   const int fw = pat->wlen <= FUSED_MAX_WLEN ? 1 : 2;
+   const bool fusable = !single && pat->wlen <= FUSED_MAX_WLEN2;
+   bool use_fused = fusable && s->avg_line <= 600.0 && s->force_path != 1;
+   if (s->force_path == 2 && fusable) use_fused = true;
    uint32_t tile_bytes = 0;
    unsigned fused_grid = 1;
    size_t fused_lds = 0;
@@ -900,7 +903,7 @@ static int run_segments(seeqdev_scan *s)
    bool use_direct = false;
    if (use_fused) {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
-      use_direct = !(ke && !strcmp(ke, "lds"));                   /* default: k_direct (text in registers) */
+      use_direct = !(ke && !strcmp(ke, "lds")) || fw == 2;        /* default: k_direct (text in registers) */
       if (use_direct && s->avg_line * 62.0 > 16.0 * 1024 - 64) use_direct = false;   /* regions are <= 16 KiB */
       const char *te = getenv("SEEQ_TILE_BYTES");
       if (use_direct) {
@@ -910,7 +913,8 @@ static int run_segments(seeqdev_scan *s)
          tile_bytes = ((uint32_t)want) & ~15u;
          if (te && atoi(te) >= 512 && atoi(te) <= DIRECT_MAXRR * 1024) tile_bytes = (uint32_t)atoi(te) & ~15u;
          int per_cu = 0;
-         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4>, 256, 0) != hipSuccess || per_cu < 1)
+         if ((fw == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4, 1>, 256, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4, 2>, 256, 0)) != hipSuccess || per_cu < 1)
             per_cu = 1;
          fused_grid = (unsigned)(ncu * per_cu);
          if ((size_t)fused_grid * 4 > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / 4);
@@ -952,16 +956,28 @@ static int run_segments(seeqdev_scan *s)
       if (s->eq_pat != pat || s->eq_options != options) {
          /* EQ[byte]: top-aligned Peq word of the byte's class, or a flag (reference seeqcore.h:89-111 folded
             with the non-DNA option, libseeq.c:223-228,265-270) */
-         uint32_t hpeq[10];                               /* forward [5], reversed pattern [5] (one word each) */
-         HIP_TRY(hipMemcpyAsync(hpeq, pat->d_peq, sizeof hpeq, hipMemcpyDeviceToHost, s->stream), EIO);
+         /* EQ[dir][byte][fw]: the top-aligned Peq column of the byte's class, or a flag (reference
+            seeqcore.h:89-111 folded with the non-DNA option, libseeq.c:223-228,265-270) */
+         uint32_t hpeq[20];                               /* [2 dirs][5 classes][Wp <= 2 words] */
+         const int Wp = pat->words;
+         HIP_TRY(hipMemcpyAsync(hpeq, pat->d_peq, (size_t)10 * Wp * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), EIO);
          HIP_TRY(hipStreamSynchronize(s->stream), EIO);
-         for (int b = 0; b < 256; b++) {
-            const uint8_t cls = sq_class_of((uint32_t)b, options);
-            const uint32_t flag = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
-            s->h_eqtab[b] = cls < 5 ? hpeq[cls] << (32 - pat->wlen) : flag;
-            s->h_eqtab[256 + b] = cls < 5 ? hpeq[5 + cls] << (32 - pat->wlen) : flag;
-         }
-         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, 512 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
+         for (int dir = 0; dir < 2; dir++)
+            for (int b = 0; b < 256; b++) {
+               const uint8_t cls = sq_class_of((uint32_t)b, options);
+               uint64_t v;
+               if (cls < 5) {
+                  const uint32_t *q = hpeq + (dir * 5 + cls) * Wp;
+                  const uint64_t col = (uint64_t)q[0] | (Wp > 1 ? (uint64_t)q[1] << 32 : 0);
+                  v = col << (32 * fw - pat->wlen);                /* row m lands on the top bit */
+               } else {
+                  v = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
+               }
+               uint32_t *dst = s->h_eqtab + (size_t)(dir * 256 + b) * fw;
+               dst[0] = (uint32_t)v;
+               if (fw == 2) dst[1] = (uint32_t)(v >> 32);
+            }
+         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)512 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
          HIP_TRY(hipStreamSynchronize(s->stream), EIO);
          s->eq_pat = pat;
          s->eq_options = options;
@@ -1017,7 +1033,8 @@ static int run_segments(seeqdev_scan *s)
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
          const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */
          f.slice_cap = f.cap_tmp / nslices;
-         if (use_direct) hipLaunchKernelGGL(k_direct<4>, dim3(fgrid), dim3(256), 0, s->stream, f);
+         if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);
+         else if (use_direct) hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, s->stream, f);
          else if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
          else if (nw == 2) hipLaunchKernelGGL(k_fused<2>, dim3(fgrid), dim3(128), fused_lds, s->stream, f);
          else hipLaunchKernelGGL(k_fused<4>, dim3(fgrid), dim3(256), fused_lds, s->stream, f);
@@ -1057,14 +1074,16 @@ static int run_segments(seeqdev_scan *s)
          if (grid_hits == 0) grid_hits = 1;
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
-            if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */
          if (want == SEEQDEV_WANT_RECORDS) {
             hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, s->stream, a);
-            if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, s->stream, a);
          }

@@ -44,10 +44,10 @@ __device__ __forceinline__ fused_v4u direct_load16(const uint8_t *text, uint64_t
    return fused_v4u{w0, w1, w2, w3};
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
+template <int NW, int W>
+__global__ __launch_bounds__(64 * NW, (W == 1 ? 4 : 3)) void k_direct(FusedArgs a)
 {
-   __shared__ uint32_t s_eq[256];
+   __shared__ __align__(8) uint32_t s_eq[256 * W];
    __shared__ uint32_t s_starts_all[NW][DIRECT_SCAP];
 
    const int tid = threadIdx.x, lane = tid & 63;
@@ -56,9 +56,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
    const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
    const uint32_t tau = (uint32_t)a.tau;
    const uint32_t TB = a.tile_bytes;
-   const uint32_t two = 2u;
+   const uint32_t two = W == 1 ? 2u : 3u;                 /* log2 of the EQ entry size */
 
-   for (int i = tid; i < 256; i += 64 * NW) s_eq[i] = a.eqtab[i];
+   for (int i = tid; i < 256 * W; i += 64 * NW) s_eq[i] = a.eqtab[i];
    __syncthreads();                                       /* the only barrier: tables are read-only from here */
    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
    const uint32_t eq_base = (uint32_t)(uintptr_t)(lds_cu32 *)s_eq;   /* LDS byte offset of the table */
@@ -167,7 +167,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
             const uint32_t lstart = active ? s_starts[rl] : 0;             /* offset of the line inside the region */
             const uint64_t lbase = t0 + lstart;                            /* absolute offset */
             uint32_t ahead = 0;                                            /* bytes of my line requested so far */
-            uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = (uint32_t)a.m, minscore = (uint32_t)a.m;
+            fused_state_t<W> st;
+            st.init((uint32_t)a.m);
+            uint32_t minscore = (uint32_t)a.m;
             bool hit = false, hdr = false;
             if (a.debug & 1u) active = false;
             auto next_window = [&](fused_v4u (&v)[DIRECT_WIN]) {
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
             };
             /* one 16-character chunk from registers: EQ lookups, flag test, 16 Myers steps */
             auto process = [&](const fused_v4u &q) {
-               uint32_t eq[16];
+               fused_eq_t<W> eq[16];
 #pragma unroll
                for (int k = 0; k < 16; k += 4) {
                   const uint32_t word = k == 0 ? q.x : k == 4 ? q.y : k == 8 ? q.z : q.w;
@@ -197,21 +199,21 @@ __global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
                       : "=v"(a2) : "v"(two), "v"(word));
                   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
                       : "=v"(a3) : "v"(two), "v"(word));
-                  eq[k + 0] = *(lds_cu32 *)(uintptr_t)(eq_base + a0);
-                  eq[k + 1] = *(lds_cu32 *)(uintptr_t)(eq_base + a1);
-                  eq[k + 2] = *(lds_cu32 *)(uintptr_t)(eq_base + a2);
-                  eq[k + 3] = *(lds_cu32 *)(uintptr_t)(eq_base + a3);
+                  eq[k + 0] = fused_eq_load<W>(eq_base + a0);
+                  eq[k + 1] = fused_eq_load<W>(eq_base + a1);
+                  eq[k + 2] = fused_eq_load<W>(eq_base + a2);
+                  eq[k + 3] = fused_eq_load<W>(eq_base + a3);
                }
                uint32_t fl[4];
 #pragma unroll
                for (int g = 0; g < 4; g++)
-                  fl[g] = (eq[4 * g] | eq[4 * g + 1] | eq[4 * g + 2] | eq[4 * g + 3]) & FUSED_FLAGS;
+                  fl[g] = (eq[4 * g].w0 | eq[4 * g + 1].w0 | eq[4 * g + 2].w0 | eq[4 * g + 3].w0) & FUSED_FLAGS;
                const uint32_t flall = fl[0] | fl[1] | fl[2] | fl[3];
                if (!__any(active && flall != 0)) {
 #pragma unroll
                   for (int k = 0; k < 16; k++) {
-                     fused_step(eq[k], pv, mv, score);
-                     minscore = score < minscore ? score : minscore;
+                     st.step(eq[k]);
+                     minscore = st.score < minscore ? st.score : minscore;
                   }
                } else {
 #pragma unroll
@@ -219,17 +221,17 @@ __global__ __launch_bounds__(64 * NW, 4) void k_direct(FusedArgs a)
                      if (!__any(active && fl[g] != 0)) {
 #pragma unroll
                         for (int k = 4 * g; k < 4 * g + 4; k++) {
-                           fused_step(eq[k], pv, mv, score);
-                           minscore = score < minscore ? score : minscore;
+                           st.step(eq[k]);
+                           minscore = st.score < minscore ? st.score : minscore;
                         }
                      } else {
 #pragma unroll
                         for (int k = 4 * g; k < 4 * g + 4; k++) {
                            if (active) {
-                              const uint32_t e = eq[k];
+                              const uint32_t e = eq[k].w0;
                               if ((e & FUSED_FLAGS) == 0) {
-                                 fused_step(e, pv, mv, score);
-                                 minscore = score < minscore ? score : minscore;
+                                 st.step(eq[k]);
+                                 minscore = st.score < minscore ? st.score : minscore;
                               } else if (e & FUSED_FLAG_TERM) {
                                  active = false;                            /* line over: latch the verdict */
                                  hit = minscore <= tau;

@@ -1,5 +1,5 @@
 /*
- * seeq_exact1.h -- k_exact1: the exact pass for one-word patterns (<= 30 positions).
+ * seeq_exact1.h -- k_exact1<MODE, W>: the exact pass for patterns of <= 30 (W = 1) / 31..62 (W = 2) positions.
  *
  * Same job as k_exact<1,*> (seeq_device.hip): over the HIT lines only, apply the reference's
  * acceptance rules (libseeq.c:277-331) and recover match starts (libseeq.c:289-316); but with the
@@ -13,19 +13,22 @@
 #define EXACT1_ROW 80          /* LDS bytes per lane: 64 text bytes + pad, 16-byte aligned */
 
 /* Reverse start recovery, reference libseeq.c:289-316, on the reversed-pattern EQ table. */
+template <int W>
 __device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *line, uint32_t i, uint32_t streak,
-                                                   const uint32_t *s_eqr, uint32_t m, uint32_t tau1)
+                                                   uint32_t eqr_base, uint32_t m, uint32_t tau1)
 {
-   uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = m;
+   fused_state_t<W> st;
+   st.init(m);
    uint32_t j = 0, d = tau1, last_d, ignores = 0;
    do {
       ++j;
-      const uint32_t e = s_eqr[line[i - j]];
+      const fused_eq_t<W> ev = fused_eq_load<W>(eqr_base + ((uint32_t)line[i - j] << (W == 1 ? 2 : 3)));
+      const uint32_t e = ev.w0;
       last_d = d;
       if ((e & FUSED_FLAGS) == 0) {
          ignores = 0;
-         fused_step(e, pv, mv, score);
-         d = score < tau1 ? score : tau1;
+         st.step(ev);
+         d = st.score < tau1 ? st.score : tau1;
       } else {
          ignores++;                                   /* any non-base byte: skipped, counted (libseeq.c:308-311) */
       }
@@ -34,14 +37,16 @@ __device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *line, uint32_t
    return (uint32_t)((int)i - jj);
 }
 
-template <int MODE>
+template <int MODE, int W>
 __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
 {
-   __shared__ uint32_t s_eqf[256];
-   __shared__ uint32_t s_eqr[256];
+   __shared__ __align__(8) uint32_t s_eqf[256 * W];
+   __shared__ __align__(8) uint32_t s_eqr[256 * W];
    __shared__ __align__(16) uint8_t s_blk[256 * EXACT1_ROW];
-   for (int i = threadIdx.x; i < 256; i += 256) { s_eqf[i] = eq2[i]; s_eqr[i] = eq2[256 + i]; }
+   for (int i = threadIdx.x; i < 256 * W; i += 256) { s_eqf[i] = eq2[i]; s_eqr[i] = eq2[256 * W + i]; }
    __syncthreads();
+   const uint32_t eqf_base = (uint32_t)(uintptr_t)(fused_lds_cu32 *)s_eqf;
+   const uint32_t eqr_base = (uint32_t)(uintptr_t)(fused_lds_cu32 *)s_eqr;
    const Counters *c = a.cnt;
    const uint32_t nhl = c->seg_nhitlines;
    const int match_opt = a.options & 3;
@@ -55,7 +60,8 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
       bool done = k >= nhl;
       const uint64_t off = done ? a.seg_base : a.seg_base + a.hit_start[k];
       const uint8_t *line = a.text + off;
-      uint32_t pv = 0xFFFFFFFFu, mv = 0u, score = m;
+      fused_state_t<W> st;
+      st.init(m);
       uint32_t streak = tau1, nhits = 0, best_d = tau1, best_end = 0, pos = 0;
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
@@ -75,13 +81,14 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
          for (uint32_t t = 0; t < 64; t++) {
             if (!__any(!done)) break;
             if (!done) {
-               const uint32_t e = s_eqf[row[t]];
+               const fused_eq_t<W> ev = fused_eq_load<W>(eqf_base + ((uint32_t)row[t] << (W == 1 ? 2 : 3)));
+               const uint32_t e = ev.w0;
                if (!(e & FUSED_FLAG_SKIP)) {
                   uint32_t cur = tau1;
                   bool end = false;
                   if (!(e & FUSED_FLAG_TERM)) {
-                     fused_step(e, pv, mv, score);
-                     cur = score < tau1 ? score : tau1;
+                     st.step(ev);
+                     cur = st.score < tau1 ? st.score : tau1;
                   } else {
                      end = true;
                   }
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
                         if (nhits < out_cap) {
                            seeqdev_hit_t h;
                            h.line = line_no;
-                           h.start = exact1_reverse(line, p, streak, s_eqr, m, tau1);
+                           h.start = exact1_reverse<W>(line, p, streak, eqr_base, m, tau1);
                            h.end = p;
                            h.dist = streak;
                            out[nhits] = h;
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
          } else if (match_opt == SQ_BEST && nhits) {
             seeqdev_hit_t h;
             h.line = line_no;
-            h.start = exact1_reverse(line, best_end, best_d, s_eqr, m, tau1);
+            h.start = exact1_reverse<W>(line, best_end, best_d, eqr_base, m, tau1);
             h.end = best_end;
             h.dist = best_d;
             out[0] = h;

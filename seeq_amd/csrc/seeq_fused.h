@@ -31,6 +31,7 @@
 #define FUSED_FLAG_SKIP 2u      /* byte is skipped but counted in coordinates  */
 #define FUSED_FLAGS     3u
 #define FUSED_MAX_WLEN  30      /* 32-bit word minus the two flag bits         */
+#define FUSED_MAX_WLEN2 62      /* two words minus the two flag bits (k_direct<.,2>, k_exact1<.,2>) */
 #define FUSED_HALO_MAX  1024    /* bytes staged beyond the tile (runtime, <= this): longest line handled from LDS */
 #define FUSED_CAPL_PER_THREAD 2 /* line starts kept in LDS per pass = this * threads */
 #define FUSED_MAXR      16      /* newline-detection rounds: tile <= MAXR * threads * 16 bytes */
@@ -97,6 +98,64 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
 }
 
 /* LDS layout of k_fused: fixed-size tables first (compile-time offsets), text window last. */
+/* ---- one- and two-word variants behind one interface (k_direct, k_exact1 are templated on W) ---- */
+/* W = 2 serves patterns of 31..62 positions: the pattern sits in the top m bits of a 64-bit column
+   (lo word = low rows), the two flag bits in bits 0-1 of the low word. */
+template <int W> struct fused_eq_t;
+template <> struct fused_eq_t<1> { uint32_t w0; };
+template <> struct fused_eq_t<2> { uint32_t w0, w1; };
+
+typedef __attribute__((address_space(3))) const uint32_t fused_lds_cu32;
+typedef __attribute__((address_space(3))) const uint64_t fused_lds_cu64;
+
+template <int W>
+__device__ __forceinline__ fused_eq_t<W> fused_eq_load(uint32_t lds_byte_addr);
+template <>
+__device__ __forceinline__ fused_eq_t<1> fused_eq_load<1>(uint32_t addr)
+{
+   fused_eq_t<1> e;
+   e.w0 = *(fused_lds_cu32 *)(uintptr_t)addr;
+   return e;
+}
+template <>
+__device__ __forceinline__ fused_eq_t<2> fused_eq_load<2>(uint32_t addr)
+{
+   const uint64_t v = *(fused_lds_cu64 *)(uintptr_t)addr;          /* ds_read_b64 */
+   fused_eq_t<2> e;
+   e.w0 = (uint32_t)v;
+   e.w1 = (uint32_t)(v >> 32);
+   return e;
+}
+
+template <int W> struct fused_state_t;
+template <> struct fused_state_t<1> {
+   uint32_t pv, mv, score;
+   __device__ __forceinline__ void init(uint32_t m) { pv = 0xFFFFFFFFu; mv = 0u; score = m; }
+   __device__ __forceinline__ void step(const fused_eq_t<1> &e) { fused_step(e.w0, pv, mv, score); }
+};
+template <> struct fused_state_t<2> {
+   uint32_t pv0, pv1, mv0, mv1, score;
+   __device__ __forceinline__ void init(uint32_t m) { pv0 = pv1 = 0xFFFFFFFFu; mv0 = mv1 = 0u; score = m; }
+   /* the 64-bit version of fused_step: one carry chain through both words; the carry out of the
+      high word of ph+ph / mh+mh is the +1 / -1 on D[m][j] */
+   __device__ __forceinline__ void step(const fused_eq_t<2> &e)
+   {
+      const uint64_t pv = ((uint64_t)pv1 << 32) | pv0, eq = ((uint64_t)e.w1 << 32) | e.w0;
+      const uint64_t s = (eq & pv) + pv;
+      const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+      const uint32_t d00 = ((s0 ^ pv0) | e.w0) | mv0, d01 = ((s1 ^ pv1) | e.w1) | mv1;
+      const uint32_t ph0 = mv0 | ~(d00 | pv0), ph1 = mv1 | ~(d01 | pv1);
+      const uint32_t mh0 = pv0 & d00, mh1 = pv1 & d01;
+      uint32_t p0, p1, m0, m1;
+      asm("v_add_co_u32 %0, vcc, %3, %3\n\tv_addc_co_u32 %1, vcc, %4, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+          : "=&v"(p0), "=&v"(p1), "+v"(score) : "v"(ph0), "v"(ph1) : "vcc");
+      asm("v_add_co_u32 %0, vcc, %3, %3\n\tv_addc_co_u32 %1, vcc, %4, %4, vcc\n\tv_subbrev_co_u32 %2, vcc, 0, %2, vcc"
+          : "=&v"(m0), "=&v"(m1), "+v"(score) : "v"(mh0), "v"(mh1) : "vcc");
+      pv0 = m0 | ~(d00 | p0); pv1 = m1 | ~(d01 | p1);
+      mv0 = p0 & d00;         mv1 = p1 & d01;
+   }
+};
+
 template <int NW>
 struct FusedLds {
    static constexpr int NT = 64 * NW;

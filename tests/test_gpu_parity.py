@@ -144,7 +144,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
     from seeq_amd import device as dev
     buf = open(os.path.join(GOLDEN, name), "rb").read()
     fasta = buf[:1] == b">"
-    fusable = len(dev.plain_pattern(pattern)) <= 30
+    fusable = len(dev.plain_pattern(pattern)) <= 62
     for nd in (SQ_FAIL, SQ_CONVERT, SQ_IGNORE):
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
             exp = oracle.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
@@ -424,3 +424,38 @@ def test_python_batched_api(gpu, capi, oracle):
     assert m.matchBestBatch([]) == []
     with pytest.raises(ValueError):
         m.matchBestBatch(["AC\nGT"])
+
+
+@pytest.mark.parametrize("m", [30, 31, 32, 33, 45, 62, 63])
+def test_two_word_fused_path(gpu, capi, oracle, m):
+    """Patterns of 31..62 positions take the two-word fused kernels (k_direct<4,2>, k_exact1<.,2>); 30 the
+    one-word ones, 63 the generic path.  Random class/N patterns, planted mutated copies, all modes."""
+    from seeq_amd import device as dev
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(1000 + m)
+    parts = []
+    for _ in range(m):
+        x = rng.random()
+        parts.append("N" if x < 0.05 else "[" + "".join(rng.sample("ACGT", 2)) + "]" if x < 0.12 else rng.choice("ACGT"))
+    pattern = "".join(parts)
+    tau = min(6, m - 1)
+    lines = []
+    for i in range(4000):
+        t = "".join(rng.choice("ACGT") for _ in range(rng.choice([0, 20, 150, 250, 400])))
+        if i % 5 == 0 and t:
+            cp = mutate(rng, plain(pattern), rng.randint(0, tau + 2))
+            q = rng.randrange(len(t) + 1)
+            t = t[:q] + cp + t[q + len(cp):]
+        if i % 97 == 0 and t:
+            q = rng.randrange(len(t)); t = t[:q] + rng.choice("NRn*") + t[q + 1:]
+        lines.append(t)
+    buf = ("\n".join(lines) + "\n").encode()
+    for opt in (SQ_FIRST, SQ_BEST | SQ_CONVERT, SQ_ALL | SQ_IGNORE, SQ_ALL):
+        exp = oracle.buffer_scan(pattern, tau, buf, opt)
+        got = _scan(capi, pattern, tau, buf, opt, dev.WANT_RECORDS, False, "auto")
+        assert got["path"] == ("fused" if m <= 62 else "generic")
+        assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"]
+        assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (m, opt)
+        cm = _scan(capi, pattern, tau, buf, opt, dev.WANT_COUNTMATCH, False, "auto")
+        assert cm["nhits"] == len(oracle.buffer_scan(pattern, tau, buf, (opt & ~3) | SQ_ALL)["records"])
