@@ -93,8 +93,9 @@ int seeqdevScanReserve(seeqdev_scan_t * scan, size_t max_bytes, size_t max_lines
  * tiles of the fused kernel.  0 (default) = estimate it from a 64 KiB sample of each new buffer. */
 int seeqdevScanSetLineHint(seeqdev_scan_t * scan, double avg_bytes_per_line);
 /* Which device path served the last run: 1 = generic (newline index + k_forward<W>),
- * 2 = fused, text tiles in LDS (k_fused), 3 = fused, text in registers (k_direct); the fused
- * kernels serve patterns <= 30 positions on read-length lines in ONE pass over the text. */
+ * 2 = fused, text tiles in LDS (k_fused), 3 = fused, text in registers (k_direct), 4 = fused,
+ * table-driven (k_dfa: the pattern's complete Levenshtein automaton in LDS; default options only).
+ * The fused kernels serve patterns <= 62 positions on read-length lines in ONE pass over the text. */
 int seeqdevScanLastPath(const seeqdev_scan_t * scan);
 
 /* Enqueue (asynchronously, on the context's stream) the whole hot path over

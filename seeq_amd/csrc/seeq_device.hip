@@ -86,7 +86,7 @@ struct Counters {
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
    uint32_t seg_tmp_hits;   /* k_fused: hit lines of this segment (summed per workgroup) */
-   uint32_t pad1;
+   uint32_t seg_nmatch;     /* lines of the segment with >= 1 verified hit (superset filters) */
    uint32_t pad2;
    uint64_t need_records;   /* total */
 };
@@ -111,6 +111,8 @@ struct ScanArgs {
    uint32_t      *nh;           /* per hit line: hits, then exclusive offsets */
    seeqdev_hit_t *records;      uint64_t cap_records;
    uint64_t      *rec_off;      /* per record: byte offset (in the whole buffer) of the line it belongs to */
+   uint32_t       use_nh;       /* record slots / line verdicts come from the per-line counts nh[] (ALL, COUNTMATCH,
+                                   or a superset filter such as k_dfa) */
    Counters      *cnt;
 };
 
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(WG) void k_exact(ScanArgs a)
             dst = c->records + a.nh[k];
             cap = 0xFFFFFFFFu;       /* exact count known from the COUNT pass */
          } else {
-            dst = c->records + k;
+            dst = c->records + (a.use_nh ? a.nh[k] : k);
             cap = 1;
          }
          sq_scan_line<W, SQ_MODE_EMIT>(a.text, a.nbytes, off, (const uint32_t *)s_peq,
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(WG) void k_rec_offsets(ScanArgs a)
    const Counters *c = a.cnt;
    if (c->overflow & 4u) return;
    const uint32_t nhl = c->seg_nhitlines;
-   const bool all = (a.options & 3) == SQ_ALL;
+   const bool all = (a.options & 3) == SQ_ALL || a.use_nh;
    const uint32_t stride = gridDim.x * WG;
    for (uint32_t k = blockIdx.x * WG + threadIdx.x; k < nhl; k += stride) {
       const uint64_t off = a.seg_base + a.hit_start[k];
@@ -479,6 +481,18 @@ __global__ __launch_bounds__(WG) void k_rec_offsets(ScanArgs a)
    }
 }
 
+/* Lines with >= 1 verified hit, from the per-line counts (before they are scanned into offsets). */
+__global__ __launch_bounds__(WG) void k_count_nonzero(ScanArgs a)
+{
+   const uint32_t nhl = a.cnt->seg_nhitlines;
+   const uint32_t stride = gridDim.x * WG;
+   uint32_t n = 0;
+   for (uint32_t k = blockIdx.x * WG + threadIdx.x; k < nhl; k += stride) n += a.nh[k] != 0;
+#pragma unroll
+   for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+   if ((threadIdx.x & 63) == 0 && n) atomicAdd(&a.cnt->seg_nmatch, n);
+}
+
 /* End of segment: fold the segment into the running totals. */
 __global__ void k_seg_end(ScanArgs a, int hits_from_nh)
 {
@@ -487,10 +501,10 @@ __global__ void k_seg_end(ScanArgs a, int hits_from_nh)
    const uint32_t seg_hits = hits_from_nh ? c->seg_nrec : c->seg_nhitlines;
    c->lines += counted;
    c->headers += c->seg_nheaders;
-   c->matchlines += c->seg_nhitlines;
+   c->matchlines += a.use_nh == 2 ? c->seg_nmatch : c->seg_nhitlines;   /* 2: the filter was a superset */
    c->hits += seg_hits;
    if (a.want == SEEQDEV_WANT_RECORDS) c->records += seg_hits;
-   c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = 0;
+   c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = c->seg_nmatch = 0;
 }
 
 /* SINGLELINE: the buffer is one string -> one line starting at 0. */
@@ -504,6 +518,10 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_fused.h"
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
+#include "seeq_dfa_kernel.h"
+extern "C" {
+#include "seeq_dfa.h"
+}
 
 /* ========================================================================== */
 /* Synthetic reads (bench / test input; CPU twin: oracle/seeq_oracle.c)        */
@@ -584,6 +602,10 @@ struct seeqdev_pattern {
    int       wlen, tau, words;
    int       device;
    uint32_t *d_peq;          /* [2][5][words] */
+   char     *keys;           /* host copy of the key bytes (DFA construction) */
+   int       dfa_state;      /* 0 not tried, 1 built, -1 too large */
+   uint16_t *d_dfa;          /* transition table in HBM (seeq_dfa.h), staged into LDS by k_dfa */
+   uint32_t  dfa_rows, dfa_final_base;
 };
 
 extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int tau)
@@ -603,6 +625,8 @@ extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int 
    seeqdev_pattern *p = (seeqdev_pattern *)calloc(1, sizeof *p);
    if (!p) return NULL;
    p->wlen = wlen; p->tau = tau; p->words = seeq_words_for(wlen);
+   p->keys = (char *)malloc((size_t)wlen);
+   if (p->keys) memcpy(p->keys, keys, (size_t)wlen);
    const size_t nw = (size_t)10 * p->words;
    uint32_t *h = (uint32_t *)malloc(nw * sizeof(uint32_t));
    char *rkeys = (char *)malloc((size_t)wlen);
@@ -627,6 +651,8 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
 {
    if (!p) return;
    if (p->d_peq) (void)hipFree(p->d_peq);
+   if (p->d_dfa) (void)hipFree(p->d_dfa);
+   free(p->keys);
    free(p);
 }
 
@@ -869,7 +895,7 @@ static int run_segments(seeqdev_scan *s)
    const bool fasta = (options & SEEQDEV_FASTA) != 0;
    const bool single = (options & SEEQDEV_SINGLELINE) != 0;
    const int match_opt = options & 3;
-   const bool need_nh = want == SEEQDEV_WANT_COUNTMATCH || (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   bool need_nh = want == SEEQDEV_WANT_COUNTMATCH || (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const size_t nbytes = s->nbytes;
    Counters *c = s->d_cnt;
 
@@ -900,10 +926,33 @@ static int run_segments(seeqdev_scan *s)
    int nw = FUSED_NW_DEFAULT;
    uint32_t halo = 0;
    unsigned nslices = 1;                      /* hit slices: one per k_fused workgroup / per k_direct wave */
-   bool use_direct = false;
+   bool use_direct = false, use_dfa = false;
+   size_t dfa_lds = 0;
    if (use_fused) {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
-      use_direct = !(ke && !strcmp(ke, "lds")) || fw == 2;        /* default: k_direct (text in registers) */
+      /* k_dfa: the table-driven scan.  Only for the default options (SQ_FAIL, line mode) -- there a non-DNA
+         byte ends the line, so column aliasing can only add spurious hit lines, which the exact pass weeds
+         out -- and only while the complete automaton fits the LDS table (seeq_dfa.h). */
+      const bool dfa_opts = (options & (MASK_NONDNA | MASK_INPUT)) == 0;
+      if (dfa_opts && s->avg_line * 63.5 <= 16.0 * 1024 - 64 && ke && !strcmp(ke, "dfa")) {      /* opt-in: see DESIGN.md */
+         seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
+         if (mp->dfa_state == 0 && mp->keys) {
+            seeq_dfa_t *d = seeq_dfa_build(mp->keys, mp->wlen, mp->tau);
+            mp->dfa_state = -1;
+            if (d) {
+               const size_t bytes = (size_t)d->nrows * 16;
+               if (hipMalloc((void **)&mp->d_dfa, bytes) == hipSuccess &&
+                   hipMemcpy(mp->d_dfa, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess) {
+                  mp->dfa_rows = d->nrows;
+                  mp->dfa_final_base = d->final_base;
+                  mp->dfa_state = 1;
+               }
+               seeq_dfa_free(d);
+            }
+         }
+         use_dfa = mp->dfa_state == 1;
+      }
+      use_direct = use_dfa || !(ke && !strcmp(ke, "lds")) || fw == 2;   /* k_direct / k_dfa: text in registers */
       if (use_direct && s->avg_line * 62.0 > 16.0 * 1024 - 64) use_direct = false;   /* regions are <= 16 KiB */
       const char *te = getenv("SEEQ_TILE_BYTES");
       if (use_direct) {
@@ -913,12 +962,20 @@ static int run_segments(seeqdev_scan *s)
          tile_bytes = ((uint32_t)want) & ~15u;
          if (te && atoi(te) >= 512 && atoi(te) <= DIRECT_MAXRR * 1024) tile_bytes = (uint32_t)atoi(te) & ~15u;
          int per_cu = 0;
+         if (use_dfa) {
+            nw = DFA_NW;
+            dfa_lds = (((size_t)pat->dfa_rows * 16 + 15) & ~(size_t)15) + (size_t)DFA_NW * DIRECT_SCAP * 4;
+            HIP_TRY(hipFuncSetAttribute((const void *)k_dfa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dfa_lds), EIO);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dfa, 64 * DFA_NW, dfa_lds) != hipSuccess || per_cu < 1)
+               per_cu = 1;
+            { const char *we = getenv("SEEQ_DFA_WGS"); if (we && atoi(we) >= 1 && atoi(we) < per_cu) per_cu = atoi(we); }
+         } else
          if ((fw == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4, 1>, 256, 0)
                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4, 2>, 256, 0)) != hipSuccess || per_cu < 1)
             per_cu = 1;
          fused_grid = (unsigned)(ncu * per_cu);
-         if ((size_t)fused_grid * 4 > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / 4);
-         nslices = fused_grid * 4;
+         if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
+         nslices = fused_grid * nw;                         /* one hit slice per wave */
       } else {
       const char *ne = getenv("SEEQ_FUSED_NW");
       if (ne && (atoi(ne) == 1 || atoi(ne) == 2 || atoi(ne) == 4)) nw = atoi(ne);
@@ -983,8 +1040,9 @@ static int run_segments(seeqdev_scan *s)
          s->eq_options = options;
       }
    }
-   s->last_path = use_fused ? (use_direct ? 3 : 2) : 1;
-   const bool generic_exact = getenv("SEEQ_EXACT") && !strcmp(getenv("SEEQ_EXACT"), "generic");   /* A/B knob */
+   s->last_path = use_fused ? (use_dfa ? 4 : use_direct ? 3 : 2) : 1;
+   if (use_dfa) need_nh = true;                          /* superset filter: every flagged line is verified */
+   const bool generic_exact = !use_dfa && getenv("SEEQ_EXACT") && !strcmp(getenv("SEEQ_EXACT"), "generic");   /* A/B knob */
 
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
@@ -1014,6 +1072,7 @@ static int run_segments(seeqdev_scan *s)
       a.hitmask = s->hitmask; a.hdrmask = s->hdrmask; a.wave_off = s->wave_off; a.hdr_off = s->hdr_off;
       a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
+      a.use_nh = need_nh ? (use_dfa ? 2u : 1u) : 0u;
       a.cnt = c;
 
       if (use_fused) {
@@ -1030,17 +1089,22 @@ static int run_segments(seeqdev_scan *s)
          f.wg_hits = s->wg_hits; f.wg_part = s->wg_part;
          { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
+         if (use_dfa) {
+            f.dfa = pat->d_dfa; f.dfa_rows = pat->dfa_rows; f.dfa_final_base = pat->dfa_final_base;
+            if (f.want == SEEQDEV_WANT_COUNTLINES) f.want = SEEQDEV_WANT_COUNTMATCH;   /* keep the hit-line list: it is verified below */
+         }
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
          const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */
          f.slice_cap = f.cap_tmp / nslices;
-         if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);
+         if (use_dfa) hipLaunchKernelGGL(k_dfa, dim3(fgrid), dim3(64 * DFA_NW), dfa_lds, s->stream, f);
+         else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);
          else if (use_direct) hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, s->stream, f);
          else if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
          else if (nw == 2) hipLaunchKernelGGL(k_fused<2>, dim3(fgrid), dim3(128), fused_lds, s->stream, f);
          else hipLaunchKernelGGL(k_fused<4>, dim3(fgrid), dim3(256), fused_lds, s->stream, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
          hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, s->stream, f, (uint32_t)nslices);
-         if (want != SEEQDEV_WANT_COUNTLINES) {
+         if (want != SEEQDEV_WANT_COUNTLINES || use_dfa) {
             launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
@@ -1065,7 +1129,7 @@ static int run_segments(seeqdev_scan *s)
       launch_scan<1>(s, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
       if (fasta) launch_scan<1>(s, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
       }
-      if (want != SEEQDEV_WANT_COUNTLINES) {
+      if (want != SEEQDEV_WANT_COUNTLINES || use_dfa) {
          /* ---- K3: compaction ---- */
          if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, s->stream, a);
          hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, s->stream, a);
@@ -1077,6 +1141,7 @@ static int run_segments(seeqdev_scan *s)
             if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
             else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            if (use_dfa) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */

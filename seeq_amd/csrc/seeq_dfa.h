@@ -1,0 +1,130 @@
+/*
+ * seeq_dfa.h -- host-side construction of the complete Levenshtein DFA of a pattern.
+ *
+ * This is the reference's own idea (a DFA whose states are the saturated Needleman-Wunsch columns,
+ * reference libseeq.c:698-842, doc/document.tex:92-136) taken to its conclusion for the GPU: instead
+ * of growing the automaton lazily while scanning, the WHOLE reachable automaton is built up front,
+ * breadth first, with every accepting state (D[m] <= tau) folded into one absorbing state -- the scan
+ * kernel only has to know whether a line ever reaches it.  For the headline pattern (20 positions,
+ * tau = 3) that is 3 342 states; the table (8 columns x u16 per state) is 53 KB and lives in LDS.
+ * Patterns whose automaton exceeds SEEQ_DFA_MAX_STATES keep using the bit-vector kernels.
+ *
+ * Row layout (16 bytes per state, entries are ROW BYTE OFFSETS so that the kernel's address is
+ * `state | (byte & 0xE)`):   column c = (byte >> 1) & 7
+ *      0 'A'  1 'C'  2 'T','U'  3 'G'  5 '\n'  7 'N'     (same for lower case);  4, 6: no DNA byte
+ * Bytes that are not DNA alias onto these columns.  Under SQ_FAIL such a byte ends the line
+ * (reference libseeq.c:267-270), so whatever the automaton does after it can only ADD spurious hit
+ * lines, never lose one: the filter is a superset and the exact pass verifies every flagged line.
+ */
+#ifndef SEEQ_DFA_H_
+#define SEEQ_DFA_H_
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SEEQ_DFA_MAX_STATES 4000        /* (states + 2 finals) * 16 B must fit 16-bit row offsets */
+
+typedef struct {
+   uint32_t  nstates;        /* BFS states incl. the absorbing accepting one */
+   uint32_t  acc_final;      /* row offset of ACC_FINAL; rows >= final_base are final */
+   uint32_t  dead_final;
+   uint32_t  final_base;
+   uint32_t  nrows;          /* nstates + 2 */
+   uint16_t *table;          /* nrows * 8 entries */
+} seeq_dfa_t;
+
+static inline void seeq_dfa_free(seeq_dfa_t *d) { if (d) { free(d->table); free(d); } }
+
+/* keys: one byte per pattern position (bit0 A, bit1 C, bit2 G, bit3 T, N = 0x1F).  Returns NULL when
+ * the automaton has more than SEEQ_DFA_MAX_STATES states (or on allocation failure). */
+static inline seeq_dfa_t *seeq_dfa_build(const char *keys, int m, int tau)
+{
+   if (m < 1 || m > 62 || tau < 0 || tau >= m) return NULL;
+   const int cap = SEEQ_DFA_MAX_STATES;
+   const size_t colsz = (size_t)m + 1;
+   uint8_t *cols = (uint8_t *)malloc((size_t)(cap + 1) * colsz);          /* state -> column */
+   uint32_t *next = (uint32_t *)malloc((size_t)(cap + 1) * 5 * sizeof(uint32_t));
+   const uint32_t HSZ = 16384;                                  /* open addressing, power of two */
+   int32_t *hash = (int32_t *)malloc(HSZ * sizeof(int32_t));
+   uint8_t *tmp = (uint8_t *)malloc(colsz);
+   seeq_dfa_t *d = NULL;
+   uint32_t n = 2;
+   static const int colof[5] = {0, 1, 3, 2, 7};                 /* column of a class: A C G T N */
+   if (!cols || !next || !hash || !tmp) goto done;
+   memset(hash, 0xFF, HSZ * sizeof(int32_t));
+   /* state 0 = root column min(i, tau+1) (reference libseeq.c:681-682); state 1 = ACC (absorbing) */
+   for (int i = 0; i <= m; i++) cols[i] = (uint8_t)(i <= tau ? i : tau + 1);
+   memset(cols + colsz, 0xFF, colsz);
+   {
+      uint32_t h = 2166136261u;
+      for (size_t i = 0; i < colsz; i++) h = (h ^ cols[i]) * 16777619u;
+      hash[h & (HSZ - 1)] = 0;
+   }
+   for (int c = 0; c < 5; c++) next[5 + c] = 1;                 /* ACC stays ACC */
+   for (uint32_t s = 0; s < n; s++) {
+      if (s == 1) continue;
+      const uint8_t *col = cols + (size_t)s * colsz;
+      for (int c = 0; c < 5; c++) {
+         /* one column of the saturated matrix: reference libseeq.c:767-786 */
+         const int bit = 1 << c;
+         int diag = col[0], up = 0;
+         tmp[0] = 0;
+         for (int i = 1; i <= m; i++) {
+            const int left = col[i];
+            int v = diag + ((keys[i - 1] & bit) == 0);
+            const int g = (up < left ? up : left) + 1;
+            if (g < v) v = g;
+            if (v > tau + 1) v = tau + 1;
+            tmp[i] = (uint8_t)v;
+            up = v;
+            diag = left;
+         }
+         uint32_t t;
+         if (tmp[m] <= tau) {
+            t = 1;                                               /* accepting: absorbed */
+         } else {
+            uint32_t h = 2166136261u;
+            for (size_t i = 0; i < colsz; i++) h = (h ^ tmp[i]) * 16777619u;
+            uint32_t slot = h & (HSZ - 1);
+            for (;;) {
+               const int32_t e = hash[slot];
+               if (e < 0) {
+                  if ((int)n >= cap) goto done;                  /* too large for the LDS table */
+                  memcpy(cols + (size_t)n * colsz, tmp, colsz);
+                  hash[slot] = (int32_t)n;
+                  t = n++;
+                  break;
+               }
+               if (memcmp(cols + (size_t)e * colsz, tmp, colsz) == 0) { t = (uint32_t)e; break; }
+               slot = (slot + 1) & (HSZ - 1);
+            }
+         }
+         next[(size_t)s * 5 + c] = t;
+      }
+   }
+   d = (seeq_dfa_t *)calloc(1, sizeof *d);
+   if (!d) goto done;
+   d->nstates = n;
+   d->nrows = n + 2;
+   d->final_base = n * 16;
+   d->acc_final = n * 16;
+   d->dead_final = (n + 1) * 16;
+   d->table = (uint16_t *)malloc((size_t)d->nrows * 8 * sizeof(uint16_t));
+   if (!d->table) { free(d); d = NULL; goto done; }
+   for (uint32_t s = 0; s < n; s++) {
+      uint16_t *row = d->table + (size_t)s * 8;
+      const uint16_t end = (uint16_t)(s == 1 ? d->acc_final : d->dead_final);
+      for (int k = 0; k < 8; k++) row[k] = end;                  /* '\n' and non-DNA columns: the line is over */
+      for (int c = 0; c < 5; c++) row[colof[c]] = (uint16_t)(next[(size_t)s * 5 + c] * 16);
+   }
+   for (int k = 0; k < 8; k++) {
+      d->table[(size_t)n * 8 + k] = (uint16_t)d->acc_final;      /* finals absorb everything */
+      d->table[(size_t)(n + 1) * 8 + k] = (uint16_t)d->dead_final;
+   }
+done:
+   free(cols); free(next); free(hash); free(tmp);
+   return d;
+}
+
+#endif

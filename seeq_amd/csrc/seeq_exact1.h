@@ -52,6 +52,8 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
    const int match_opt = a.options & 3;
    if (MODE == SQ_MODE_EMIT && (c->overflow & 4u)) return;
    const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1;
+   const bool count_any = a.want != SEEQDEV_WANT_COUNTMATCH && !(a.want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   const bool by_nh = a.use_nh != 0;                       /* record slots come from the scanned per-line counts */
    uint8_t *row = s_blk + threadIdx.x * EXACT1_ROW;
    const uint32_t stride = gridDim.x * 256;
    /* wave-uniform trip count so that every lane of a wave takes part in the wave-level votes */
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
       if (MODE == SQ_MODE_EMIT && !done) {
          line_no = a.hit_line[k];
          if (match_opt == SQ_ALL) { out = a.records + c->records + a.nh[k]; out_cap = 0xFFFFFFFFu; }
-         else { out = a.records + c->records + k; out_cap = 1; }
+         else { out = a.records + c->records + (by_nh ? a.nh[k] : k); out_cap = 1; }
       }
       while (__any(!done)) {
          /* next 64 bytes of my line -> my LDS row (bytes beyond the buffer read as NUL) */
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
                      const uint32_t p = pos + t;
                      if (MODE == SQ_MODE_COUNT) {
                         nhits++;
+                        if (count_any) end = true;                   /* presence is enough: FIRST/BEST/COUNTLINES */
                      } else if (match_opt == SQ_BEST) {
                         if (streak < best_d) { best_d = streak; best_end = p; nhits = 1; }
                      } else {

@@ -60,6 +60,9 @@ struct FusedArgs {
    uint32_t      *wg_hits;     /* per slice (workgroup of k_fused / wave of k_direct): entries stored */
    uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31}               */
    uint32_t       debug;       /* profiling experiments only (SEEQ_FUSED_DEBUG): 1 = skip the per-line scan */
+   const uint16_t *dfa;        /* k_dfa: transition table, dfa_rows x 8 u16 (seeq_dfa.h) */
+   uint32_t       dfa_rows;
+   uint32_t       dfa_final_base;   /* row offset of ACC_FINAL; DEAD_FINAL = +16 */
    Counters      *cnt;
 };
 
