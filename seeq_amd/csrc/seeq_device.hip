@@ -87,8 +87,10 @@ struct Counters {
    uint32_t need_hitlines;  /* max over segments */
    uint32_t seg_tmp_hits;   /* k_fused: hit lines of this segment (summed per workgroup) */
    uint32_t seg_nmatch;     /* lines of the segment with >= 1 verified hit (superset filters) */
-   uint32_t pad2;
+   uint32_t dirty;          /* k_stream: the text holds bytes outside {ACGTN, acgtn, '\n'}: its hit lines need verifying */
    uint64_t need_records;   /* total */
+   uint32_t prev_hit_line;  /* k_stream: line number of the last hit line of the previous segment (a line can span segments) */
+   uint32_t pad3;
 };
 
 struct ScanArgs {
@@ -111,8 +113,9 @@ struct ScanArgs {
    uint32_t      *nh;           /* per hit line: hits, then exclusive offsets */
    seeqdev_hit_t *records;      uint64_t cap_records;
    uint64_t      *rec_off;      /* per record: byte offset (in the whole buffer) of the line it belongs to */
-   uint32_t       use_nh;       /* record slots / line verdicts come from the per-line counts nh[] (ALL, COUNTMATCH,
-                                   or a superset filter such as k_dfa) */
+   uint32_t       use_nh;       /* record slots / line verdicts come from the per-line counts nh[]: 1 = ALL, COUNTMATCH;
+                                   2 = superset filter (k_dfa); 3 = k_stream (superset only when Counters.dirty,
+                                   hit list may repeat a line: hit_start = 0xFFFFFFFF marks a repeat) */
    Counters      *cnt;
 };
 
@@ -484,16 +487,21 @@ __global__ __launch_bounds__(WG) void k_rec_offsets(ScanArgs a)
 /* Lines with >= 1 verified hit, from the per-line counts (before they are scanned into offsets). */
 __global__ __launch_bounds__(WG) void k_count_nonzero(ScanArgs a)
 {
+   __shared__ uint32_t s_n[WG / 64];
    const uint32_t nhl = a.cnt->seg_nhitlines;
    const uint32_t stride = gridDim.x * WG;
    uint32_t n = 0;
    for (uint32_t k = blockIdx.x * WG + threadIdx.x; k < nhl; k += stride) n += a.nh[k] != 0;
 #pragma unroll
    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
-   if ((threadIdx.x & 63) == 0 && n) atomicAdd(&a.cnt->seg_nmatch, n);
+   if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+   __syncthreads();
+   if (threadIdx.x == 0) {                                 /* one atomic per block: same-address atomics serialise */
+      n = 0;
+      for (int w = 0; w < WG / 64; w++) n += s_n[w];
+      if (n) atomicAdd(&a.cnt->seg_nmatch, n);
+   }
 }
-
-/* End of segment: fold the segment into the running totals. */
 __global__ void k_seg_end(ScanArgs a, int hits_from_nh)
 {
    Counters *c = a.cnt;
@@ -501,7 +509,8 @@ __global__ void k_seg_end(ScanArgs a, int hits_from_nh)
    const uint32_t seg_hits = hits_from_nh ? c->seg_nrec : c->seg_nhitlines;
    c->lines += counted;
    c->headers += c->seg_nheaders;
-   c->matchlines += a.use_nh == 2 ? c->seg_nmatch : c->seg_nhitlines;   /* 2: the filter was a superset */
+   c->matchlines += a.use_nh >= 2 ? c->seg_nmatch : c->seg_nhitlines;   /* >= 2: the filter was a superset */
+   if (a.use_nh == 3 && c->seg_nhitlines) c->prev_hit_line = a.hit_line[c->seg_nhitlines - 1];
    c->hits += seg_hits;
    if (a.want == SEEQDEV_WANT_RECORDS) c->records += seg_hits;
    c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = c->seg_nmatch = 0;
@@ -519,6 +528,7 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_dfa_kernel.h"
+#include "seeq_stream.h"
 extern "C" {
 #include "seeq_dfa.h"
 }
@@ -606,6 +616,9 @@ struct seeqdev_pattern {
    int       dfa_state;      /* 0 not tried, 1 built, -1 too large */
    uint16_t *d_dfa;          /* transition table in HBM (seeq_dfa.h), staged into LDS by k_dfa */
    uint32_t  dfa_rows, dfa_final_base;
+   int       sdfa_state;     /* the streaming automaton of k_stream (seeq_dfa_build_stream), same states */
+   uint16_t *d_sdfa;
+   uint32_t  sdfa_rows, sdfa_final_base;
 };
 
 extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int tau)
@@ -652,6 +665,7 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
    if (!p) return;
    if (p->d_peq) (void)hipFree(p->d_peq);
    if (p->d_dfa) (void)hipFree(p->d_dfa);
+   if (p->d_sdfa) (void)hipFree(p->d_sdfa);
    free(p->keys);
    free(p);
 }
@@ -698,6 +712,7 @@ struct seeqdev_scan {
    float fwd_ms_avg;           /* mean k_forward launch duration of the last run */
    size_t seg_bytes;           /* segment size */
    bool user_reserved;         /* caller sized the per-line workspace: trust it */
+   bool no_stream;             /* k_stream met a line it cannot address (starts > 1 GiB before its segment): use the per-line kernels */
 };
 
 static int ws_alloc(void **p, size_t bytes)
@@ -926,7 +941,10 @@ static int run_segments(seeqdev_scan *s)
    int nw = FUSED_NW_DEFAULT;
    uint32_t halo = 0;
    unsigned nslices = 1;                      /* hit slices: one per k_fused workgroup / per k_direct wave */
-   bool use_direct = false, use_dfa = false;
+   bool use_direct = false, use_dfa = false, use_stream = false;
+   int stream_ch = 128;
+   const int stream_wu = pat->wlen + pat->tau - 1 <= 24 ? 6 : 8;     /* warm-up dwords */
+   const void *stream_fn = nullptr;
    size_t dfa_lds = 0;
    if (use_fused) {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
@@ -934,7 +952,28 @@ static int run_segments(seeqdev_scan *s)
          byte ends the line, so column aliasing can only add spurious hit lines, which the exact pass weeds
          out -- and only while the complete automaton fits the LDS table (seeq_dfa.h). */
       const bool dfa_opts = (options & (MASK_NONDNA | MASK_INPUT)) == 0;
-      if (dfa_opts && s->avg_line * 63.5 <= 16.0 * 1024 - 64 && ke && !strcmp(ke, "dfa")) {      /* opt-in: see DESIGN.md */
+      /* k_stream: line-agnostic table-driven scan (seeq_stream.h), the default whenever it applies */
+      if (dfa_opts && !fasta && !s->no_stream && pat->wlen + pat->tau - 1 <= 32 && (!ke || !strcmp(ke, "stream"))) {
+         seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
+         if (mp->sdfa_state == 0 && mp->keys) {
+            seeq_dfa_t *d = seeq_dfa_build_stream(mp->keys, mp->wlen, mp->tau);
+            mp->sdfa_state = -1;
+            if (d) {
+               const size_t bytes = (size_t)d->nrows * 16;
+               if (hipMalloc((void **)&mp->d_sdfa, bytes) == hipSuccess &&
+                   hipMemcpy(mp->d_sdfa, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess) {
+                  mp->sdfa_rows = d->nrows;
+                  mp->sdfa_final_base = d->acc_final;            /* state value of ACC_NEW */
+                  mp->sdfa_state = 1;
+               }
+               seeq_dfa_free(d);
+            }
+         }
+         const char *ce = getenv("SEEQ_STREAM_CH");
+         stream_ch = ce && atoi(ce) == 64 ? 64 : 128;
+         use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
+      }
+      if (!use_stream && dfa_opts && s->avg_line * 63.5 <= 16.0 * 1024 - 64 && ke && !strcmp(ke, "dfa")) {      /* opt-in: see DESIGN.md */
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (mp->dfa_state == 0 && mp->keys) {
             seeq_dfa_t *d = seeq_dfa_build(mp->keys, mp->wlen, mp->tau);
@@ -955,7 +994,22 @@ static int run_segments(seeqdev_scan *s)
       use_direct = use_dfa || !(ke && !strcmp(ke, "lds")) || fw == 2;   /* k_direct / k_dfa: text in registers */
       if (use_direct && s->avg_line * 62.0 > 16.0 * 1024 - 64) use_direct = false;   /* regions are <= 16 KiB */
       const char *te = getenv("SEEQ_TILE_BYTES");
-      if (use_direct) {
+      if (use_stream) {
+         use_direct = false;
+         nw = STREAM_NW;
+         tile_bytes = 64u * (uint32_t)stream_ch;
+         stream_fn = stream_ch == 128 ? (stream_wu == 6 ? (const void *)k_stream<128, 6> : (const void *)k_stream<128, 8>)
+                                      : (stream_wu == 6 ? (const void *)k_stream<64, 6> : (const void *)k_stream<64, 8>);
+         dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
+         HIP_TRY(hipFuncSetAttribute(stream_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dfa_lds), EIO);
+         int per_cu = 0;
+         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_fn, 64 * STREAM_NW, dfa_lds) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+         { const char *we = getenv("SEEQ_DFA_WGS"); if (we && atoi(we) >= 1 && atoi(we) < per_cu) per_cu = atoi(we); }
+         fused_grid = (unsigned)(ncu * per_cu);
+         if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
+         nslices = fused_grid * nw;                         /* one hit slice per wave */
+      } else if (use_direct) {
          nw = 4;
          double want = s->avg_line * 63.5;                /* <= 64 lines per region: one per lane */
          if (want < 512) want = 512;
@@ -1040,9 +1094,10 @@ static int run_segments(seeqdev_scan *s)
          s->eq_options = options;
       }
    }
-   s->last_path = use_fused ? (use_dfa ? 4 : use_direct ? 3 : 2) : 1;
-   if (use_dfa) need_nh = true;                          /* superset filter: every flagged line is verified */
-   const bool generic_exact = !use_dfa && getenv("SEEQ_EXACT") && !strcmp(getenv("SEEQ_EXACT"), "generic");   /* A/B knob */
+   s->last_path = use_fused ? (use_stream ? 5 : use_dfa ? 4 : use_direct ? 3 : 2) : 1;
+   const bool superset = use_dfa || use_stream;          /* the scan kernel's hit lines are candidates: nh[] decides */
+   if (superset) need_nh = true;
+   const bool generic_exact = !superset && getenv("SEEQ_EXACT") && !strcmp(getenv("SEEQ_EXACT"), "generic");   /* A/B knob */
 
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
@@ -1072,7 +1127,7 @@ static int run_segments(seeqdev_scan *s)
       a.hitmask = s->hitmask; a.hdrmask = s->hdrmask; a.wave_off = s->wave_off; a.hdr_off = s->hdr_off;
       a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
-      a.use_nh = need_nh ? (use_dfa ? 2u : 1u) : 0u;
+      a.use_nh = need_nh ? (use_stream ? 3u : use_dfa ? 2u : 1u) : 0u;
       a.cnt = c;
 
       if (use_fused) {
@@ -1093,10 +1148,25 @@ static int run_segments(seeqdev_scan *s)
             f.dfa = pat->d_dfa; f.dfa_rows = pat->dfa_rows; f.dfa_final_base = pat->dfa_final_base;
             if (f.want == SEEQDEV_WANT_COUNTLINES) f.want = SEEQDEV_WANT_COUNTMATCH;   /* keep the hit-line list: it is verified below */
          }
+         uint32_t pos_bias = 0;
+         if (use_stream) {
+            f.dfa = pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
+            /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
+            uint64_t room = 0xFFFFFFF0ull - a.seg_len;
+            if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;
+            pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room);
+            f.halo = pos_bias;
+         }
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
          const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */
          f.slice_cap = f.cap_tmp / nslices;
-         if (use_dfa) hipLaunchKernelGGL(k_dfa, dim3(fgrid), dim3(64 * DFA_NW), dfa_lds, s->stream, f);
+         if (use_stream) {
+            if (stream_ch == 128 && stream_wu == 6) hipLaunchKernelGGL((k_stream<128, 6>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else if (stream_ch == 128) hipLaunchKernelGGL((k_stream<128, 8>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else if (stream_wu == 6) hipLaunchKernelGGL((k_stream<64, 6>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else hipLaunchKernelGGL((k_stream<64, 8>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+         }
+         else if (use_dfa) hipLaunchKernelGGL(k_dfa, dim3(fgrid), dim3(64 * DFA_NW), dfa_lds, s->stream, f);
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);
          else if (use_direct) hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, s->stream, f);
          else if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
@@ -1104,12 +1174,13 @@ static int run_segments(seeqdev_scan *s)
          else hipLaunchKernelGGL(k_fused<4>, dim3(fgrid), dim3(256), fused_lds, s->stream, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
          hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, s->stream, f, (uint32_t)nslices);
-         if (want != SEEQDEV_WANT_COUNTLINES || use_dfa) {
+         if (want != SEEQDEV_WANT_COUNTLINES || superset) {
             launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
             hipLaunchKernelGGL(k_clear_tmp, dim3(1), dim3(1), 0, s->stream, c);
          }
+         a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
       } else {
       /* ---- K0: newline index ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[0], s->stream), EIO);
@@ -1129,19 +1200,20 @@ static int run_segments(seeqdev_scan *s)
       launch_scan<1>(s, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
       if (fasta) launch_scan<1>(s, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
       }
-      if (want != SEEQDEV_WANT_COUNTLINES || use_dfa) {
+      if (want != SEEQDEV_WANT_COUNTLINES || superset) {
          /* ---- K3: compaction ---- */
          if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, s->stream, a);
          hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, s->stream, a);
          const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
          if (grid_hits == 0) grid_hits = 1;
+         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a);   /* hit position -> line start; repeats dropped */
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
             if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
             else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
-            if (use_dfa) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            if (superset) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */
@@ -1238,6 +1310,7 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
       size_t nl = s->cap_lines, nhl = s->cap_hitlines, nrec = s->cap_records;
       if (h.overflow & 1u) nl = (size_t)h.need_lines + (h.need_lines >> 3) + 64;
       if (h.overflow & 2u) nhl = (size_t)h.need_hitlines + (h.need_hitlines >> 3) + 64;
+      if (h.overflow & 8u) s->no_stream = true;
       if (h.overflow & 4u) {
          /* need_records keeps counting after the overflow, so it is the total of this run. */
          nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;

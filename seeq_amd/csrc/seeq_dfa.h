@@ -19,6 +19,7 @@
 #ifndef SEEQ_DFA_H_
 #define SEEQ_DFA_H_
 
+#include <stdbool.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,11 +37,14 @@ typedef struct {
 
 static inline void seeq_dfa_free(seeq_dfa_t *d) { if (d) { free(d->table); free(d); } }
 
-/* keys: one byte per pattern position (bit0 A, bit1 C, bit2 G, bit3 T, N = 0x1F).  Returns NULL when
- * the automaton has more than SEEQ_DFA_MAX_STATES states (or on allocation failure). */
-static inline seeq_dfa_t *seeq_dfa_build(const char *keys, int m, int tau)
+/* Breadth-first construction of the reachable automaton.  keys: one byte per pattern position (bit0 A,
+ * bit1 C, bit2 G, bit3 T, N = 0x1F).  On success returns the number of states n (state 0 = root, state 1 =
+ * the absorbing accepting state) and *next_out = n * 5 transitions (classes A C G T N), to be free()d.
+ * Returns 0 when the automaton has more than SEEQ_DFA_MAX_STATES states (or on allocation failure). */
+static inline uint32_t seeq_dfa_bfs(const char *keys, int m, int tau, uint32_t **next_out)
 {
-   if (m < 1 || m > 62 || tau < 0 || tau >= m) return NULL;
+   *next_out = NULL;
+   if (m < 1 || m > 62 || tau < 0 || tau >= m) return 0;
    const int cap = SEEQ_DFA_MAX_STATES;
    const size_t colsz = (size_t)m + 1;
    uint8_t *cols = (uint8_t *)malloc((size_t)(cap + 1) * colsz);          /* state -> column */
@@ -48,9 +52,8 @@ static inline seeq_dfa_t *seeq_dfa_build(const char *keys, int m, int tau)
    const uint32_t HSZ = 16384;                                  /* open addressing, power of two */
    int32_t *hash = (int32_t *)malloc(HSZ * sizeof(int32_t));
    uint8_t *tmp = (uint8_t *)malloc(colsz);
-   seeq_dfa_t *d = NULL;
    uint32_t n = 2;
-   static const int colof[5] = {0, 1, 3, 2, 7};                 /* column of a class: A C G T N */
+   bool ok = false;
    if (!cols || !next || !hash || !tmp) goto done;
    memset(hash, 0xFF, HSZ * sizeof(int32_t));
    /* state 0 = root column min(i, tau+1) (reference libseeq.c:681-682); state 1 = ACC (absorbing) */
@@ -103,27 +106,96 @@ static inline seeq_dfa_t *seeq_dfa_build(const char *keys, int m, int tau)
          next[(size_t)s * 5 + c] = t;
       }
    }
-   d = (seeq_dfa_t *)calloc(1, sizeof *d);
-   if (!d) goto done;
-   d->nstates = n;
-   d->nrows = n + 2;
-   d->final_base = n * 16;
-   d->acc_final = n * 16;
-   d->dead_final = (n + 1) * 16;
-   d->table = (uint16_t *)malloc((size_t)d->nrows * 8 * sizeof(uint16_t));
-   if (!d->table) { free(d); d = NULL; goto done; }
-   for (uint32_t s = 0; s < n; s++) {
-      uint16_t *row = d->table + (size_t)s * 8;
-      const uint16_t end = (uint16_t)(s == 1 ? d->acc_final : d->dead_final);
-      for (int k = 0; k < 8; k++) row[k] = end;                  /* '\n' and non-DNA columns: the line is over */
-      for (int c = 0; c < 5; c++) row[colof[c]] = (uint16_t)(next[(size_t)s * 5 + c] * 16);
-   }
-   for (int k = 0; k < 8; k++) {
-      d->table[(size_t)n * 8 + k] = (uint16_t)d->acc_final;      /* finals absorb everything */
-      d->table[(size_t)(n + 1) * 8 + k] = (uint16_t)d->dead_final;
-   }
+   ok = true;
 done:
-   free(cols); free(next); free(hash); free(tmp);
+   free(cols); free(hash); free(tmp);
+   if (!ok) { free(next); return 0; }
+   *next_out = next;
+   return n;
+}
+
+static const int seeq_dfa_colof[5] = {0, 1, 3, 2, 7};           /* table column of a class: A C G T N */
+
+/* Per-line automaton (k_dfa): '\n' and the non-DNA columns lead to two absorbing final rows. */
+static inline seeq_dfa_t *seeq_dfa_build(const char *keys, int m, int tau)
+{
+   uint32_t *next = NULL;
+   const uint32_t n = seeq_dfa_bfs(keys, m, tau, &next);
+   if (!n) return NULL;
+   seeq_dfa_t *d = (seeq_dfa_t *)calloc(1, sizeof *d);
+   if (d) {
+      d->nstates = n;
+      d->nrows = n + 2;
+      d->final_base = n * 16;
+      d->acc_final = n * 16;
+      d->dead_final = (n + 1) * 16;
+      d->table = (uint16_t *)malloc((size_t)d->nrows * 8 * sizeof(uint16_t));
+      if (!d->table) { free(d); d = NULL; }
+   }
+   if (d) {
+      for (uint32_t s = 0; s < n; s++) {
+         uint16_t *row = d->table + (size_t)s * 8;
+         const uint16_t end = (uint16_t)(s == 1 ? d->acc_final : d->dead_final);
+         for (int k = 0; k < 8; k++) row[k] = end;               /* '\n' and non-DNA columns: the line is over */
+         for (int c = 0; c < 5; c++) row[seeq_dfa_colof[c]] = (uint16_t)(next[(size_t)s * 5 + c] * 16);
+      }
+      for (int k = 0; k < 8; k++) {
+         d->table[(size_t)n * 8 + k] = (uint16_t)d->acc_final;   /* finals absorb everything */
+         d->table[(size_t)(n + 1) * 8 + k] = (uint16_t)d->dead_final;
+      }
+   }
+   free(next);
+   return d;
+}
+
+/* Streaming automaton (k_stream): runs across line ends.  Special rows, as row byte offsets:
+ *    16           ACC_OLD   the line already has a hit (absorbing until the line ends)
+ *    acc_final    ACC_NEW   same row, entered by the transition that completes the FIRST hit of the line
+ *    dead_final   DEAD      a non-DNA byte ended the line (SQ_FAIL, reference libseeq.c:267-270); waits for '\n'
+ *    final_base+32 ROOT_NL  copy of the root row: the state right after a '\n'
+ * so "state == ACC_NEW" marks the text position where a line gets its first hit. */
+static inline seeq_dfa_t *seeq_dfa_build_stream(const char *keys, int m, int tau)
+{
+   uint32_t *next = NULL;
+   const uint32_t n = seeq_dfa_bfs(keys, m, tau, &next);
+   if (!n) return NULL;
+   seeq_dfa_t *d = (seeq_dfa_t *)calloc(1, sizeof *d);
+   if (d) {
+      d->nstates = n;
+      d->nrows = n + 3;
+      d->final_base = n * 16;
+      d->acc_final = n * 16;                                      /* ACC_NEW */
+      d->dead_final = (n + 1) * 16;                               /* DEAD */
+      d->table = (uint16_t *)malloc((size_t)d->nrows * 8 * sizeof(uint16_t));
+      if (!d->table) { free(d); d = NULL; }
+   }
+   if (d) {
+      /* Bank spreading: the DNA columns are the first 8 bytes of a row, i.e. half of the LDS banks a row
+         covers.  Odd rows are stored rotated by 8 bytes and their state VALUE carries bit 3, so that the
+         kernel's address "state ^ column" lands in the other half: all banks serve DNA transitions. */
+#define SEEQ_SV(row) ((uint16_t)((row) * 16 + (((row) & 1) ? 8 : 0)))
+      const uint32_t r_accnew = n, r_dead = n + 1, r_rootnl = n + 2;
+      const uint16_t acc_new = SEEQ_SV(r_accnew), dead = SEEQ_SV(r_dead), root_nl = SEEQ_SV(r_rootnl);
+      uint16_t lrow[8];                                           /* logical row: entry per column */
+      for (uint32_t s = 0; s < d->nrows; s++) {
+         const uint32_t src = s == r_accnew ? 1 : (s == r_rootnl ? 0 : s);     /* ACC_NEW = ACC_OLD row, ROOT_NL = root row */
+         for (int k = 0; k < 8; k++) lrow[k] = dead;              /* columns no DNA byte maps to */
+         lrow[5] = root_nl;                                       /* '\n' */
+         if (s != r_dead) {
+            for (int c = 0; c < 5; c++) {
+               const uint32_t t = next[(size_t)src * 5 + c];
+               lrow[seeq_dfa_colof[c]] = t == 1 ? (src == 1 ? SEEQ_SV(1) : acc_new) : SEEQ_SV(t);
+            }
+         }
+         uint16_t *row = d->table + (size_t)s * 8;
+         for (int k = 0; k < 8; k++) row[k ^ ((s & 1) ? 4 : 0)] = lrow[k];       /* 8-byte rotation = column ^ 4 */
+      }
+      d->acc_final = acc_new;                                     /* state VALUES (rotation bit included) */
+      d->dead_final = dead;
+      d->final_base = root_nl;
+#undef SEEQ_SV
+   }
+   free(next);
    return d;
 }
 

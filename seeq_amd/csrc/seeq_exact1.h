@@ -60,7 +60,14 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
    const uint32_t kmax = (nhl + stride - 1) / stride * stride;
    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < kmax; k += stride) {
       bool done = k >= nhl;
-      const uint64_t off = done ? a.seg_base : a.seg_base + a.hit_start[k];
+      const uint32_t hs = done ? 0u : a.hit_start[k];
+      if (hs == 0xFFFFFFFFu) done = true;                  /* k_stream: repeat of the previous entry's line */
+      if (MODE == SQ_MODE_COUNT && a.use_nh == 3 && count_any && !c->dirty) {
+         /* clean text: k_stream's verdict is exact (wave-uniform branch) */
+         if (k < nhl) a.nh[k] = done ? 0u : 1u;
+         continue;
+      }
+      const uint64_t off = done ? a.seg_base : a.seg_base + hs;
       const uint8_t *line = a.text + off;
       fused_state_t<W> st;
       st.init(m);

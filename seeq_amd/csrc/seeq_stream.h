@@ -1,0 +1,252 @@
+/*
+ * seeq_stream.h -- k_stream: line-agnostic, table-driven scan.  The text is read ONCE, coalesced by
+ * construction, and the per-character work is one LDS gather.
+ *
+ * k_direct / k_dfa give every lane one LINE; the lane then fetches its line with strided loads, which
+ * re-reads the text from L2 / HBM a second time and is what bounds those kernels.  Here a lane owns a
+ * fixed CHUNK of CH consecutive bytes (a wave owns a tile of 64 * CH bytes), whatever the line structure:
+ *
+ *   - The lane walks the streaming Levenshtein automaton of the pattern (seeq_dfa.h, seeq_dfa_build_stream:
+ *     the reference's DFA of saturated NW columns, libseeq.c:698-842, complete, in LDS) over its chunk,
+ *     after a WARM-UP over the 4*WU >= m+tau-1 bytes before it, started from the root state.  A hit ending at
+ *     text position j only depends on the m+tau bytes up to j, and the root column is the largest column
+ *     there is, so at every OWNED position "D[m][j] <= tau" is decided exactly as the line-long scan would.
+ *   - '\n' resets the automaton (ROOT_NL).  The first hit of a line inside a lane's window is marked by the
+ *     state ACC_NEW; the lane records it in a bit mask (v_cmp + v_addc per character).  A line that spans
+ *     chunks can be reported by more than one lane: duplicates are adjacent after the ordered compaction
+ *     and are dropped by k_stream_bounds.
+ *   - Newlines are found exactly (SDWA byte compare + v_addc into a second mask); the rank of a hit's line
+ *     is the number of newlines before the hit, so lines are numbered without ever building a line index.
+ *   - Bytes outside {A,C,G,T,N,a,c,g,t,n,'\n'} alias onto table columns; such a byte sets Counters.dirty and
+ *     every reported line is then verified by the exact pass (k_exact1 COUNT), exactly as for k_dfa.  On
+ *     clean input the exact pass trusts the filter.
+ *
+ * Per tile the wave emits {tile, rank among the tile's hits, hit position, line rank inside the tile}
+ * into its private slice (same layout as k_direct), tile_cl[] = line starts owned, tile_hits[].
+ * Only for SQ_FAIL + SQ_LINES, no FASTA, m + tau - 1 <= 32.
+ */
+#ifndef SEEQ_STREAM_H_
+#define SEEQ_STREAM_H_
+
+#define STREAM_NW 16
+
+#define STREAM_OR(K) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K \
+                         : "=v"(ad) : "v"(state), "v"(wm))
+#define STREAM_HIT asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(state), "v"(acc_new) : "vcc")
+#define STREAM_NL(K) asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" \
+                         : "+v"(nm) : "v"(w), "v"(ten) : "vcc")
+
+typedef __attribute__((address_space(3))) const uint16_t stream_lds_cu16;
+
+/* four warm-up characters: walk only */
+__device__ __forceinline__ void stream_warm4(uint32_t &state, uint32_t w)
+{
+   const uint32_t wm = w & 0x0E0E0E0Eu;
+   uint32_t ad;
+   STREAM_OR(0); state = *(stream_lds_cu16 *)(uintptr_t)ad;
+   STREAM_OR(1); state = *(stream_lds_cu16 *)(uintptr_t)ad;
+   STREAM_OR(2); state = *(stream_lds_cu16 *)(uintptr_t)ad;
+   STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad;
+}
+
+/* four owned characters: walk, first-hit mask, newline mask, alphabet check */
+__device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_t &hm, uint32_t &nm, uint32_t &bad,
+                                            uint32_t acc_new, uint32_t ten)
+{
+   const uint32_t wm = w & 0x0E0E0E0Eu;
+   /* canonical byte of each column (A C T G . \n . N); case folded text must equal it */
+   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, wm >> 1);
+   bad |= (w & 0xDFDFDFDFu) ^ canon;
+   uint32_t ad;
+   STREAM_OR(0); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(0);
+   STREAM_OR(1); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(1);
+   STREAM_OR(2); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(2);
+   STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(3);
+}
+
+/* the value of `x` in the previous lane; lane 0 gets `first` (DPP wave_shr:1) */
+__device__ __forceinline__ uint32_t stream_from_prev_lane(uint32_t x, uint32_t first)
+{
+   return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xf, 0xf, false);
+}
+
+template <int CH, int WU>
+__global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
+{
+   constexpr int NW = STREAM_NW;
+   constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
+   constexpr int NM = CH / 32;                            /* mask registers per lane */
+   constexpr uint32_t TB = 64u * CH;                      /* tile bytes */
+   static_assert(WU == 6 || WU == 8, "warm-up is 24 or 32 bytes");
+   extern __shared__ __align__(16) uint8_t dsmem[];
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   {
+      const fused_v4u *src = reinterpret_cast<const fused_v4u *>(a.dfa);
+      for (uint32_t i = tid; i < a.dfa_rows; i += 64 * NW) reinterpret_cast<fused_v4u *>(dsmem)[i] = src[i];
+   }
+   __syncthreads();                                       /* the only barrier: the table is read-only from here */
+   const uint32_t acc_new = a.dfa_final_base;              /* state value of ACC_NEW (seeq_dfa_build_stream) */
+   const uint32_t ten = 0x0Au;
+
+   const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
+   uint32_t wv_lines = 0, wv_hitlines = 0, slice_pos = 0, bad = 0;
+   bool wv_overflow = false;
+   uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
+   const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
+   const uint64_t last = a.nbytes - 1;
+
+   for (uint32_t tile = gwave; tile < a.ntiles; tile += nwaves) {
+      const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;
+      /* opaque per tile: keeps the compiler from hoisting the per-lane 64-bit addresses of the guarded loads
+         out of the tile loop (that costs ~20 VGPRs and spills) */
+      uint32_t lane_off = (uint32_t)lane * CH;
+      asm volatile("" : "+v"(lane_off));
+      const uint64_t my = t0 + lane_off;
+      const bool partial = t0 + TB > lim;                 /* wave-uniform */
+      fused_v4u v[NQ];
+      if (!partial) {
+         const uint8_t *p = a.text + my;
+#pragma unroll
+         for (int q = 0; q < NQ; q++) v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * q);
+      } else {
+#pragma unroll
+         for (int q = 0; q < NQ; q++) v[q] = dfa_load16(a.text, my + 16 * q, lim);       /* '\n' beyond the segment */
+      }
+      /* the 32 bytes before the tile (lane 0's warm-up); '\n' when the buffer starts here */
+      fused_v4u pa = fused_v4u{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}, pb = pa;
+      if (t0 >= 32) {
+         pa = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 32);
+         pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
+      }
+      /* ---- warm-up over the previous lane's last 4*WU bytes, from the root state ---- */
+      uint32_t state = 0;
+      {
+         if (WU == 8) {
+            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].x, pa.x));
+            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].y, pa.y));
+         }
+         stream_warm4(state, stream_from_prev_lane(v[NQ - 2].z, pa.z));
+         stream_warm4(state, stream_from_prev_lane(v[NQ - 2].w, pa.w));
+         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].x, pb.x));
+         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].y, pb.y));
+         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].z, pb.z));
+         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].w, pb.w));
+      }
+      /* ---- the owned chunk ---- */
+      uint32_t hmask[NM], nmask[NM];
+#pragma unroll
+      for (int r = 0; r < NM; r++) {
+         uint32_t hm = 0, nm = 0;
+#pragma unroll
+         for (int q = 2 * r; q < 2 * r + 2; q++) {
+            stream_own4(state, v[q].x, hm, nm, bad, acc_new, ten);
+            stream_own4(state, v[q].y, hm, nm, bad, acc_new, ten);
+            stream_own4(state, v[q].z, hm, nm, bad, acc_new, ten);
+            stream_own4(state, v[q].w, hm, nm, bad, acc_new, ten);
+         }
+         hmask[r] = hm; nmask[r] = nm;                    /* first character of the group = bit 31 */
+      }
+      /* ---- bookkeeping: what the tile owns ---- */
+      if (partial) {                                      /* filler bytes are nobody's newlines */
+         const uint32_t valid = lim > my ? (lim - my < CH ? (uint32_t)(lim - my) : (uint32_t)CH) : 0u;
+#pragma unroll
+         for (int r = 0; r < NM; r++) {
+            const uint32_t lo = 32u * r;
+            const uint32_t keep = valid <= lo ? 0u : (valid >= lo + 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (valid - lo)));
+            nmask[r] &= keep; hmask[r] &= keep;
+         }
+      }
+      if (t0 <= last && last < t0 + TB) {                 /* a newline in the very last byte starts no line */
+         const uint32_t o = (uint32_t)(last - t0);
+         if ((uint32_t)lane == o / CH) {
+            const uint32_t pos = o % CH;
+#pragma unroll
+            for (int r = 0; r < NM; r++)
+               if ((pos >> 5) == (uint32_t)r) nmask[r] &= ~(0x80000000u >> (pos & 31));
+         }
+      }
+      uint32_t lane_hits = 0, lane_nl = 0;
+#pragma unroll
+      for (int r = 0; r < NM; r++) { lane_hits += (uint32_t)__popc(hmask[r]); lane_nl += (uint32_t)__popc(nmask[r]); }
+      const uint32_t incl_h = wave_incl_scan_u32(lane_hits), incl_n = wave_incl_scan_u32(lane_nl);
+      const uint32_t tot_h = (uint32_t)__builtin_amdgcn_readlane((int)incl_h, 63);
+      const uint32_t tot_n = (uint32_t)__builtin_amdgcn_readlane((int)incl_n, 63);
+      const uint32_t extra = (a.first_seg && tile == 0) ? 1u : 0u;          /* the line starting at byte 0 */
+      /* ---- ordered compaction of the hit positions: per-wave slice, no atomics ---- */
+      if (tot_h) {
+         if (slice_pos + tot_h <= a.slice_cap) {
+            if (lane_hits) {
+               uint32_t ord = incl_h - lane_hits;
+               uint32_t nlb = incl_n - lane_nl + extra - 1u;                /* rank of the line my chunk starts in */
+#pragma unroll
+               for (int r = 0; r < NM; r++) {
+                  uint32_t mm = hmask[r];
+                  while (mm) {
+                     const uint32_t lz = (uint32_t)__builtin_clz(mm);
+                     mm &= ~(0x80000000u >> lz);
+                     const uint32_t nb = lz ? (uint32_t)__popc(nmask[r] >> (32 - lz)) : 0u;
+                     const uint32_t pseg = tile * TB + (uint32_t)lane * CH + 32u * r + lz;
+                     slice[slice_pos + ord] = make_uint4(tile, ord, pseg + a.halo /* position bias */, nlb + nb);
+                     ord++;
+                  }
+                  nlb += (uint32_t)__popc(nmask[r]);
+               }
+            }
+            slice_pos += tot_h;
+         } else {
+            wv_overflow = true;
+         }
+      }
+      if (lane == 0) {
+         a.tile_cl[tile] = tot_n + extra;
+         a.tile_hits[tile] = tot_h;
+      }
+      wv_lines += tot_n + extra;
+      wv_hitlines += tot_h;
+   }
+   if (__any(bad != 0) && lane == 0) atomicOr(&a.cnt->dirty, 1u);
+   if (lane == 0) {
+      a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
+      a.wg_part[3 * gwave + 0] = wv_lines;
+      a.wg_part[3 * gwave + 1] = 0;
+      a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
+   }
+}
+
+/* After the reorder: hit_start[k] holds the (biased) position of the first hit of a line, hit_line[k] its
+ * line number, both ascending.  Turn the position into the start of its line (the exact pass scans whole
+ * lines), and drop the repeats of a line (hit_start = 0xFFFFFFFF: k_exact1 skips the entry, nh = 0). */
+__global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a)
+{
+   Counters *c = a.cnt;
+   const uint32_t nhl = c->seg_nhitlines;
+   const uint32_t stride = gridDim.x * 256;
+   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
+      const uint32_t ln = a.hit_line[k];
+      const uint32_t prev = k ? a.hit_line[k - 1] : c->prev_hit_line;
+      if (ln == prev) { a.hit_start[k] = 0xFFFFFFFFu; continue; }
+      uint64_t q = a.seg_base + a.hit_start[k];          /* a byte of the line; never '\n' */
+      /* backwards to the byte after the previous '\n' (or the start of the buffer) */
+      while (q >= 16) {
+         const fused_v4u v = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + q - 16);
+         const uint32_t g3 = nl_flags(v.w), g2 = nl_flags(v.z), g1 = nl_flags(v.y), g0 = nl_flags(v.x);
+         if (g3 | g2 | g1 | g0) {
+            uint32_t byte;                                 /* index of the LAST newline among the 16 bytes */
+            if (g3) byte = 12 + ((31 - (uint32_t)__builtin_clz(g3)) >> 3);
+            else if (g2) byte = 8 + ((31 - (uint32_t)__builtin_clz(g2)) >> 3);
+            else if (g1) byte = 4 + ((31 - (uint32_t)__builtin_clz(g1)) >> 3);
+            else byte = (31 - (uint32_t)__builtin_clz(g0)) >> 3;
+            q = q - 16 + byte + 1;
+            goto found;
+         }
+         q -= 16;
+      }
+      while (q > 0 && a.text[q - 1] != '\n') q--;
+found:
+      if (q < a.seg_base) { atomicOr(&c->overflow, 8u); a.hit_start[k] = 0xFFFFFFFFu; }
+      else a.hit_start[k] = (uint32_t)(q - a.seg_base);
+   }
+}
+
+#endif

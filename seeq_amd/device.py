@@ -95,10 +95,10 @@ class Scanner:
         _check(self._lib.seeqdevScanSetLineHint(self._h, float(avg_bytes_per_line)))
 
     def last_path(self):
-        return {1: "generic", 2: "fused", 3: "fused", 4: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "generic", 2: "fused", 3: "fused", 4: "fused", 5: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
     def last_kernel(self):
-        return {1: "k_forward", 2: "k_fused", 3: "k_direct", 4: "k_dfa"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "k_forward", 2: "k_fused", 3: "k_direct", 4: "k_dfa", 5: "k_stream"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
     def last_times_ms(self):
         ms = (C.c_float * 4)()

@@ -112,16 +112,19 @@ def test_long_pattern_words(gpu, capi, oracle):
 
 def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=None):
     """One batched scan through the device C-ABI.  path: 'generic' (newline index + k_forward<W>),
-    'fused' = k_direct (text in registers), 'fused-lds' = k_fused (text tiles in LDS), 'fused-dfa' = k_dfa
-    (transition table in LDS; default options only, k_direct otherwise), or 'auto' (the library's own choice);
-    the env knobs are read by the library when the scan runs."""
+    'fused' = k_direct (text in registers), 'fused-lds' = k_fused (text tiles in LDS), 'fused-dfa' = k_dfa and
+    'fused-stream' = k_stream (transition table in LDS; default options only, k_direct otherwise; for k_stream
+    `tile` is the chunk size per lane), or 'auto' (the library's own choice); the env knobs are read by the
+    library when the scan runs."""
     from seeq_amd import device as dev
     if path != "auto":
-        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-lds": "lds", "fused-dfa": "dfa"}.get(path, "direct")
+        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-lds": "lds", "fused-dfa": "dfa", "fused-stream": "stream"}.get(path, "direct")
+    if tile and path == "fused-stream":
+        os.environ["SEEQ_STREAM_CH"] = str(tile)
+    elif tile:
+        os.environ["SEEQ_TILE_BYTES"] = str(tile)
     path = "fused" if path.startswith("fused-") else path
     os.environ["SEEQ_PATH"] = path
-    if tile:
-        os.environ["SEEQ_TILE_BYTES"] = str(tile)
     try:
         pat = dev.Pattern(pattern, tau)
         sc = dev.Scanner()
@@ -133,12 +136,14 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
     finally:
         os.environ.pop("SEEQ_PATH", None)
         os.environ.pop("SEEQ_TILE_BYTES", None)
+        os.environ.pop("SEEQ_STREAM_CH", None)
         os.environ.pop("SEEQ_FUSED_KERNEL", None)
     return res
 
 
 @pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024), ("fused-lds", None),
-                                       ("fused-lds", 4096), ("fused-dfa", None), ("fused-dfa", 1024)])
+                                       ("fused-lds", 4096), ("fused-dfa", None), ("fused-dfa", 1024),
+                                       ("fused-stream", None), ("fused-stream", 64)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
                                               ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3),
@@ -155,6 +160,8 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
             assert got["path"] == (path.split("-")[0] if fusable else "generic")     # the kernel under test really ran
             if path == "fused-dfa" and nd == SQ_FAIL and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
                 assert got["kernel"] == "k_dfa"
+            if path == "fused-stream" and nd == SQ_FAIL and not fasta and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
+                assert got["kernel"] == "k_stream"
             assert got["nlines"] == exp["nlines"]
             assert got["nmatchlines"] == exp["nmatchlines"]
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (name, mo, nd)
@@ -166,7 +173,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
         assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
 
 
-@pytest.mark.parametrize("path", ["generic", "fused", "fused-lds", "fused-dfa"])
+@pytest.mark.parametrize("path", ["generic", "fused", "fused-lds", "fused-dfa", "fused-stream"])
 def test_edge_buffers(gpu, capi, oracle, path):
     """Empty / ragged / maximum-ish inputs: no trailing newline, empty lines, NUL and CR bytes, a line longer
     than the LDS window (fused: falls back to the HBM per-line scan), 70 k empty lines (fused: many passes
@@ -181,11 +188,11 @@ def test_edge_buffers(gpu, capi, oracle, path):
     for buf in cases:
         for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
             exp = oracle.buffer_scan("ACGT", 1, buf, opt)
-            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, {"fused": 1024, "fused-lds": 4096, "fused-dfa": 1024}.get(path))
+            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, {"fused": 1024, "fused-lds": 4096, "fused-dfa": 1024, "fused-stream": 64}.get(path))
             assert got["nlines"] == exp["nlines"], (buf[:20], opt)
             assert got["nmatchlines"] == exp["nmatchlines"], (buf[:20], opt)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (buf[:20], opt)
-            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, {"fused": 1024, "fused-lds": 4096, "fused-dfa": 1024}.get(path))
+            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, {"fused": 1024, "fused-lds": 4096, "fused-dfa": 1024, "fused-stream": 64}.get(path))
             assert cnt["nmatchlines"] == exp["nmatchlines"] and cnt["nlines"] == exp["nlines"]
 
 
