@@ -933,27 +933,16 @@ static int run_segments(seeqdev_scan *s)
    /* fw = words of the fused kernels' column: 1 for <= 30 positions, 2 for 31..62 (two flag bits needed) */
    const int fw = pat->wlen <= FUSED_MAX_WLEN ? 1 : 2;
    const bool fusable = !single && pat->wlen <= FUSED_MAX_WLEN2;
-   bool use_fused = fusable && s->avg_line <= 600.0 && s->force_path != 1;
-   if (s->force_path == 2 && fusable) use_fused = true;
-   uint32_t tile_bytes = 0;
-   unsigned fused_grid = 1;
-   size_t fused_lds = 0;
-   int nw = FUSED_NW_DEFAULT;
-   uint32_t halo = 0;
-   unsigned nslices = 1;                      /* hit slices: one per k_fused workgroup / per k_direct wave */
-   bool use_direct = false, use_dfa = false, use_stream = false;
+   /* k_stream: line-agnostic table-driven scan (seeq_stream.h), the default whenever it applies -- any line
+      length.  Only for the default options (SQ_FAIL, line mode, no FASTA headers), m + tau - 1 <= 32 and while
+      the complete automaton fits the LDS table (seeq_dfa.h). */
+   bool use_stream = false;
    int stream_ch = 128;
-   const int stream_wu = pat->wlen + pat->tau - 1 <= 24 ? 6 : 8;     /* warm-up dwords */
-   const void *stream_fn = nullptr;
-   size_t dfa_lds = 0;
-   if (use_fused) {
+   {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
-      /* k_dfa: the table-driven scan.  Only for the default options (SQ_FAIL, line mode) -- there a non-DNA
-         byte ends the line, so column aliasing can only add spurious hit lines, which the exact pass weeds
-         out -- and only while the complete automaton fits the LDS table (seeq_dfa.h). */
       const bool dfa_opts = (options & (MASK_NONDNA | MASK_INPUT)) == 0;
-      /* k_stream: line-agnostic table-driven scan (seeq_stream.h), the default whenever it applies */
-      if (dfa_opts && !fasta && !s->no_stream && pat->wlen + pat->tau - 1 <= 32 && (!ke || !strcmp(ke, "stream"))) {
+      if (fusable && s->force_path != 1 && dfa_opts && !fasta && !s->no_stream && pat->wlen + pat->tau - 1 <= 32 &&
+          (!ke || !strcmp(ke, "stream"))) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (mp->sdfa_state == 0 && mp->keys) {
             seeq_dfa_t *d = seeq_dfa_build_stream(mp->keys, mp->wlen, mp->tau);
@@ -973,6 +962,25 @@ static int run_segments(seeqdev_scan *s)
          stream_ch = ce && atoi(ce) == 64 ? 64 : 128;
          use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
       }
+   }
+   bool use_fused = fusable && (s->avg_line <= 600.0 || use_stream) && s->force_path != 1;
+   if (s->force_path == 2 && fusable) use_fused = true;
+   uint32_t tile_bytes = 0;
+   unsigned fused_grid = 1;
+   size_t fused_lds = 0;
+   int nw = FUSED_NW_DEFAULT;
+   uint32_t halo = 0;
+   unsigned nslices = 1;                      /* hit slices: one per k_fused workgroup / per k_direct wave */
+   bool use_direct = false, use_dfa = false;
+   const int stream_wu = pat->wlen + pat->tau - 1 <= 24 ? 6 : 8;     /* warm-up dwords */
+   const void *stream_fn = nullptr;
+   size_t dfa_lds = 0;
+   if (use_fused) {
+      const char *ke = getenv("SEEQ_FUSED_KERNEL");
+      /* k_dfa: the table-driven scan.  Only for the default options (SQ_FAIL, line mode) -- there a non-DNA
+         byte ends the line, so column aliasing can only add spurious hit lines, which the exact pass weeds
+         out -- and only while the complete automaton fits the LDS table (seeq_dfa.h). */
+      const bool dfa_opts = (options & (MASK_NONDNA | MASK_INPUT)) == 0;
       if (!use_stream && dfa_opts && s->avg_line * 63.5 <= 16.0 * 1024 - 64 && ke && !strcmp(ke, "dfa")) {      /* opt-in: see DESIGN.md */
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (mp->dfa_state == 0 && mp->keys) {

@@ -471,3 +471,85 @@ def test_two_word_fused_path(gpu, capi, oracle, m):
         assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (m, opt)
         cm = _scan(capi, pattern, tau, buf, opt, dev.WANT_COUNTMATCH, False, "auto")
         assert cm["nhits"] == len(oracle.buffer_scan(pattern, tau, buf, (opt & ~3) | SQ_ALL)["records"])
+
+
+def _mutate(rng, pat, nerr):
+    """pat with nerr random edits (substitution / deletion / insertion)."""
+    s = list(pat)
+    for _ in range(nerr):
+        i = rng.randrange(len(s))
+        k = rng.randrange(3)
+        if k == 0:
+            s[i] = rng.choice("ACGT")
+        elif k == 1 and len(s) > 1:
+            del s[i]
+        else:
+            s.insert(i, rng.choice("ACGT"))
+    return "".join(s)
+
+
+@pytest.mark.parametrize("ch", [128, 64])
+def test_stream_chunk_and_tile_boundaries(gpu, capi, oracle, ch):
+    """k_stream gives lanes fixed chunks of the text, so hits, newlines and whole lines straddle chunk, tile
+    (64 chunks) and segment boundaries in every possible way: pattern copies planted at every offset around
+    the boundaries, lines from 0 to 30 000 bytes with several hits each (one line reported by many lanes),
+    non-DNA bytes before / after hits (dirty text: the filter's verdicts get verified), small segments."""
+    code = r'''
+import os, sys, random, numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from oracle.pyoracle import Oracle, SQ_ALL, SQ_BEST, SQ_FIRST
+from seeq_amd import device as dev
+from test_gpu_parity import _mutate
+o = Oracle()
+pat = "GATGTAGCGCGATTAGCCTG"
+rng = random.Random(77)
+def dna(n): return "".join(rng.choice("ACGT") for _ in range(n))
+tile = 64 * %d
+for dirty in (False, True):
+    parts = []
+    # 1. copies ending at every offset around the first tile boundaries (one line per copy, lengths vary)
+    for off in range(-40, 40):
+        pre = dna(rng.randrange(0, 200))
+        parts.append(pre + _mutate(rng, pat, rng.randrange(0, 5)) + dna(rng.randrange(0, 60)))
+    # 2. short and empty lines, lines shorter than the pattern
+    parts += ["", "A", dna(5), "", _mutate(rng, pat, 2), dna(19), pat, pat[:17]]
+    # 3. long lines: several hits each, one of them longer than three tiles
+    for n in (1000, tile - 7, tile, tile + 9, 30000):
+        line = dna(n)
+        for _ in range(1 + n // 700):
+            p = rng.randrange(0, max(1, n - 30))
+            c = _mutate(rng, pat, rng.randrange(0, 4))
+            line = line[:p] + c + line[p + len(c):]
+        parts.append(line[:n])
+    # 4. N in the text, lower case
+    parts += [pat[:8] + "N" + pat[9:], pat.lower(), dna(50) + pat[:5] + "NNN" + pat[8:] + dna(50)]
+    if dirty:       # bytes that alias onto table columns, before and after would-be hits
+        parts += [pat[:11] + "!" + pat[12:], dna(30) + "*" + pat + dna(10), pat + "\tX" + dna(40), "@read/1 " + pat,
+                  "+", "IIIIIIIIIIIIIIIIIIII!!!!&&&&((((***", dna(40) + "B" + pat[1:], "\r" + pat + "\r"]
+    rng.shuffle(parts)
+    for tail in ("\n", ""):
+        buf = ("\n".join(parts) + tail).encode()
+        p = dev.Pattern(pat, 3)
+        sc = dev.Scanner()
+        for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = o.buffer_scan(pat, 3, buf, opt)
+            got = sc.scan_host(p, buf, opt, dev.WANT_RECORDS)
+            assert sc.last_kernel() == "k_stream", sc.last_kernel()
+            assert got["nlines"] == exp["nlines"], (dirty, opt, got["nlines"], exp["nlines"])
+            assert got["nmatchlines"] == exp["nmatchlines"], (dirty, opt, got["nmatchlines"], exp["nmatchlines"])
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, opt)
+        expa = o.buffer_scan(pat, 3, buf, SQ_ALL)
+        c1 = sc.scan_host(p, buf, 0, dev.WANT_COUNTLINES)
+        c2 = sc.scan_host(p, buf, 0, dev.WANT_COUNTMATCH)
+        assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"]
+        assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
+        sc.close(); p.close()
+print("OK")
+''' % (ROOT, os.path.join(ROOT, "tests"), ch)
+    for seg in ("65536", "0"):
+        env = dict(os.environ, SEEQ_STREAM_CH=str(ch))
+        if seg != "0":
+            env["SEEQ_SEGMENT_BYTES"] = seg
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "OK" in r.stdout, (seg, r.stdout[-500:], r.stderr[-2000:])
