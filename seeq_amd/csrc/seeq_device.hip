@@ -733,7 +733,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    }
    seeqdev_scan *s = (seeqdev_scan *)calloc(1, sizeof *s);
    if (!s) return NULL;
-   s->seg_bytes = (size_t)1 << 31;          /* 2 GiB segments: u32 offsets, 16-byte aligned */
+   s->seg_bytes = (size_t)0xE0000000u;      /* 3.5 GiB segments: u32 offsets with room for k_stream's bias; multiple of every tile size */
    const char *env = getenv("SEEQ_SEGMENT_BYTES");
    if (env && atoll(env) >= 65536) s->seg_bytes = ((size_t)atoll(env) + 15) & ~(size_t)15;
    if (s->seg_bytes > 0xFFFF0000ull) s->seg_bytes = 0xFFFF0000ull;
@@ -1185,7 +1185,8 @@ static int run_segments(seeqdev_scan *s)
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
             launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
-            hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
+            hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line,
+                               use_stream ? s->nh : (uint32_t *)nullptr);
             hipLaunchKernelGGL(k_clear_tmp, dim3(1), dim3(1), 0, s->stream, c);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */

@@ -70,6 +70,19 @@ __device__ __forceinline__ uint32_t stream_from_prev_lane(uint32_t x, uint32_t f
    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xf, 0xf, false);
 }
 
+/* inclusive prefix maximum over the 64 lanes of a wave (DPP; lanes shifted in from outside read 0) */
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
+{
+   uint32_t y;
+   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); x = y > x ? y : x;   /* row_shr:1 */
+   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); x = y > x ? y : x;   /* row_shr:2 */
+   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); x = y > x ? y : x;   /* row_shr:4 */
+   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); x = y > x ? y : x;   /* row_shr:8 */
+   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true); x = y > x ? y : x;   /* row_bcast:15 */
+   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true); x = y > x ? y : x;   /* row_bcast:31 */
+   return x;
+}
+
 template <int CH, int WU>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
@@ -173,9 +186,19 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       const uint32_t tot_h = (uint32_t)__builtin_amdgcn_readlane((int)incl_h, 63);
       const uint32_t tot_n = (uint32_t)__builtin_amdgcn_readlane((int)incl_n, 63);
       const uint32_t extra = (a.first_seg && tile == 0) ? 1u : 0u;          /* the line starting at byte 0 */
-      /* ---- ordered compaction of the hit positions: per-wave slice, no atomics ---- */
+      /* ---- ordered compaction of the hit lines: per-wave slice, no atomics ---- */
       if (tot_h) {
          if (slice_pos + tot_h <= a.slice_cap) {
+            /* Where does the line of a hit start?  After the last newline before it: in my chunk, else in a
+               lower lane's chunk (prefix maximum), else before the tile -- then the entry carries the hit
+               position and k_stream_bounds searches backwards.  Offsets are tile-relative, +1 so 0 = none. */
+            uint32_t my_last = 0;
+#pragma unroll
+            for (int r = 0; r < NM; r++)
+               if (nmask[r]) my_last = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
+            const uint32_t incl_last = wave_incl_max_u32(my_last);
+            uint32_t before = stream_from_prev_lane(incl_last, 0u);        /* start+1 of the line my chunk begins in */
+            if (extra && before == 0) before = 1;                          /* ... the buffer starts here */
             if (lane_hits) {
                uint32_t ord = incl_h - lane_hits;
                uint32_t nlb = incl_n - lane_nl + extra - 1u;                /* rank of the line my chunk starts in */
@@ -185,11 +208,15 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
                   while (mm) {
                      const uint32_t lz = (uint32_t)__builtin_clz(mm);
                      mm &= ~(0x80000000u >> lz);
-                     const uint32_t nb = lz ? (uint32_t)__popc(nmask[r] >> (32 - lz)) : 0u;
-                     const uint32_t pseg = tile * TB + (uint32_t)lane * CH + 32u * r + lz;
-                     slice[slice_pos + ord] = make_uint4(tile, ord, pseg + a.halo /* position bias */, nlb + nb);
+                     const uint32_t nlt = lz ? nmask[r] >> (32 - lz) : 0u;  /* newlines before the hit, same group */
+                     const uint32_t nb = (uint32_t)__popc(nlt);
+                     const uint32_t st1 = nlt ? (uint32_t)lane * CH + 32u * r + lz - (uint32_t)__builtin_ctz(nlt) + 1u : before;
+                     const uint32_t pos = st1 ? st1 - 1u : (uint32_t)lane * CH + 32u * r + lz;
+                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord,
+                                                         tile * TB + pos + a.halo /* position bias */, nlb + nb);
                      ord++;
                   }
+                  if (nmask[r]) before = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
                   nlb += (uint32_t)__popc(nmask[r]);
                }
             }
@@ -226,6 +253,7 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a)
       const uint32_t ln = a.hit_line[k];
       const uint32_t prev = k ? a.hit_line[k - 1] : c->prev_hit_line;
       if (ln == prev) { a.hit_start[k] = 0xFFFFFFFFu; continue; }
+      if (!a.nh[k]) continue;                             /* k_stream already found the start of the line */
       uint64_t q = a.seg_base + a.hit_start[k];          /* a byte of the line; never '\n' */
       /* backwards to the byte after the previous '\n' (or the start of the buffer) */
       while (q >= 16) {
