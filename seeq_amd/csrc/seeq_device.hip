@@ -680,7 +680,7 @@ struct seeqdev_scan {
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
-   uint32_t *hit_start, *hit_line, *nh; uint4 *tmp; size_t cap_hitlines;
+   uint32_t *hit_start, *hit_line, *nh, *hit_col; uint4 *tmp; size_t cap_hitlines;
    /* fused path */
    uint32_t *tile_cl, *tile_hits; size_t cap_ftiles;
    uint32_t *wg_hits;             /* [MAX_FUSED_GRID] */
@@ -765,7 +765,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    (void)hipStreamSynchronize(s->stream);
    void *bufs[] = {s->rec_off, s->wg_hits, s->wg_part, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->d_eqtab,
-                   s->nh, s->records, s->scan_ws, s->d_cnt, s->d_text};
+                   s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
    if (s->h_eqtab) (void)hipHostFree(s->h_eqtab);
@@ -810,6 +810,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
       if (ws_alloc((void **)&s->hit_line, max_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->tmp, max_hitlines * sizeof(uint4))) return -1;
       if (ws_alloc((void **)&s->nh, max_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->hit_col, max_hitlines * sizeof(uint32_t))) return -1;
       s->cap_hitlines = max_hitlines;
    }
    if (max_records > s->cap_records) {
@@ -1185,8 +1186,8 @@ static int run_segments(seeqdev_scan *s)
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
             launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
-            hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line,
-                               use_stream ? s->nh : (uint32_t *)nullptr);
+            if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line, s->nh, s->hit_col);
+            else hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
             hipLaunchKernelGGL(k_clear_tmp, dim3(1), dim3(1), 0, s->stream, c);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
@@ -1216,11 +1217,12 @@ static int run_segments(seeqdev_scan *s)
          const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
          if (grid_hits == 0) grid_hits = 1;
-         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a);   /* hit position -> line start; repeats dropped */
+         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a, s->hit_col);   /* hit position -> line start; repeats dropped */
+         const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
-            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
-            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
+            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             if (superset) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
@@ -1228,8 +1230,8 @@ static int run_segments(seeqdev_scan *s)
          /* ---- K5: records ---- */
          if (want == SEEQDEV_WANT_RECORDS) {
             hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, s->stream, a);
-            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
-            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab);
+            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
+            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, s->stream, a);
          }

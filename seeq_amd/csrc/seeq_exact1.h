@@ -12,17 +12,31 @@
 
 #define EXACT1_ROW 80          /* LDS bytes per lane: 64 text bytes + pad, 16-byte aligned */
 
-/* Reverse start recovery, reference libseeq.c:289-316, on the reversed-pattern EQ table. */
+/* Reverse start recovery, reference libseeq.c:289-316, on the reversed-pattern EQ table.  `text + off` is
+ * the line, i the column the match ends before.  With `row` (the lane's 64-byte LDS row, free at that
+ * point) the 64 bytes before the match end are fetched with four loads up front instead of one dependent
+ * byte load per step; columns further back (non-base bytes skipped under SQ_IGNORE) come from memory. */
 template <int W>
-__device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *line, uint32_t i, uint32_t streak,
-                                                   uint32_t eqr_base, uint32_t m, uint32_t tau1)
+__device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *text, uint64_t off, uint64_t nbytes, uint32_t i, uint32_t streak,
+                                                   uint32_t eqr_base, uint32_t m, uint32_t tau1, uint8_t *row)
 {
+   const uint8_t *line = text + off;
+   uint64_t base = ~(uint64_t)0;                          /* absolute offset of row[0]; none */
+   if (row) {
+      const uint64_t end = off + i;
+      base = end >= 64 ? end - 64 : 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+         *reinterpret_cast<fused_v4u *>(row + 16 * q) = direct_load16(text, base + 16 * q, nbytes);
+   }
    fused_state_t<W> st;
    st.init(m);
    uint32_t j = 0, d = tau1, last_d, ignores = 0;
    do {
       ++j;
-      const fused_eq_t<W> ev = fused_eq_load<W>(eqr_base + ((uint32_t)line[i - j] << (W == 1 ? 2 : 3)));
+      const uint64_t at = off + (i - j);
+      const uint32_t b = at >= base ? (uint32_t)row[at - base] : (uint32_t)line[i - j];
+      const fused_eq_t<W> ev = fused_eq_load<W>(eqr_base + (b << (W == 1 ? 2 : 3)));
       const uint32_t e = ev.w0;
       last_d = d;
       if ((e & FUSED_FLAGS) == 0) {
@@ -37,8 +51,22 @@ __device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *line, uint32_t
    return (uint32_t)((int)i - jj);
 }
 
+template <int W> __device__ __forceinline__ void exact1_take(fused_state_t<W> &st, const fused_state_t<W> &s2, bool take);
+template <> __device__ __forceinline__ void exact1_take<1>(fused_state_t<1> &st, const fused_state_t<1> &s2, bool take)
+{
+   st.pv = take ? s2.pv : st.pv; st.mv = take ? s2.mv : st.mv; st.score = take ? s2.score : st.score;
+}
+template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st, const fused_state_t<2> &s2, bool take)
+{
+   st.pv0 = take ? s2.pv0 : st.pv0; st.pv1 = take ? s2.pv1 : st.pv1;
+   st.mv0 = take ? s2.mv0 : st.mv0; st.mv1 = take ? s2.mv1 : st.mv1; st.score = take ? s2.score : st.score;
+}
+
+/* hit_col (k_stream only, else NULL): column of the FIRST hit end of each line.  On clean text no earlier
+ * column has D[m] <= tau, so the scan may start 32 >= m + tau - 1 columns before it with a fresh column:
+ * from the hit column on the saturated scores -- all the acceptance rules look at -- are the same. */
 template <int MODE, int W>
-__global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
+__global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col)
 {
    __shared__ __align__(8) uint32_t s_eqf[256 * W];
    __shared__ __align__(8) uint32_t s_eqr[256 * W];
@@ -54,6 +82,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
    const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1;
    const bool count_any = a.want != SEEQDEV_WANT_COUNTMATCH && !(a.want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const bool by_nh = a.use_nh != 0;                       /* record slots come from the scanned per-line counts */
+   const bool trusted = a.use_nh == 3 && !c->dirty;        /* k_stream on clean text: its verdicts are exact */
    uint8_t *row = s_blk + threadIdx.x * EXACT1_ROW;
    const uint32_t stride = gridDim.x * 256;
    /* wave-uniform trip count so that every lane of a wave takes part in the wave-level votes */
@@ -62,16 +91,15 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
       bool done = k >= nhl;
       const uint32_t hs = done ? 0u : a.hit_start[k];
       if (hs == 0xFFFFFFFFu) done = true;                  /* k_stream: repeat of the previous entry's line */
-      if (MODE == SQ_MODE_COUNT && a.use_nh == 3 && count_any && !c->dirty) {
-         /* clean text: k_stream's verdict is exact (wave-uniform branch) */
-         if (k < nhl) a.nh[k] = done ? 0u : 1u;
+      if (MODE == SQ_MODE_COUNT && trusted && count_any) {
+         if (k < nhl) a.nh[k] = done ? 0u : 1u;            /* (wave-uniform branch) */
          continue;
       }
       const uint64_t off = done ? a.seg_base : a.seg_base + hs;
-      const uint8_t *line = a.text + off;
       fused_state_t<W> st;
       st.init(m);
       uint32_t streak = tau1, nhits = 0, best_d = tau1, best_end = 0, pos = 0;
+      if (hit_col && trusted && !done) { const uint32_t col = hit_col[k]; pos = col > 32 ? col - 32 : 0; }
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
       uint32_t out_cap = 0, line_no = 0;
@@ -87,46 +115,53 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
             for (int q = 0; q < 4; q++)
                *reinterpret_cast<fused_v4u *>(row + 16 * q) = direct_load16(a.text, off + pos + 16 * q, a.nbytes);
          }
-         for (uint32_t t = 0; t < 64; t++) {
+#pragma unroll 1
+         for (uint32_t t4 = 0; t4 < 64; t4 += 4) {
             if (!__any(!done)) break;
-            if (!done) {
-               const fused_eq_t<W> ev = fused_eq_load<W>(eqf_base + ((uint32_t)row[t] << (W == 1 ? 2 : 3)));
-               const uint32_t e = ev.w0;
-               if (!(e & FUSED_FLAG_SKIP)) {
-                  uint32_t cur = tau1;
-                  bool end = false;
-                  if (!(e & FUSED_FLAG_TERM)) {
-                     st.step(ev);
-                     cur = st.score < tau1 ? st.score : tau1;
-                  } else {
-                     end = true;
-                  }
-                  const bool stop = streak < cur, zero = streak == 0;
-                  const bool emit = stop ? !latch : zero;
-                  latch = stop ? true : zero;
+            /* four characters: the EQ lookups go out together, the column steps are predicated (no branches) */
+            const uint32_t w4 = *reinterpret_cast<const uint32_t *>(row + t4);
+            fused_eq_t<W> ev[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+               ev[cc] = fused_eq_load<W>(eqf_base + (((w4 >> (8 * cc)) & 0xFFu) << (W == 1 ? 2 : 3)));
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+               const uint32_t e = ev[cc].w0;
+               const bool term = (e & FUSED_FLAG_TERM) != 0;
+               const bool act = !done && !(e & FUSED_FLAG_SKIP);
+               fused_state_t<W> s2 = st;
+               s2.step(ev[cc]);
+               exact1_take<W>(st, s2, act && !term);
+               const uint32_t sc = s2.score < tau1 ? s2.score : tau1;
+               const uint32_t cur = term ? tau1 : sc;
+               const bool stop = streak < cur, zero = streak == 0;
+               const bool emit = act && (stop ? !latch : zero);
+               latch = act ? (stop ? true : zero) : latch;
+               const uint32_t p = pos + t4 + cc;
+               bool end = term;
+               if (MODE == SQ_MODE_COUNT) {
+                  nhits += emit ? 1u : 0u;
+                  end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */
+               } else if (match_opt == SQ_BEST) {
+                  const bool upd = emit && streak < best_d;
+                  best_d = upd ? streak : best_d; best_end = upd ? p : best_end; nhits = upd ? 1u : nhits;
+               } else if (__any(emit)) {
                   if (emit) {
-                     const uint32_t p = pos + t;
-                     if (MODE == SQ_MODE_COUNT) {
-                        nhits++;
-                        if (count_any) end = true;                   /* presence is enough: FIRST/BEST/COUNTLINES */
-                     } else if (match_opt == SQ_BEST) {
-                        if (streak < best_d) { best_d = streak; best_end = p; nhits = 1; }
-                     } else {
-                        if (nhits < out_cap) {
-                           seeqdev_hit_t h;
-                           h.line = line_no;
-                           h.start = exact1_reverse<W>(line, p, streak, eqr_base, m, tau1);
-                           h.end = p;
-                           h.dist = streak;
-                           out[nhits] = h;
-                        }
-                        nhits++;
-                        if (match_opt != SQ_ALL) end = true;            /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */
+                     if (nhits < out_cap) {
+                        seeqdev_hit_t h;
+                        h.line = line_no;
+                        /* the row is free only when the scan of this line ends here (SQ_FIRST) */
+                        h.start = exact1_reverse<W>(a.text, off, a.nbytes, p, streak, eqr_base, m, tau1, match_opt != SQ_ALL ? row : nullptr);
+                        h.end = p;
+                        h.dist = streak;
+                        out[nhits] = h;
                      }
+                     nhits++;
+                     if (match_opt != SQ_ALL) end = true;               /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */
                   }
-                  if (end) done = true;
-                  streak = cur;
                }
+               streak = act ? cur : streak;
+               done = done || (act && end);
             }
          }
          pos += 64;
@@ -137,7 +172,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2)
          } else if (match_opt == SQ_BEST && nhits) {
             seeqdev_hit_t h;
             h.line = line_no;
-            h.start = exact1_reverse<W>(line, best_end, best_d, eqr_base, m, tau1);
+            h.start = exact1_reverse<W>(a.text, off, a.nbytes, best_end, best_d, eqr_base, m, tau1, row);
             h.end = best_end;
             h.dist = best_d;
             out[0] = h;

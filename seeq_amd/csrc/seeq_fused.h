@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
 
 /* Slices -> ordered (hit_start, hit_line).  tile_hits / tile_cl hold exclusive prefixes by now.
    One workgroup per k_fused workgroup slice. */
-__global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line, uint32_t *unresolved)
+__global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line)
 {
    const Counters *c = a.cnt;
    if (c->overflow & 2u) return;
@@ -536,11 +536,9 @@ __global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t *hi
    const uint4 *slice = a.tmp + (size_t)blockIdx.x * a.slice_cap;
    for (uint32_t i = threadIdx.x; i < n; i += 256) {
       const uint4 e = slice[i];
-      const uint32_t tile = e.x & 0x7FFFFFFFu;
-      const uint32_t dst = a.tile_hits[tile] + e.y;
+      const uint32_t dst = a.tile_hits[e.x] + e.y;
       hit_start[dst] = e.z;
-      hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[tile] + e.w + 1);      /* 1-based, reference seeq.c:377 */
-      if (unresolved) unresolved[dst] = e.x >> 31;         /* k_stream: e.z is a byte of the line, not its start */
+      hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[e.x] + e.w + 1);      /* 1-based, reference seeq.c:377 */
    }
 }
 

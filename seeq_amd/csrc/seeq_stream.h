@@ -211,8 +211,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
                      const uint32_t nlt = lz ? nmask[r] >> (32 - lz) : 0u;  /* newlines before the hit, same group */
                      const uint32_t nb = (uint32_t)__popc(nlt);
                      const uint32_t st1 = nlt ? (uint32_t)lane * CH + 32u * r + lz - (uint32_t)__builtin_ctz(nlt) + 1u : before;
-                     const uint32_t pos = st1 ? st1 - 1u : (uint32_t)lane * CH + 32u * r + lz;
-                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord,
+                     const uint32_t hp = (uint32_t)lane * CH + 32u * r + lz;           /* the hit, tile-relative */
+                     const uint32_t pos = st1 ? st1 - 1u : hp;
+                     /* {tile | unresolved, rank | column of the hit << 13, line start (or hit) position, line rank} */
+                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord | ((hp - pos) << 13),
                                                          tile * TB + pos + a.halo /* position bias */, nlb + nb);
                      ord++;
                   }
@@ -241,10 +243,29 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    }
 }
 
+/* Slices -> ordered per-line arrays (tile_hits / tile_cl hold exclusive prefixes by now). */
+__global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line, uint32_t *unresolved,
+                                                        uint32_t *hit_col)
+{
+   const Counters *c = a.cnt;
+   if (c->overflow & 2u) return;
+   const uint32_t n = a.wg_hits[blockIdx.x];
+   const uint4 *slice = a.tmp + (size_t)blockIdx.x * a.slice_cap;
+   for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      const uint4 e = slice[i];
+      const uint32_t tile = e.x & 0x7FFFFFFFu;
+      const uint32_t dst = a.tile_hits[tile] + (e.y & 0x1FFFu);
+      hit_start[dst] = e.z;
+      hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[tile] + e.w + 1);     /* 1-based, reference seeq.c:377 */
+      unresolved[dst] = e.x >> 31;                        /* e.z is the hit itself: the line starts before the tile */
+      hit_col[dst] = e.y >> 13;
+   }
+}
+
 /* After the reorder: hit_start[k] holds the (biased) position of the first hit of a line, hit_line[k] its
  * line number, both ascending.  Turn the position into the start of its line (the exact pass scans whole
  * lines), and drop the repeats of a line (hit_start = 0xFFFFFFFF: k_exact1 skips the entry, nh = 0). */
-__global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a)
+__global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit_col)
 {
    Counters *c = a.cnt;
    const uint32_t nhl = c->seg_nhitlines;
@@ -273,7 +294,10 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a)
       while (q > 0 && a.text[q - 1] != '\n') q--;
 found:
       if (q < a.seg_base) { atomicOr(&c->overflow, 8u); a.hit_start[k] = 0xFFFFFFFFu; }
-      else a.hit_start[k] = (uint32_t)(q - a.seg_base);
+      else {
+         hit_col[k] = (uint32_t)(a.seg_base + a.hit_start[k] - q);
+         a.hit_start[k] = (uint32_t)(q - a.seg_base);
+      }
    }
 }
 
