@@ -49,14 +49,19 @@ __device__ __forceinline__ void stream_warm4(uint32_t &state, uint32_t w)
    STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad;
 }
 
-/* four owned characters: walk, first-hit mask, newline mask, alphabet check */
-__device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_t &hm, uint32_t &nm, uint32_t &bad,
+/* alphabet check of four characters: nonzero when a byte is outside {ACGTN, acgtn, '\n'} */
+__device__ __forceinline__ uint32_t stream_bad4(uint32_t w)
+{
+   /* canonical byte of each table column (A C T G . \n . N); the case-folded text must equal it */
+   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, (w & 0x0E0E0E0Eu) >> 1);
+   return (w & 0xDFDFDFDFu) ^ canon;
+}
+
+/* four owned characters: walk, first-hit mask, newline mask */
+__device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_t &hm, uint32_t &nm,
                                             uint32_t acc_new, uint32_t ten)
 {
    const uint32_t wm = w & 0x0E0E0E0Eu;
-   /* canonical byte of each column (A C T G . \n . N); case folded text must equal it */
-   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, wm >> 1);
-   bad |= (w & 0xDFDFDFDFu) ^ canon;
    uint32_t ad;
    STREAM_OR(0); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(0);
    STREAM_OR(1); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(1);
@@ -103,8 +108,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    const uint32_t ten = 0x0Au;
 
    const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
-   uint32_t wv_lines = 0, wv_hitlines = 0, slice_pos = 0, bad = 0;
+   uint32_t wv_lines = 0, wv_hitlines = 0, slice_pos = 0;                 /* wave-uniform */
    bool wv_overflow = false;
+   uint32_t wv_dirty = 0;
    uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
    const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
    const uint64_t last = a.nbytes - 1;
@@ -132,6 +138,16 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          pa = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 32);
          pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
       }
+      /* ---- alphabet check, done with before the walk starts (nothing of it stays live) ---- */
+      {
+         uint32_t bad = 0;
+#pragma unroll
+         for (int q = 0; q < NQ; q++) bad |= stream_bad4(v[q].x) | stream_bad4(v[q].y) | stream_bad4(v[q].z) | stream_bad4(v[q].w);
+         /* a byte outside the alphabet anywhere in the tile: the scan's verdicts need verifying */
+         uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(__any(bad != 0) ? 1 : 0);
+         asm volatile("" : "+s"(flag));                   /* pinned here: the walk below needs the registers */
+         wv_dirty |= flag;
+      }
       /* ---- warm-up over the previous lane's last 4*WU bytes, from the root state ---- */
       uint32_t state = 0;
       {
@@ -153,10 +169,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          uint32_t hm = 0, nm = 0;
 #pragma unroll
          for (int q = 2 * r; q < 2 * r + 2; q++) {
-            stream_own4(state, v[q].x, hm, nm, bad, acc_new, ten);
-            stream_own4(state, v[q].y, hm, nm, bad, acc_new, ten);
-            stream_own4(state, v[q].z, hm, nm, bad, acc_new, ten);
-            stream_own4(state, v[q].w, hm, nm, bad, acc_new, ten);
+            stream_own4(state, v[q].x, hm, nm, acc_new, ten);
+            stream_own4(state, v[q].y, hm, nm, acc_new, ten);
+            stream_own4(state, v[q].z, hm, nm, acc_new, ten);
+            stream_own4(state, v[q].w, hm, nm, acc_new, ten);
          }
          hmask[r] = hm; nmask[r] = nm;                    /* first character of the group = bit 31 */
       }
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       const uint32_t incl_h = wave_incl_scan_u32(lane_hits), incl_n = wave_incl_scan_u32(lane_nl);
       const uint32_t tot_h = (uint32_t)__builtin_amdgcn_readlane((int)incl_h, 63);
       const uint32_t tot_n = (uint32_t)__builtin_amdgcn_readlane((int)incl_n, 63);
-      const uint32_t extra = (a.first_seg && tile == 0) ? 1u : 0u;          /* the line starting at byte 0 */
+      const uint32_t extra = (uint32_t)__builtin_amdgcn_readfirstlane((a.first_seg && tile == 0) ? 1 : 0);   /* the line starting at byte 0 */
       /* ---- ordered compaction of the hit lines: per-wave slice, no atomics ---- */
       if (tot_h) {
          if (slice_pos + tot_h <= a.slice_cap) {
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       wv_lines += tot_n + extra;
       wv_hitlines += tot_h;
    }
-   if (__any(bad != 0) && lane == 0) atomicOr(&a.cnt->dirty, 1u);
+   if (wv_dirty && lane == 0) atomicOr(&a.cnt->dirty, 1u);
    if (lane == 0) {
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[3 * gwave + 0] = wv_lines;
