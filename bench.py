@@ -201,21 +201,28 @@ def main():
         fwd_avg_ms = fwd_ms / max(1, fwd_launches)
         achieved = algo_bytes_launch / (fwd_avg_ms * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_scan_kernel.json")
+        kern = sc.last_kernel()
+        pmc = os.path.join(ROOT, "profiles", "pmc_scan_kernels.json")
         if os.path.exists(pmc):
             try:
-                pj = json.load(open(pmc))
+                pj = json.load(open(pmc)).get(kern)
                 # HBM bytes per text byte measured with rocprofv3 PMC passes (profiles/), scaled to this launch size
-                if pj.get("kernel") == sc.last_kernel():
+                if pj:
                     traffic = pj["hbm_bytes_per_text_byte"] * (n * (READ_LEN + 1) / launches_per_step)
             except Exception:
                 traffic = None
+        notes = {
+            "k_stream": "line-agnostic table-driven scan: text read once (coalesced 128 B per lane), one LDS gather per "
+                        "character; bound by LDS gather issue (32 banks) just above the HBM stream time: see DESIGN.md",
+            "k_direct": "one-pass per-line scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte) and "
+                        "on re-reading lines from L2: see DESIGN.md",
+        }
         out = {
             "metric": "lines/s scanned (20 bp pattern, d=3, 150 bp reads; GB/s in gb_per_s)",
             "value": value, "unit": "lines/s", "gb_per_s": gbs,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u16" if kern == "k_stream" else "u32", "data": "synthetic",
             "config": {"workload": {"best": "BASELINE configs[2]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, "
                                             "--best with positions (ordered hit records)" % n,
                                     "count": "BASELINE configs[1]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, "
@@ -227,11 +234,11 @@ def main():
                         "oracle_prefix_check": check},
             "device_ms_per_step": {"newline_index": idx_ms / args.steps, "forward_scan": fwd_ms / args.steps,
                                    "compaction_exact_records": ex_ms / args.steps},
-            "roofline": {"bound": "hbm", "kernel": sc.last_kernel(), "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches_per_step": launches_per_step, "avg_launch_ms": fwd_avg_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "note": "one-pass scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte), HBM traffic ~1x: see DESIGN.md"},
+                         "note": notes.get(kern, "see DESIGN.md")},
         }
         if world == 1 and not args.no_e2e:
             # Timed region (ii) of SURVEY 8d: same path fed from page-locked HOST memory (H2D + scan + D2H of the

@@ -975,6 +975,7 @@ static int run_segments(seeqdev_scan *s)
    bool use_direct = false, use_dfa = false;
    const int stream_wu = pat->wlen + pat->tau - 1 <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
+   bool stream_ilp2 = false;
    size_t dfa_lds = 0;
    if (use_fused) {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
@@ -1007,8 +1008,10 @@ static int run_segments(seeqdev_scan *s)
          use_direct = false;
          nw = STREAM_NW;
          tile_bytes = 64u * (uint32_t)stream_ch;
-         stream_fn = stream_ch == 128 ? (stream_wu == 6 ? (const void *)k_stream<128, 6> : (const void *)k_stream<128, 8>)
-                                      : (stream_wu == 6 ? (const void *)k_stream<64, 6> : (const void *)k_stream<64, 8>);
+         { const char *ie = getenv("SEEQ_STREAM_ILP"); stream_ilp2 = stream_ch == 128 && !(ie && atoi(ie) == 1); }
+         stream_fn = stream_ch == 128 ? (stream_ilp2 ? (stream_wu == 6 ? (const void *)k_stream<128, 6, true> : (const void *)k_stream<128, 8, true>)
+                                                     : (stream_wu == 6 ? (const void *)k_stream<128, 6, false> : (const void *)k_stream<128, 8, false>))
+                                      : (stream_wu == 6 ? (const void *)k_stream<64, 6, false> : (const void *)k_stream<64, 8, false>);
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          HIP_TRY(hipFuncSetAttribute(stream_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dfa_lds), EIO);
          int per_cu = 0;
@@ -1170,10 +1173,12 @@ static int run_segments(seeqdev_scan *s)
          const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */
          f.slice_cap = f.cap_tmp / nslices;
          if (use_stream) {
-            if (stream_ch == 128 && stream_wu == 6) hipLaunchKernelGGL((k_stream<128, 6>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else if (stream_ch == 128) hipLaunchKernelGGL((k_stream<128, 8>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else if (stream_wu == 6) hipLaunchKernelGGL((k_stream<64, 6>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else hipLaunchKernelGGL((k_stream<64, 8>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            if (stream_ch == 128 && stream_ilp2 && stream_wu == 6) hipLaunchKernelGGL((k_stream<128, 6, true>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else if (stream_ch == 128 && stream_ilp2) hipLaunchKernelGGL((k_stream<128, 8, true>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else if (stream_ch == 128 && stream_wu == 6) hipLaunchKernelGGL((k_stream<128, 6, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else if (stream_ch == 128) hipLaunchKernelGGL((k_stream<128, 8, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else if (stream_wu == 6) hipLaunchKernelGGL((k_stream<64, 6, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+            else hipLaunchKernelGGL((k_stream<64, 8, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
          }
          else if (use_dfa) hipLaunchKernelGGL(k_dfa, dim3(fgrid), dim3(64 * DFA_NW), dfa_lds, s->stream, f);
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);

@@ -69,6 +69,33 @@ __device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_
    STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(3);
 }
 
+/* Two independent walks interleaved (chains A and B of one lane): twice the gathers in flight per wave. */
+#define STREAM_X2(K) \
+   asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K : "=v"(ada) : "v"(sa), "v"(wma)); \
+   asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K : "=v"(adb) : "v"(sb), "v"(wmb)); \
+   sa = *(stream_lds_cu16 *)(uintptr_t)ada; sb = *(stream_lds_cu16 *)(uintptr_t)adb;
+#define STREAM_EV2(K) \
+   asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hma) : "v"(sa), "v"(acc_new) : "vcc"); \
+   asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nma) : "v"(wa), "v"(ten) : "vcc"); \
+   asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hmb) : "v"(sb), "v"(acc_new) : "vcc"); \
+   asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nmb) : "v"(wb), "v"(ten) : "vcc");
+
+__device__ __forceinline__ void stream_warm4x2(uint32_t &sa, uint32_t wa, uint32_t &sb, uint32_t wb)
+{
+   const uint32_t wma = wa & 0x0E0E0E0Eu, wmb = wb & 0x0E0E0E0Eu;
+   uint32_t ada, adb;
+   STREAM_X2(0) STREAM_X2(1) STREAM_X2(2) STREAM_X2(3)
+}
+
+__device__ __forceinline__ void stream_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &nma,
+                                              uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t &nmb,
+                                              uint32_t acc_new, uint32_t ten)
+{
+   const uint32_t wma = wa & 0x0E0E0E0Eu, wmb = wb & 0x0E0E0E0Eu;
+   uint32_t ada, adb;
+   STREAM_X2(0) STREAM_EV2(0) STREAM_X2(1) STREAM_EV2(1) STREAM_X2(2) STREAM_EV2(2) STREAM_X2(3) STREAM_EV2(3)
+}
+
 /* the value of `x` in the previous lane; lane 0 gets `first` (DPP wave_shr:1) */
 __device__ __forceinline__ uint32_t stream_from_prev_lane(uint32_t x, uint32_t first)
 {
@@ -88,7 +115,7 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
    return x;
 }
 
-template <int CH, int WU>
+template <int CH, int WU, bool ILP2>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
@@ -148,6 +175,34 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          asm volatile("" : "+s"(flag));                   /* pinned here: the walk below needs the registers */
          wv_dirty |= flag;
       }
+      uint32_t hmask[NM], nmask[NM];
+      if (ILP2 && CH == 128) {
+         /* Two chains per lane: A = bytes 0..63 (warm-up: the previous lane's last bytes), B = bytes 64..127
+            (warm-up: my own bytes before 64).  Same result, 16 % more gathers, but two of them in flight. */
+         uint32_t sa = 0, sb = 0;
+         if (WU == 8) {
+            stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].x, pa.x), sb, v[NQ / 2 - 2].x);
+            stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].y, pa.y), sb, v[NQ / 2 - 2].y);
+         }
+         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].z, pa.z), sb, v[NQ / 2 - 2].z);
+         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].w, pa.w), sb, v[NQ / 2 - 2].w);
+         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].x, pb.x), sb, v[NQ / 2 - 1].x);
+         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].y, pb.y), sb, v[NQ / 2 - 1].y);
+         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].z, pb.z), sb, v[NQ / 2 - 1].z);
+         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].w, pb.w), sb, v[NQ / 2 - 1].w);
+#pragma unroll
+         for (int r = 0; r < NM / 2; r++) {
+            uint32_t hma = 0, nma = 0, hmb = 0, nmb = 0;
+#pragma unroll
+            for (int q = 2 * r; q < 2 * r + 2; q++) {
+               stream_own4x2(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, acc_new, ten);
+               stream_own4x2(sa, v[q].y, hma, nma, sb, v[q + NQ / 2].y, hmb, nmb, acc_new, ten);
+               stream_own4x2(sa, v[q].z, hma, nma, sb, v[q + NQ / 2].z, hmb, nmb, acc_new, ten);
+               stream_own4x2(sa, v[q].w, hma, nma, sb, v[q + NQ / 2].w, hmb, nmb, acc_new, ten);
+            }
+            hmask[r] = hma; nmask[r] = nma; hmask[r + NM / 2] = hmb; nmask[r + NM / 2] = nmb;
+         }
+      } else {
       /* ---- warm-up over the previous lane's last 4*WU bytes, from the root state ---- */
       uint32_t state = 0;
       {
@@ -163,7 +218,6 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          stream_warm4(state, stream_from_prev_lane(v[NQ - 1].w, pb.w));
       }
       /* ---- the owned chunk ---- */
-      uint32_t hmask[NM], nmask[NM];
 #pragma unroll
       for (int r = 0; r < NM; r++) {
          uint32_t hm = 0, nm = 0;
@@ -175,6 +229,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
             stream_own4(state, v[q].w, hm, nm, acc_new, ten);
          }
          hmask[r] = hm; nmask[r] = nm;                    /* first character of the group = bit 31 */
+      }
       }
       /* ---- bookkeeping: what the tile owns ---- */
       if (partial) {                                      /* filler bytes are nobody's newlines */
