@@ -1226,8 +1226,8 @@ static int run_segments(seeqdev_scan *s)
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
-            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
-            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
+            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
+            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             if (superset) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
@@ -1235,8 +1235,14 @@ static int run_segments(seeqdev_scan *s)
          /* ---- K5: records ---- */
          if (want == SEEQDEV_WANT_RECORDS) {
             hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, s->stream, a);
-            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
-            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
+            if (use_fused && !generic_exact) {
+               const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
+               const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
+#define SEEQ_EMIT1(WW, OO) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol)
+               if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST); else SEEQ_EMIT1(2, -1); }
+               else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST); else SEEQ_EMIT1(1, -1); }
+#undef SEEQ_EMIT1
+            }
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, s->stream, a);
          }

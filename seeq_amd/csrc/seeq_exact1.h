@@ -65,7 +65,9 @@ template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st,
 /* hit_col (k_stream only, else NULL): column of the FIRST hit end of each line.  On clean text no earlier
  * column has D[m] <= tau, so the scan may start 32 >= m + tau - 1 columns before it with a fresh column:
  * from the hit column on the saturated scores -- all the acceptance rules look at -- are the same. */
-template <int MODE, int W>
+/* OPT: the match option (SQ_FIRST / SQ_BEST / SQ_ALL; SQ_COUNT behaves as SQ_FIRST) as a compile-time constant for
+ * the EMIT kernels -- the per-character body then has no option branches; -1 = read it from a.options (COUNT). */
+template <int MODE, int W, int OPT>
 __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col)
 {
    __shared__ __align__(8) uint32_t s_eqf[256 * W];
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
    const uint32_t eqr_base = (uint32_t)(uintptr_t)(fused_lds_cu32 *)s_eqr;
    const Counters *c = a.cnt;
    const uint32_t nhl = c->seg_nhitlines;
-   const int match_opt = a.options & 3;
+   const int match_opt = OPT >= 0 ? OPT : (a.options & 3);
    if (MODE == SQ_MODE_EMIT && (c->overflow & 4u)) return;
    const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1;
    const bool count_any = a.want != SEEQDEV_WANT_COUNTMATCH && !(a.want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
