@@ -553,3 +553,55 @@ print("OK")
             env["SEEQ_SEGMENT_BYTES"] = seg
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "OK" in r.stdout, (seg, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_stream_fuzz_patterns(gpu, capi, oracle):
+    """Random patterns (1..26 positions, N and [..] classes, every distance k_stream takes) over random reads with
+    planted mutated copies, N, lower case and a few non-DNA bytes: FIRST/BEST/ALL records and both counts through
+    the library's own kernel choice (k_stream whenever the automaton fits) against the oracle."""
+    from seeq_amd import device as dev
+    rng = random.Random(2025)
+    kernels = {}
+    for it in range(40):
+        m = rng.choice([1, 2, 3, 5, 8, 12, 16, 20, 23, 26])
+        parts, plain = [], []
+        for _ in range(m):
+            r = rng.random()
+            if r < 0.08:
+                parts.append("N"); plain.append("N")
+            elif r < 0.18:
+                cls = "".join(sorted(set(rng.choice("ACGT") for _ in range(rng.randint(1, 3)))))
+                parts.append("[" + cls + "]"); plain.append(cls[0])
+            else:
+                c = rng.choice("ACGTacgt")
+                parts.append(c); plain.append(c.upper())
+        pattern, core = "".join(parts), "".join(plain)
+        tau = rng.randint(0, min(5, m - 1, 33 - m))
+        lines = []
+        for _ in range(1500):
+            n = rng.choice([0, 1, 7, 30, 60, 100, 151, 300])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            if n >= m and rng.random() < 0.4:
+                c = _mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
+                p = rng.randrange(0, n - len(c) + 1) if n >= len(c) else 0
+                t[p:p + len(c)] = list(c)
+            if rng.random() < 0.05 and n:
+                t[rng.randrange(n)] = "N"
+            if rng.random() < 0.03 and n:
+                t = [x.lower() for x in t]
+            if it % 4 == 3 and rng.random() < 0.02 and n:
+                t[rng.randrange(n)] = rng.choice("!*+BJXZ.\t\r@")
+            lines.append("".join(t)[:n])
+        buf = ("\n".join(lines) + ("\n" if it % 2 else "")).encode()
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = oracle.buffer_scan(pattern, tau, buf, mo)
+            got = _scan(capi, pattern, tau, buf, mo, dev.WANT_RECORDS)
+            kernels[got["kernel"]] = kernels.get(got["kernel"], 0) + 1
+            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, tau, mo)
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, mo)
+        expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL)
+        c1 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTLINES)
+        c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH)
+        assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], (pattern, tau)
+        assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau)
+    assert kernels.get("k_stream", 0) >= 60, kernels          # the automaton path really is what ran, mostly
