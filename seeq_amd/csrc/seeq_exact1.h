@@ -137,16 +137,23 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                const uint32_t sc = s2.score < tau1 ? s2.score : tau1;
                const uint32_t cur = term ? tau1 : sc;
                const bool stop = streak < cur, zero = streak == 0;
-               const bool emit = act && (stop ? !latch : zero);
-               latch = act ? (stop ? true : zero) : latch;
                const uint32_t p = pos + t4 + cc;
                bool end = term;
+               bool emit = false;
+               if (MODE == SQ_MODE_EMIT && match_opt == SQ_BEST) {
+                  /* SQ_BEST needs no latch: an emission the latch suppresses never beats best_d -- after a rise
+                     from s, best_d <= s already (by induction over consecutive rises), and after a zero-distance
+                     emission best_d = 0.  So: smallest distance, first position it is left or repeated as 0. */
+                  const bool upd = act && streak < best_d && (stop || zero);
+                  best_d = upd ? streak : best_d; best_end = upd ? p : best_end; nhits = upd ? 1u : nhits;
+               } else {
+                  emit = act && (stop ? !latch : zero);
+                  latch = act ? (stop ? true : zero) : latch;
+               }
                if (MODE == SQ_MODE_COUNT) {
                   nhits += emit ? 1u : 0u;
                   end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */
                } else if (match_opt == SQ_BEST) {
-                  const bool upd = emit && streak < best_d;
-                  best_d = upd ? streak : best_d; best_end = upd ? p : best_end; nhits = upd ? 1u : nhits;
                } else if (__any(emit)) {
                   if (emit) {
                      if (nhits < out_cap) {
