@@ -733,7 +733,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    }
    seeqdev_scan *s = (seeqdev_scan *)calloc(1, sizeof *s);
    if (!s) return NULL;
-   s->seg_bytes = (size_t)0xE0000000u;      /* 3.5 GiB segments: u32 offsets with room for k_stream's bias; multiple of every tile size */
+   s->seg_bytes = (size_t)0xF0000000u;      /* 3.75 GiB segments: u32 offsets with room for k_stream's bias; multiple of every tile size */
    const char *env = getenv("SEEQ_SEGMENT_BYTES");
    if (env && atoll(env) >= 65536) s->seg_bytes = ((size_t)atoll(env) + 15) & ~(size_t)15;
    if (s->seg_bytes > 0xFFFF0000ull) s->seg_bytes = 0xFFFF0000ull;

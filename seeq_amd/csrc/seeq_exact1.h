@@ -126,6 +126,28 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
 #pragma unroll
             for (int cc = 0; cc < 4; cc++)
                ev[cc] = fused_eq_load<W>(eqf_base + (((w4 >> (8 * cc)) & 0xFFu) << (W == 1 ? 2 : 3)));
+            if (MODE == SQ_MODE_EMIT && match_opt == SQ_BEST) {
+               /* SQ_BEST: smallest distance, first position where it is left (score rises) or repeated as 0.
+                  No latch is needed: an emission the latch suppresses never beats best_d -- after a rise from s,
+                  best_d <= s already (by induction over consecutive rises), and after a zero-distance emission
+                  best_d = 0.  A finished lane is fed the line-end flag: that step is idempotent. */
+#pragma unroll
+               for (int cc = 0; cc < 4; cc++) {
+                  const uint32_t e = done ? FUSED_FLAG_TERM : ev[cc].w0;
+                  const bool term = (e & FUSED_FLAG_TERM) != 0, skip = (e & FUSED_FLAG_SKIP) != 0;
+                  fused_state_t<W> s2 = st;
+                  s2.step(ev[cc]);
+                  exact1_take<W>(st, s2, (e & FUSED_FLAGS) == 0);
+                  const uint32_t sc = s2.score < tau1 ? s2.score : tau1;
+                  const uint32_t cur = term ? tau1 : sc;
+                  const bool upd = !skip && streak < best_d && (streak < cur || streak == 0);
+                  best_d = upd ? streak : best_d;
+                  best_end = upd ? pos + t4 + cc : best_end;
+                  streak = skip ? streak : cur;
+                  done = done || term;
+               }
+               continue;
+            }
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
                const uint32_t e = ev[cc].w0;
@@ -139,21 +161,11 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                const bool stop = streak < cur, zero = streak == 0;
                const uint32_t p = pos + t4 + cc;
                bool end = term;
-               bool emit = false;
-               if (MODE == SQ_MODE_EMIT && match_opt == SQ_BEST) {
-                  /* SQ_BEST needs no latch: an emission the latch suppresses never beats best_d -- after a rise
-                     from s, best_d <= s already (by induction over consecutive rises), and after a zero-distance
-                     emission best_d = 0.  So: smallest distance, first position it is left or repeated as 0. */
-                  const bool upd = act && streak < best_d && (stop || zero);
-                  best_d = upd ? streak : best_d; best_end = upd ? p : best_end; nhits = upd ? 1u : nhits;
-               } else {
-                  emit = act && (stop ? !latch : zero);
-                  latch = act ? (stop ? true : zero) : latch;
-               }
+               const bool emit = act && (stop ? !latch : zero);
+               latch = act ? (stop ? true : zero) : latch;
                if (MODE == SQ_MODE_COUNT) {
                   nhits += emit ? 1u : 0u;
                   end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */
-               } else if (match_opt == SQ_BEST) {
                } else if (__any(emit)) {
                   if (emit) {
                      if (nhits < out_cap) {
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       if (k < nhl) {
          if (MODE == SQ_MODE_COUNT) {
             a.nh[k] = nhits;
-         } else if (match_opt == SQ_BEST && nhits) {
+         } else if (match_opt == SQ_BEST && best_d < tau1) {
             seeqdev_hit_t h;
             h.line = line_no;
             h.start = exact1_reverse<W>(a.text, off, a.nbytes, best_end, best_d, eqr_base, m, tau1, row);
