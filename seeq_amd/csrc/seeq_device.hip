@@ -1224,10 +1224,11 @@ static int run_segments(seeqdev_scan *s)
          if (grid_hits == 0) grid_hits = 1;
          if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a, s->hit_col);   /* hit position -> line start; repeats dropped */
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
+         uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? s->tmp : nullptr;   /* COUNT -> EMIT */
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
-            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
-            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol);
+            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
+            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             if (superset) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
@@ -1238,7 +1239,7 @@ static int run_segments(seeqdev_scan *s)
             if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
                const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
-#define SEEQ_EMIT1(WW, OO) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol)
+#define SEEQ_EMIT1(WW, OO) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol, ecache)
                if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST); else SEEQ_EMIT1(2, -1); }
                else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST); else SEEQ_EMIT1(1, -1); }
 #undef SEEQ_EMIT1

@@ -67,8 +67,12 @@ template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st,
  * from the hit column on the saturated scores -- all the acceptance rules look at -- are the same. */
 /* OPT: the match option (SQ_FIRST / SQ_BEST / SQ_ALL; SQ_COUNT behaves as SQ_FIRST) as a compile-time constant for
  * the EMIT kernels -- the per-character body then has no option branches; -1 = read it from a.options (COUNT). */
+/* cache (16 B per hit line, the scan kernels' slice buffer, free by now; NULL = off): when records are wanted, the
+ * COUNT pass leaves the first two emissions {end, dist} of every line there (for SQ_BEST: the best one, and it then
+ * scans the whole line instead of stopping at the first hit), and the EMIT pass only recovers the starts of lines
+ * with <= 2 records instead of scanning them again. */
 template <int MODE, int W, int OPT>
-__global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col)
+__global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
 {
    __shared__ __align__(8) uint32_t s_eqf[256 * W];
    __shared__ __align__(8) uint32_t s_eqr[256 * W];
@@ -85,6 +89,9 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
    const bool count_any = a.want != SEEQDEV_WANT_COUNTMATCH && !(a.want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const bool by_nh = a.use_nh != 0;                       /* record slots come from the scanned per-line counts */
    const bool trusted = a.use_nh == 3 && !c->dirty;        /* k_stream on clean text: its verdicts are exact */
+   const bool caching = MODE == SQ_MODE_COUNT && cache != nullptr && a.want == SEEQDEV_WANT_RECORDS;
+   const bool count_best = caching && match_opt == SQ_BEST;
+   const bool cache_ok = MODE == SQ_MODE_EMIT && cache != nullptr && by_nh && !(trusted && count_any);
    uint8_t *row = s_blk + threadIdx.x * EXACT1_ROW;
    const uint32_t stride = gridDim.x * 256;
    /* wave-uniform trip count so that every lane of a wave takes part in the wave-level votes */
@@ -105,10 +112,21 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
       uint32_t out_cap = 0, line_no = 0;
+      uint32_t c0p = 0, c0d = 0, c1p = 0, c1d = 0, ncached = 0;       /* COUNT: what goes to the cache; EMIT: what came from it */
+      bool from_cache = false;
       if (MODE == SQ_MODE_EMIT && !done) {
          line_no = a.hit_line[k];
          if (match_opt == SQ_ALL) { out = a.records + c->records + a.nh[k]; out_cap = 0xFFFFFFFFu; }
          else { out = a.records + c->records + (by_nh ? a.nh[k] : k); out_cap = 1; }
+         if (cache_ok) {
+            ncached = (k + 1 < nhl ? a.nh[k + 1] : c->seg_nrec) - a.nh[k];
+            if (ncached <= 2) {                            /* the COUNT pass has seen every emission of this line */
+               const uint4 ce = cache[k];
+               c0p = ce.x; c0d = ce.y; c1p = ce.z; c1d = ce.w;
+               from_cache = true;
+               done = true;
+            }
+         }
       }
       while (__any(!done)) {
          /* next 64 bytes of my line -> my LDS row (bytes beyond the buffer read as NUL) */
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
 #pragma unroll
             for (int cc = 0; cc < 4; cc++)
                ev[cc] = fused_eq_load<W>(eqf_base + (((w4 >> (8 * cc)) & 0xFFu) << (W == 1 ? 2 : 3)));
-            if (MODE == SQ_MODE_EMIT && match_opt == SQ_BEST) {
+            if ((MODE == SQ_MODE_EMIT && match_opt == SQ_BEST) || (MODE == SQ_MODE_COUNT && count_best)) {
                /* SQ_BEST: smallest distance, first position where it is left (score rises) or repeated as 0.
                   No latch is needed: an emission the latch suppresses never beats best_d -- after a rise from s,
                   best_d <= s already (by induction over consecutive rises), and after a zero-distance emission
@@ -164,6 +182,10 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                const bool emit = act && (stop ? !latch : zero);
                latch = act ? (stop ? true : zero) : latch;
                if (MODE == SQ_MODE_COUNT) {
+                  if (caching) {
+                     const bool f0 = emit && nhits == 0, f1 = emit && nhits == 1;
+                     c0p = f0 ? p : c0p; c0d = f0 ? streak : c0d; c1p = f1 ? p : c1p; c1d = f1 ? streak : c1d;
+                  }
                   nhits += emit ? 1u : 0u;
                   end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */
                } else if (__any(emit)) {
@@ -189,7 +211,18 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       }
       if (k < nhl) {
          if (MODE == SQ_MODE_COUNT) {
+            if (count_best) { nhits = best_d < tau1 ? 1u : 0u; c0p = best_end; c0d = best_d; }
             a.nh[k] = nhits;
+            if (caching) cache[k] = make_uint4(c0p, c0d, c1p, c1d);
+         } else if (from_cache) {
+            for (uint32_t i = 0; i < ncached; i++) {
+               seeqdev_hit_t h;
+               h.line = line_no;
+               h.end = i ? c1p : c0p;
+               h.dist = i ? c1d : c0d;
+               h.start = exact1_reverse<W>(a.text, off, a.nbytes, h.end, h.dist, eqr_base, m, tau1, row);
+               out[i] = h;
+            }
          } else if (match_opt == SQ_BEST && best_d < tau1) {
             seeqdev_hit_t h;
             h.line = line_no;
