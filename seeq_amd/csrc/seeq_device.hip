@@ -1193,7 +1193,6 @@ static int run_segments(seeqdev_scan *s)
             launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line, s->nh, s->hit_col);
             else hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
-            hipLaunchKernelGGL(k_clear_tmp, dim3(1), dim3(1), 0, s->stream, c);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
       } else {

@@ -66,8 +66,6 @@ struct FusedArgs {
    Counters      *cnt;
 };
 
-__global__ void k_clear_tmp(Counters *c) { c->seg_tmp_hits = 0; }
-
 /* One Myers column step on a TOP-aligned pattern (row m = bit 31).  The two
  * left shifts double as the extraction of the horizontal delta of row m: the
  * carry out of ph+ph / mh+mh is +1 / -1 on D[m][j]. */
