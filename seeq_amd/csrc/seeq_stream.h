@@ -152,8 +152,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       const bool partial = t0 + TB > lim;                 /* wave-uniform */
       fused_v4u v[NQ];
       if (!partial) {
-         /* (debug 32, profiling experiment only: every tile re-reads the wave's FIRST tile -- walk without HBM traffic) */
-         const uint8_t *p = a.text + ((a.debug & 32u) ? a.seg_base + (uint64_t)gwave * TB + lane_off : my);
+         const uint8_t *p = a.text + my;
 #pragma unroll
          for (int q = 0; q < NQ; q++)
             v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * q);   /* (nt loads: the eight loads of a 128-B line no longer merge in L1 -- 2x slower) */
@@ -163,16 +162,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       }
       /* the 32 bytes before the tile (lane 0's warm-up); '\n' when the buffer starts here */
       fused_v4u pa = fused_v4u{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}, pb = pa;
-      if (t0 >= 32 && !(a.debug & 4u)) {
+      if (t0 >= 32) {
          pa = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 32);
          pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
-      }
-      if (a.debug & 16u) {                               /* profiling experiment only: the bare loads */
-         uint32_t acc = pa.x ^ pb.y;
-#pragma unroll
-         for (int q = 0; q < NQ; q++) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
-         if (__any(acc == 0x12345678u)) wv_lines++;
-         continue;
       }
       /* ---- alphabet check, done with before the walk starts (nothing of it stays live) ---- */
       {
@@ -185,10 +177,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          wv_dirty |= flag;
       }
       uint32_t hmask[NM], nmask[NM];
-      if (a.debug & 1u) {                                  /* profiling experiment only (SEEQ_FUSED_DEBUG=1): loads without the walk */
-#pragma unroll
-         for (int r = 0; r < NM; r++) { hmask[r] = 0; nmask[r] = v[2 * r].x & v[2 * r + 1].y & 1u; }
-      } else if (ILP2 && CH == 128) {
+      if (ILP2 && CH == 128) {
          /* Two chains per lane: A = bytes 0..63 (warm-up: the previous lane's last bytes), B = bytes 64..127
             (warm-up: my own bytes before 64).  Same result, 16 % more gathers, but two of them in flight. */
          uint32_t sa = 0, sb = 0;
@@ -310,7 +299,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
             wv_overflow = true;
          }
       }
-      if (lane == 0 && !(a.debug & 8u)) {
+      if (lane == 0) {
          a.tile_cl[tile] = tot_n + extra;
          a.tile_hits[tile] = tot_h;
       }
