@@ -1243,8 +1243,10 @@ static int run_segments(seeqdev_scan *s)
                else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST); else SEEQ_EMIT1(1, -1); }
 #undef SEEQ_EMIT1
             }
-            else hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
-            hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            else {
+               hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+               hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, s->stream, a);    /* k_exact1 writes them itself */
+            }
          }
       }
       hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, need_nh ? 1 : 0);

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                         h.end = p;
                         h.dist = streak;
                         out[nhits] = h;
+                        a.rec_off[(out - a.records) + nhits] = off;
                      }
                      nhits++;
                      if (match_opt != SQ_ALL) end = true;               /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                h.dist = i ? c1d : c0d;
                h.start = exact1_reverse<W>(a.text, off, a.nbytes, h.end, h.dist, eqr_base, m, tau1, row);
                out[i] = h;
+               a.rec_off[(out - a.records) + i] = off;     /* byte offset of the record's line (seeqdevScanCopyOffsets) */
             }
          } else if (match_opt == SQ_BEST && best_d < tau1) {
             seeqdev_hit_t h;
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
             h.end = best_end;
             h.dist = best_d;
             out[0] = h;
+            a.rec_off[out - a.records] = off;
          }
       }
    }
