@@ -4,7 +4,9 @@
  *
  * k_direct / k_dfa give every lane one LINE; the lane then fetches its line with strided loads, which
  * re-reads the text from L2 / HBM a second time and is what bounds those kernels.  Here a lane owns a
- * fixed CHUNK of CH consecutive bytes (a wave owns a tile of 64 * CH bytes), whatever the line structure:
+ * fixed CHUNK of CH consecutive bytes (a wave owns a tile of 64 * CH bytes), whatever the line structure;
+ * with CH = 128 every 128-byte memory line is consumed whole by one lane (eight back-to-back 16-byte loads
+ * that L1 merges; measured HBM traffic 1.02x the text):
  *
  *   - The lane walks the streaming Levenshtein automaton of the pattern (seeq_dfa.h, seeq_dfa_build_stream:
  *     the reference's DFA of saturated NW columns, libseeq.c:698-842, complete, in LDS) over its chunk,
@@ -21,9 +23,15 @@
  *     every reported line is then verified by the exact pass (k_exact1 COUNT), exactly as for k_dfa.  On
  *     clean input the exact pass trusts the filter.
  *
- * Per tile the wave emits {tile, rank among the tile's hits, hit position, line rank inside the tile}
- * into its private slice (same layout as k_direct), tile_cl[] = line starts owned, tile_hits[].
- * Only for SQ_FAIL + SQ_LINES, no FASTA, m + tau - 1 <= 32.
+ *   - ILP2: the chunk is walked as two independent chains (bytes 0-63 warm up on the previous lane's tail, bytes
+ *     64-127 on the lane's own bytes 40-63), so two gathers are in flight per lane.
+ *
+ * Per tile the wave emits {tile | unresolved, rank among the tile's hits | column of the hit, start of the hit's
+ * line (or the hit position when the line starts before the tile), line rank inside the tile} into its private
+ * slice, and tile_cl[] = line starts owned, tile_hits[] (same layout as k_direct).  k_stream_reorder orders the
+ * entries, k_stream_bounds finishes the unresolved ones and drops repeats of a line.
+ * Only for SQ_FAIL + SQ_LINES, no FASTA, m + tau - 1 <= 32, automaton <= 4 000 states.
+ * What bounds it: the LDS gather unit (32 banks: 5.6 cycles per 64-lane gather), HBM hidden.
  */
 #ifndef SEEQ_STREAM_H_
 #define SEEQ_STREAM_H_
