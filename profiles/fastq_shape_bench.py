@@ -23,6 +23,7 @@ from seeq_amd import device as dev                       # noqa: E402
 PATTERN, TAU, L = "GATGTAGCGCGATTAGCCTG", 3, 150
 nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 mode = sys.argv[2] if len(sys.argv) > 2 else "best"
+shape = sys.argv[3] if len(sys.argv) > 3 else "fastq"       # "fastq" (4-line records) or "fasta" (">id" + read, SEEQDEV_FASTA)
 d = torch.device("cuda:0")
 reads = torch.empty(nrec * (L + 1), dtype=torch.uint8, device=d)
 dev.synth_reads(reads.data_ptr(), 0, nrec, L, PATTERN, TAU)
@@ -40,7 +41,12 @@ buf[:, HDR + L + 1] = ord("+"); buf[:, HDR + L + 2] = 10
 g = torch.Generator(device=d); g.manual_seed(7)
 buf[:, HDR + L + 3:HDR + L + 3 + L] = torch.randint(33, 75, (nrec, L), device=d, generator=g, dtype=torch.uint8)
 buf[:, REC - 1] = 10
-text = buf.view(-1)
+if shape == "fasta":
+    buf[:, 0] = ord(">")
+    text = buf[:, :HDR + L + 1].contiguous().view(-1)
+    REC = HDR + L + 1
+else:
+    text = buf.view(-1)
 del reads
 torch.cuda.synchronize()
 
@@ -48,6 +54,8 @@ pat = dev.Pattern(PATTERN, TAU)
 sc = dev.Scanner()
 sc.set_profiling(True)
 opt, want = (0, dev.WANT_COUNTLINES) if mode == "count" else (dev.SQ_BEST, dev.WANT_RECORDS)
+FA = dev.SEEQDEV_FASTA if shape == "fasta" else 0
+opt |= FA
 for _ in range(2):
     cnt = sc.scan_tensor(pat, text, opt, want)
 torch.cuda.synchronize()
@@ -61,13 +69,13 @@ dt = (time.perf_counter() - t0) / steps
 from oracle.pyoracle import Oracle                        # noqa: E402
 k = 50_000
 host = text[:k * REC].cpu().numpy()
-exp = Oracle().buffer_scan(PATTERN, TAU, host, opt)
+exp = Oracle().buffer_scan(PATTERN, TAU, host, opt & ~FA, fasta=bool(FA))
 c2 = dev.Scanner().scan_tensor(pat, text[:k * REC], opt, want)
 ok = c2["nmatchlines"] == exp["nmatchlines"] and c2["nlines"] == exp["nlines"]
 if want == dev.WANT_RECORDS:
     s2 = dev.Scanner(); c3 = s2.scan_tensor(pat, text[:k * REC], opt, want)
     ok = ok and np.array_equal(s2.records(c3["nrecords"]).astype(np.uint64), exp["records"])
-print(json.dumps({"shape": "Q (4-line FASTQ records)", "mode": mode, "records": nrec, "lines": int(cnt["nlines"]),
+print(json.dumps({"shape": "Q (4-line FASTQ records)" if shape == "fastq" else "2-line FASTA records", "mode": mode, "records": nrec, "lines": int(cnt["nlines"]),
                   "bytes": int(text.numel()), "ms_per_step": dt * 1e3, "lines_per_s": cnt["nlines"] / dt,
                   "gb_per_s": text.numel() / dt / 1e9, "matching_lines": int(cnt["nmatchlines"]),
                   "kernel": sc.last_kernel(), "times_ms": sc.last_times_ms(),

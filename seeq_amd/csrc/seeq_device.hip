@@ -942,7 +942,7 @@ static int run_segments(seeqdev_scan *s)
    {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
       const bool dfa_opts = (options & (MASK_NONDNA | MASK_INPUT)) == 0;
-      if (fusable && s->force_path != 1 && dfa_opts && !fasta && !s->no_stream && pat->wlen + pat->tau - 1 <= 32 &&
+      if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && pat->wlen + pat->tau - 1 <= 32 &&
           (!ke || !strcmp(ke, "stream"))) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (mp->sdfa_state == 0 && mp->keys) {
@@ -962,6 +962,7 @@ static int run_segments(seeqdev_scan *s)
          const char *ce = getenv("SEEQ_STREAM_CH");
          stream_ch = ce && atoi(ce) == 64 ? 64 : 128;
          use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
+         { const char *ie = getenv("SEEQ_STREAM_ILP"); if (fasta && (stream_ch != 128 || (ie && atoi(ie) == 1))) use_stream = false; }   /* FASTA: default variant only */
       }
    }
    bool use_fused = fusable && (s->avg_line <= 600.0 || use_stream) && s->force_path != 1;
@@ -1009,9 +1010,10 @@ static int run_segments(seeqdev_scan *s)
          nw = STREAM_NW;
          tile_bytes = 64u * (uint32_t)stream_ch;
          { const char *ie = getenv("SEEQ_STREAM_ILP"); stream_ilp2 = stream_ch == 128 && !(ie && atoi(ie) == 1); }
-         stream_fn = stream_ch == 128 ? (stream_ilp2 ? (stream_wu == 6 ? (const void *)k_stream<128, 6, true> : (const void *)k_stream<128, 8, true>)
-                                                     : (stream_wu == 6 ? (const void *)k_stream<128, 6, false> : (const void *)k_stream<128, 8, false>))
-                                      : (stream_wu == 6 ? (const void *)k_stream<64, 6, false> : (const void *)k_stream<64, 8, false>);
+         stream_fn = fasta ? (stream_wu == 6 ? (const void *)k_stream<128, 6, true, true> : (const void *)k_stream<128, 8, true, true>)
+                   : stream_ch == 128 ? (stream_ilp2 ? (stream_wu == 6 ? (const void *)k_stream<128, 6, true, false> : (const void *)k_stream<128, 8, true, false>)
+                                                     : (stream_wu == 6 ? (const void *)k_stream<128, 6, false, false> : (const void *)k_stream<128, 8, false, false>))
+                                      : (stream_wu == 6 ? (const void *)k_stream<64, 6, false, false> : (const void *)k_stream<64, 8, false, false>);
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          HIP_TRY(hipFuncSetAttribute(stream_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dfa_lds), EIO);
          int per_cu = 0;
@@ -1173,12 +1175,12 @@ static int run_segments(seeqdev_scan *s)
          const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */
          f.slice_cap = f.cap_tmp / nslices;
          if (use_stream) {
-            if (stream_ch == 128 && stream_ilp2 && stream_wu == 6) hipLaunchKernelGGL((k_stream<128, 6, true>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else if (stream_ch == 128 && stream_ilp2) hipLaunchKernelGGL((k_stream<128, 8, true>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else if (stream_ch == 128 && stream_wu == 6) hipLaunchKernelGGL((k_stream<128, 6, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else if (stream_ch == 128) hipLaunchKernelGGL((k_stream<128, 8, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else if (stream_wu == 6) hipLaunchKernelGGL((k_stream<64, 6, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
-            else hipLaunchKernelGGL((k_stream<64, 8, false>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f);
+#define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f)
+            if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true); }
+            else if (stream_ch == 128 && stream_ilp2) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, false); }
+            else if (stream_ch == 128) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, false, false); else SEEQ_STREAM_LAUNCH(128, 8, false, false); }
+            else { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(64, 6, false, false); else SEEQ_STREAM_LAUNCH(64, 8, false, false); }
+#undef SEEQ_STREAM_LAUNCH
          }
          else if (use_dfa) hipLaunchKernelGGL(k_dfa, dim3(fgrid), dim3(64 * DFA_NW), dfa_lds, s->stream, f);
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);

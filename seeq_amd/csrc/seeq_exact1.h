@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
          continue;
       }
       const uint64_t off = done ? a.seg_base : a.seg_base + hs;
+      if (a.use_nh == 3 && (a.options & SEEQDEV_FASTA) && !done && a.text[off] == '>') done = true;   /* k_stream candidate inside a FASTA header */
       fused_state_t<W> st;
       st.init(m);
       uint32_t streak = tau1, nhits = 0, best_d = tau1, best_end = 0, pos = 0;

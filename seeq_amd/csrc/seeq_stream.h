@@ -30,7 +30,7 @@
  * line (or the hit position when the line starts before the tile), line rank inside the tile} into its private
  * slice, and tile_cl[] = line starts owned, tile_hits[] (same layout as k_direct).  k_stream_reorder orders the
  * entries, k_stream_bounds finishes the unresolved ones and drops repeats of a line.
- * Only for SQ_FAIL + SQ_LINES, no FASTA, m + tau - 1 <= 32, automaton <= 4 000 states.
+ * Only for SQ_FAIL + SQ_LINES, m + tau - 1 <= 32, automaton <= 4 000 states.
  * What bounds it: the LDS gather unit (32 banks: 5.6 cycles per 64-lane gather), HBM hidden.
  */
 #ifndef SEEQ_STREAM_H_
@@ -123,7 +123,10 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
    return x;
 }
 
-template <int CH, int WU, bool ILP2>
+/* FA: FASTA input (SEEQDEV_FASTA): a line that starts with '>' is a header -- not counted, never a hit line
+ * (reference seeq.c:367-374).  Headers are found per NEWLINE (is the byte after it a '>'?), so the walk itself is
+ * unchanged; candidates inside a header are discarded by the exact pass, which looks at the first byte of the line. */
+template <int CH, int WU, bool ILP2, bool FA>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    const uint32_t ten = 0x0Au;
 
    const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
-   uint32_t wv_lines = 0, wv_hitlines = 0, slice_pos = 0;                 /* wave-uniform */
+   uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0;    /* wave-uniform */
    bool wv_overflow = false;
    uint32_t wv_dirty = 0;
    uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
@@ -266,6 +269,27 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       const uint32_t tot_h = (uint32_t)__builtin_amdgcn_readlane((int)incl_h, 63);
       const uint32_t tot_n = (uint32_t)__builtin_amdgcn_readlane((int)incl_n, 63);
       const uint32_t extra = (uint32_t)__builtin_amdgcn_readfirstlane((a.first_seg && tile == 0) ? 1 : 0);   /* the line starting at byte 0 */
+      /* FASTA: which of my newlines start a header line?  (few newlines per lane: one byte load each) */
+      uint32_t dmask[NM], lane_hd = 0, excl_d = 0, tot_d = 0, hd_extra = 0;
+#pragma unroll
+      for (int r = 0; r < NM; r++) dmask[r] = 0;
+      if (FA) {
+#pragma unroll
+         for (int r = 0; r < NM; r++) {
+            uint32_t mm = nmask[r];
+            while (mm) {
+               const uint32_t lz = (uint32_t)__builtin_clz(mm);
+               mm &= ~(0x80000000u >> lz);
+               const uint64_t nxt = my + 32u * r + lz + 1;             /* < nbytes: a newline in the last byte was dropped */
+               if (a.text[nxt] == '>') dmask[r] |= 0x80000000u >> lz;
+            }
+            lane_hd += (uint32_t)__popc(dmask[r]);
+         }
+         const uint32_t incl_d = wave_incl_scan_u32(lane_hd);
+         excl_d = incl_d - lane_hd;
+         tot_d = (uint32_t)__builtin_amdgcn_readlane((int)incl_d, 63);
+         hd_extra = extra && a.text[0] == '>' ? 1u : 0u;                /* (first_seg: the buffer starts at byte 0) */
+      }
       /* ---- ordered compaction of the hit lines: per-wave slice, no atomics ---- */
       if (tot_h) {
          if (slice_pos + tot_h <= a.slice_cap) {
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
             if (extra && before == 0) before = 1;                          /* ... the buffer starts here */
             if (lane_hits) {
                uint32_t ord = incl_h - lane_hits;
-               uint32_t nlb = incl_n - lane_nl + extra - 1u;                /* rank of the line my chunk starts in */
+               uint32_t nlb = incl_n - lane_nl + extra - 1u - excl_d - hd_extra;   /* counted rank of the line my chunk starts in */
 #pragma unroll
                for (int r = 0; r < NM; r++) {
                   uint32_t mm = hmask[r];
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
                      const uint32_t lz = (uint32_t)__builtin_clz(mm);
                      mm &= ~(0x80000000u >> lz);
                      const uint32_t nlt = lz ? nmask[r] >> (32 - lz) : 0u;  /* newlines before the hit, same group */
-                     const uint32_t nb = (uint32_t)__popc(nlt);
+                     const uint32_t nb = (uint32_t)__popc(nlt) - (FA && lz ? (uint32_t)__popc(dmask[r] >> (32 - lz)) : 0u);
                      const uint32_t st1 = nlt ? (uint32_t)lane * CH + 32u * r + lz - (uint32_t)__builtin_ctz(nlt) + 1u : before;
                      const uint32_t hp = (uint32_t)lane * CH + 32u * r + lz;           /* the hit, tile-relative */
                      const uint32_t pos = st1 ? st1 - 1u : hp;
@@ -299,7 +323,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
                      ord++;
                   }
                   if (nmask[r]) before = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
-                  nlb += (uint32_t)__popc(nmask[r]);
+                  nlb += (uint32_t)__popc(nmask[r]) - (uint32_t)__popc(dmask[r]);
                }
             }
             slice_pos += tot_h;
@@ -308,17 +332,18 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          }
       }
       if (lane == 0) {
-         a.tile_cl[tile] = tot_n + extra;
+         a.tile_cl[tile] = tot_n + extra - tot_d - hd_extra;    /* counted lines: headers excluded */
          a.tile_hits[tile] = tot_h;
       }
       wv_lines += tot_n + extra;
+      wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;
    }
    if (wv_dirty && lane == 0) atomicOr(&a.cnt->dirty, 1u);
    if (lane == 0) {
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[3 * gwave + 0] = wv_lines;
-      a.wg_part[3 * gwave + 1] = 0;
+      a.wg_part[3 * gwave + 1] = wv_hdrs;
       a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
    }
 }

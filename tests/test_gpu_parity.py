@@ -545,8 +545,37 @@ for dirty in (False, True):
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"]
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
         sc.close(); p.close()
+# FASTA input: '>' header lines are not counted and never hit lines; headers next to tile / chunk boundaries, at the
+# start of the buffer, in a row, as the last line, and headers that contain the pattern
+hdrs = [">chr1 test", ">" + pat, ">", ">x " + dna(150) + pat + dna(30), ">seq|" + "N" * 40, "> " + pat.lower()]
+fparts = [">first header " + pat]
+for x in parts:
+    if rng.random() < 0.45:
+        fparts.append(rng.choice(hdrs))
+        if rng.random() < 0.2:
+            fparts.append(rng.choice(hdrs))
+    fparts.append(x)
+fparts.append(">last " + pat)
+for tail in ("\n", ""):
+    buf = ("\n".join(fparts) + tail).encode()
+    p = dev.Pattern(pat, 3)
+    sc = dev.Scanner()
+    for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
+        exp = o.buffer_scan(pat, 3, buf, opt, fasta=True)
+        got = sc.scan_host(p, buf, opt | dev.SEEQDEV_FASTA, dev.WANT_RECORDS)
+        if %d == 128:
+            assert sc.last_kernel() == "k_stream", sc.last_kernel()
+        assert got["nlines"] == exp["nlines"], ("fasta", opt, got["nlines"], exp["nlines"])
+        assert got["nmatchlines"] == exp["nmatchlines"], ("fasta", opt, got["nmatchlines"], exp["nmatchlines"])
+        assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), ("fasta", opt)
+    expa = o.buffer_scan(pat, 3, buf, SQ_ALL, fasta=True)
+    c1 = sc.scan_host(p, buf, dev.SEEQDEV_FASTA, dev.WANT_COUNTLINES)
+    c2 = sc.scan_host(p, buf, dev.SEEQDEV_FASTA, dev.WANT_COUNTMATCH)
+    assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"]
+    assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
+    sc.close(); p.close()
 print("OK")
-''' % (ROOT, os.path.join(ROOT, "tests"), ch)
+''' % (ROOT, os.path.join(ROOT, "tests"), ch, ch)
     for seg in ("65536", "0"):
         env = dict(os.environ, SEEQ_STREAM_CH=str(ch))
         if seg != "0":
