@@ -94,7 +94,7 @@ int seeqdevScanReserve(seeqdev_scan_t * scan, size_t max_bytes, size_t max_lines
 int seeqdevScanSetLineHint(seeqdev_scan_t * scan, double avg_bytes_per_line);
 /* Which device path served the last run: 1 = generic (newline index + k_forward<W>),
  * 2 = fused, text tiles in LDS (k_fused), 3 = fused, text in registers (k_direct), 4 = fused,
- * table-driven per line (k_dfa: the pattern's complete Levenshtein automaton in LDS; default options only),
+ * table-driven per line (k_dfa: the pattern's complete Levenshtein automaton in LDS; SQ_FAIL only),
  * 5 = fused, table-driven and line-agnostic (k_stream: every lane walks a fixed chunk of the text).
  * The fused kernels serve patterns <= 62 positions on read-length lines in ONE pass over the text. */
 int seeqdevScanLastPath(const seeqdev_scan_t * scan);

@@ -82,7 +82,7 @@ struct Counters {
    uint64_t records;
    uint64_t headers;
    /* workspace overflow report */
-   uint32_t overflow;       /* bit0 lines, bit1 hitlines, bit2 records */
+   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
    uint32_t seg_tmp_hits;   /* k_fused: hit lines of this segment (summed per workgroup) */
@@ -713,6 +713,7 @@ struct seeqdev_scan {
    size_t seg_bytes;           /* segment size */
    bool user_reserved;         /* caller sized the per-line workspace: trust it */
    bool no_stream;             /* k_stream met a line it cannot address (starts > 1 GiB before its segment): use the per-line kernels */
+   bool no_stream_nd;          /* SQ_CONVERT / SQ_IGNORE: the text has non-DNA bytes, k_stream (exact for clean text only) is off */
 };
 
 static int ws_alloc(void **p, size_t bytes)
@@ -941,7 +942,10 @@ static int run_segments(seeqdev_scan *s)
    int stream_ch = 128;
    {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
-      const bool dfa_opts = (options & (MASK_NONDNA | MASK_INPUT)) == 0;
+      /* SQ_CONVERT / SQ_IGNORE differ from SQ_FAIL only on non-DNA bytes: k_stream runs, and when it meets one
+         (Counters.dirty) it raises overflow flag 16 -> the scan is re-run on the per-line kernels, for good */
+      const int nd = options & MASK_NONDNA;
+      const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || (!s->no_stream_nd && !fasta));
       if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && pat->wlen + pat->tau - 1 <= 32 &&
           (!ke || !strcmp(ke, "stream"))) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
@@ -1337,6 +1341,7 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
       if (h.overflow & 1u) nl = (size_t)h.need_lines + (h.need_lines >> 3) + 64;
       if (h.overflow & 2u) nhl = (size_t)h.need_hitlines + (h.need_hitlines >> 3) + 64;
       if (h.overflow & 8u) s->no_stream = true;
+      if (h.overflow & 16u) s->no_stream_nd = true;
       if (h.overflow & 4u) {
          /* need_records keeps counting after the overflow, so it is the total of this run. */
          nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;

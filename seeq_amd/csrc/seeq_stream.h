@@ -339,7 +339,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;
    }
-   if (wv_dirty && lane == 0) atomicOr(&a.cnt->dirty, 1u);
+   if (wv_dirty && lane == 0) {
+      atomicOr(&a.cnt->dirty, 1u);
+      if (a.options & MASK_NONDNA) atomicOr(&a.cnt->overflow, 16u);   /* SQ_CONVERT / SQ_IGNORE: only exact on clean text -> re-run */
+   }
    if (lane == 0) {
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[3 * gwave + 0] = wv_lines;

@@ -545,6 +545,17 @@ for dirty in (False, True):
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"]
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
         sc.close(); p.close()
+        # SQ_CONVERT / SQ_IGNORE: k_stream on clean text; a non-DNA byte makes the library re-run on a per-line kernel
+        for nd in (dev.SQ_CONVERT, dev.SQ_IGNORE):
+            p = dev.Pattern(pat, 3)
+            sc = dev.Scanner()
+            for opt in (SQ_BEST, SQ_ALL):
+                exp = o.buffer_scan(pat, 3, buf, opt | nd)
+                got = sc.scan_host(p, buf, opt | nd, dev.WANT_RECORDS)
+                assert (sc.last_kernel() == "k_stream") == (not dirty), (dirty, nd, sc.last_kernel())
+                assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (dirty, nd, opt)
+                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, nd, opt)
+            sc.close(); p.close()
 # FASTA input: '>' header lines are not counted and never hit lines; headers next to tile / chunk boundaries, at the
 # start of the buffer, in a row, as the last line, and headers that contain the pattern
 hdrs = [">chr1 test", ">" + pat, ">", ">x " + dna(150) + pat + dna(30), ">seq|" + "N" * 40, "> " + pat.lower()]
