@@ -38,7 +38,8 @@ def harness():
     so = os.path.join(ROOT, "tests", "libharness.so")
     src = os.path.join(ROOT, "tests", "host_harness.cpp")
     core = os.path.join(ROOT, "seeq_amd", "csrc", "seeq_kernel_core.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+    dfa = os.path.join(ROOT, "seeq_amd", "csrc", "seeq_dfa.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core), os.path.getmtime(dfa)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", src, "-o", so])
     H = C.CDLL(so)
     H.harness_scan.restype = C.c_long

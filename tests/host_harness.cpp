@@ -62,3 +62,31 @@ extern "C" long harness_scan(const uint8_t *text, size_t n, const char *keys, in
 }
 
 extern "C" int harness_compile(const char *expr, char *keys, int *err) { return seeq_compile_pattern(expr, keys, err); }
+
+// ---- the streaming automaton of k_stream (seeq_amd/csrc/seeq_dfa.h: host-side table builder) ----
+// Emulates the kernel's decomposition on the host: every `chunk`-byte chunk of the text is walked on its own from the
+// root state after a warm-up over the `warm` bytes before it ('\n' where the buffer starts), with the kernel's
+// addressing "state ^ (byte & 0xE)"; positions where the walk enters ACC_NEW inside the owned chunk are reported.
+// Returns the number of events (positions in out[], ascending), -1 when the automaton does not fit; *nstates = its size.
+#include "../seeq_amd/csrc/seeq_dfa.h"
+extern "C" long harness_dfa_stream(const uint8_t *text, size_t n, const char *keys, int m, int tau, int chunk, int warm,
+                                   uint64_t *out, size_t cap, uint32_t *nstates)
+{
+   seeq_dfa_t *d = seeq_dfa_build_stream(keys, m, tau);
+   if (!d) return -1;
+   if (nstates) *nstates = d->nstates;
+   size_t ne = 0;
+   for (size_t c0 = 0; c0 < n; c0 += (size_t)chunk) {
+      uint32_t state = 0;
+      for (long long p = (long long)c0 - warm; p < (long long)c0 + chunk && p < (long long)n; p++) {
+         const uint8_t b = p < 0 ? (uint8_t)'\n' : text[p];
+         state = d->table[(state ^ (uint32_t)(b & 0xE)) >> 1];
+         if (p >= (long long)c0 && state == d->acc_final) {
+            if (ne < cap) out[ne] = (uint64_t)p;
+            ne++;
+         }
+      }
+   }
+   seeq_dfa_free(d);
+   return (long)ne;
+}

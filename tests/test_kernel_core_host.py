@@ -69,3 +69,56 @@ def test_fuzz_vs_oracle(harness, oracle):
         allh = oracle.string_match(pat, tau, text, (opt & ~3) | SQ_ALL)
         assert run(harness, oracle, pat, tau, text, opt, ANY) == (1 if allh else 0)
         assert run(harness, oracle, pat, tau, text, opt, COUNT) == len(allh)
+
+
+def test_stream_automaton_vs_oracle(harness, oracle):
+    """Host side of k_stream: the complete Levenshtein automaton (seeq_dfa.h) walked chunk by chunk with a warm-up,
+    exactly as the kernel decomposes the text, reports a first-hit event in a line iff the oracle finds a hit in it
+    (clean text: A C G T N, both cases, newlines) -- for chunk sizes 128 / 64 / 16 and the smallest legal warm-up."""
+    import ctypes as C
+    harness.harness_dfa_stream.restype = C.c_long
+    harness.harness_dfa_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    rng = random.Random(11)
+    cases = [("GATGTAGCGCGATTAGCCTG", 3), ("GATTAGC", 1), ("CACAGAT", 3), ("ACGT", 1), ("A", 0), ("ACNNGT[AC]TTG", 2),
+             ("GATGTAGCGCGATTAGCCTGAAAATG", 2), ("TTTTTTTT", 2), ("GATGTAGCGCGATTAG", 4)]
+    for pat, tau in cases:
+        keys, _ = oracle.parse(pat)
+        m = len(keys)
+        core = "".join("ACGT"[(k & -k).bit_length() - 1] if k != 0x1F else "N" for k in keys)
+        lines = []
+        for _ in range(400):
+            n = rng.choice([0, 3, 20, 60, 150, 151, 400])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            if n >= m and rng.random() < 0.5:
+                c = list(core.replace("N", "A"))
+                for _e in range(rng.randint(0, tau + 2)):
+                    i = rng.randrange(len(c))
+                    k = rng.randrange(3)
+                    if k == 0:
+                        c[i] = rng.choice("ACGT")
+                    elif k == 1 and len(c) > 1:
+                        del c[i]
+                    else:
+                        c.insert(i, rng.choice("ACGT"))
+                p = rng.randrange(0, max(1, n - len(c) + 1))
+                t[p:p + len(c)] = c
+            if n and rng.random() < 0.1:
+                t[rng.randrange(len(t))] = "N"
+            s = "".join(t)[:n]
+            lines.append(s.lower() if rng.random() < 0.05 else s)
+        buf = ("\n".join(lines) + "\n").encode()
+        exp = oracle.buffer_scan(pat, tau, buf, SQ_FIRST)
+        want = sorted(set(int(x) for x in exp["records"][:, 0]))
+        starts = np.cumsum([0] + [len(x) + 1 for x in lines])            # byte offset of every line
+        for chunk in (128, 64, 16):
+            warm = m + tau - 1
+            out = np.zeros(1 << 16, dtype=np.uint64)
+            ns = C.c_uint32(0)
+            ne = harness.harness_dfa_stream(buf, len(buf), bytes(keys), m, tau, chunk, warm, out.ctypes.data, out.size,
+                                            C.byref(ns))
+            assert ne >= 0, (pat, tau)
+            got = sorted(set(int(np.searchsorted(starts, int(p), side="right")) for p in out[:ne]))   # 1-based line numbers
+            assert got == want, (pat, tau, chunk)
+        if (pat, tau) == ("GATGTAGCGCGATTAGCCTG", 3):
+            assert ns.value == 3342
