@@ -502,11 +502,12 @@ __global__ __launch_bounds__(WG) void k_count_nonzero(ScanArgs a)
       if (n) atomicAdd(&a.cnt->seg_nmatch, n);
    }
 }
-__global__ void k_seg_end(ScanArgs a, int hits_from_nh)
+__global__ void k_seg_end(ScanArgs a, int flags /* 1: hits come from nh[]; 2: nh[] holds 0/1 verdicts, their sum = matching lines */)
 {
    Counters *c = a.cnt;
    const uint32_t counted = c->seg_nlines - c->seg_nheaders;
-   const uint32_t seg_hits = hits_from_nh ? c->seg_nrec : c->seg_nhitlines;
+   const uint32_t seg_hits = (flags & 1) ? c->seg_nrec : c->seg_nhitlines;
+   if (flags & 2) c->seg_nmatch = c->seg_nrec;
    c->lines += counted;
    c->headers += c->seg_nheaders;
    c->matchlines += a.use_nh >= 2 ? c->seg_nmatch : c->seg_nhitlines;   /* >= 2: the filter was a superset */
@@ -913,6 +914,7 @@ static int run_segments(seeqdev_scan *s)
    const bool single = (options & SEEQDEV_SINGLELINE) != 0;
    const int match_opt = options & 3;
    bool need_nh = want == SEEQDEV_WANT_COUNTMATCH || (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   const bool nh_is_count = need_nh;                      /* nh[] = hits per line; else (superset filters) a 0/1 verdict per line */
    const size_t nbytes = s->nbytes;
    Counters *c = s->d_cnt;
 
@@ -1235,7 +1237,8 @@ static int run_segments(seeqdev_scan *s)
             if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
             else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
-            if (superset) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
+            /* lines with >= 1 verified hit: with 0/1 verdicts that is the scan total (seg_nrec) -- no extra pass */
+            if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
             launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */
@@ -1255,7 +1258,7 @@ static int run_segments(seeqdev_scan *s)
             }
          }
       }
-      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, need_nh ? 1 : 0);
+      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));
       if (ev) HIP_TRY(hipEventRecord(ev[3], s->stream), EIO);
       HIP_TRY(hipGetLastError(), EIO);
    }
