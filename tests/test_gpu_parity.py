@@ -645,3 +645,29 @@ def test_stream_fuzz_patterns(gpu, capi, oracle):
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], (pattern, tau)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau)
     assert kernels.get("k_stream", 0) >= 60, kernels          # the automaton path really is what ran, mostly
+
+
+def test_device_pointer_alignment(gpu, capi, oracle):
+    """seeqdevScanRun on device pointers of any alignment (a tensor sliced at odd byte offsets): k_stream's 128-byte
+    chunks then straddle memory lines; results must not change."""
+    import torch
+    from seeq_amd import device as dev
+    n, length = 30_000, 150
+    t = torch.empty(n * (length + 1) + 256, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    pat = dev.Pattern(PAT20, 3)
+    sc = dev.Scanner(stream)
+    for off in (1, 3, 17, 131):
+        body = t[off:off + n * (length + 1)]
+        dev.synth_reads(body.data_ptr(), 0, n, length, PAT20, 3, stream=stream)
+        for cut in (0, 5):                          # also start in the middle of a line
+            view = body[cut:]
+            host = view.cpu().numpy()
+            for mo in (SQ_BEST, SQ_ALL):
+                exp = oracle.buffer_scan(PAT20, 3, host, mo)
+                got = sc.scan_tensor(pat, view, mo, dev.WANT_RECORDS)
+                assert sc.last_kernel() == "k_stream"
+                assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (off, cut, mo)
+                assert np.array_equal(sc.records(got["nrecords"]).astype(np.uint64), exp["records"]), (off, cut, mo)
+    sc.close()
+    pat.close()
