@@ -139,7 +139,7 @@ def main():
                  "all": (dev.SQ_ALL, dev.WANT_RECORDS)}[args.workload]
     pat = dev.Pattern(PATTERN, TAU)
     sc = dev.Scanner(stream)
-    seg = int(os.environ.get("SEEQ_SEGMENT_BYTES", str(1 << 31)))
+    seg = int(os.environ.get("SEEQ_SEGMENT_BYTES", str(0xF0000000)))      # the library's default segment size
     seg_lines = min(n, seg // (READ_LEN + 1) + 2)
     sc.reserve(nbytes, seg_lines + 64, seg_lines // 8 + 1024, n // 8 + 1024)
     sc.set_profiling(True)
