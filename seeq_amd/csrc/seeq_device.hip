@@ -1025,7 +1025,7 @@ static int run_segments(seeqdev_scan *s)
          int per_cu = 0;
          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_fn, 64 * STREAM_NW, dfa_lds) != hipSuccess || per_cu < 1)
             per_cu = 1;
-         { const char *we = getenv("SEEQ_DFA_WGS"); if (we && atoi(we) >= 1 && atoi(we) < per_cu) per_cu = atoi(we); }
+         { const char *we = getenv("SEEQ_DFA_WGS"); if (we && atoi(we) >= 1 && atoi(we) < per_cu) per_cu = atoi(we); }   /* experiments: workgroups per CU */
          fused_grid = (unsigned)(ncu * per_cu);
          if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
          nslices = fused_grid * nw;                         /* one hit slice per wave */
@@ -1175,7 +1175,7 @@ static int run_segments(seeqdev_scan *s)
             uint64_t room = 0xFFFFFFF0ull - a.seg_len;
             if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;
             pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room);
-            f.halo = pos_bias;
+            f.pos_bias = pos_bias;
          }
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
          const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */

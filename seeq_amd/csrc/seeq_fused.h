@@ -47,7 +47,8 @@ struct FusedArgs {
    uint32_t       seg_len;
    uint32_t       first_seg;
    uint32_t       tile_bytes;  /* multiple of 16                               */
-   uint32_t       halo;        /* multiple of 16, <= FUSED_HALO_MAX            */
+   uint32_t       halo;        /* k_fused: multiple of 16, <= FUSED_HALO_MAX   */
+   uint32_t       pos_bias;    /* k_stream: hit offsets are relative to seg_base - pos_bias (a line can start before the segment) */
    uint32_t       ntiles;
    const uint32_t *eqtab;      /* [256] top-aligned Peq word or flag, per byte */
    const uint32_t *peq;        /* [2][5][1] bottom-aligned (long-line fallback)*/

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
                      const uint32_t pos = st1 ? st1 - 1u : hp;
                      /* {tile | unresolved, rank | column of the hit << 13, line start (or hit) position, line rank} */
                      slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord | ((hp - pos) << 13),
-                                                         tile * TB + pos + a.halo /* position bias */, nlb + nb);
+                                                         tile * TB + pos + a.pos_bias, nlb + nb);
                      ord++;
                   }
                   if (nmask[r]) before = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
