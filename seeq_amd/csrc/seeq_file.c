@@ -378,21 +378,34 @@ long seeqFileMatch(seeqfile_t *sqfile, seeq_t *sq, int match_opt, int file_opt)
 /* ------------------------------------------------------------------------ */
 /* seeq(): open, match, print.  Output formats of reference seeq.c:104-176.   */
 /* ------------------------------------------------------------------------ */
-static void put_range(const char *s, size_t from, size_t to) { fwrite(s + from, 1, to - from, stdout); }
+/* The formatter writes with the *_unlocked calls (the reference is single-threaded) and formats its integers
+   itself: hit-rich or inverted outputs print tens of millions of short lines.  (The CLI gives stdout a 1 MiB buffer.) */
+static void put_range(const char *s, size_t from, size_t to) { fwrite_unlocked(s + from, 1, to - from, stdout); }
+static void put_str(const char *s) { fwrite_unlocked(s, 1, strlen(s), stdout); }
+static void put_long(long v, char trail)            /* "%ld" followed by `trail` (0 = nothing) */
+{
+   char b[24];
+   int i = 23;
+   unsigned long u = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v;
+   if (trail) b[i--] = trail;
+   do { b[i--] = (char)('0' + u % 10); u /= 10; } while (u);
+   if (v < 0) b[i--] = '-';
+   fwrite_unlocked(b + i + 1, 1, (size_t)(23 - i), stdout);
+}
 
 static void print_hit(const struct seeqarg_t *a, const seeqfile_t *f, const seeq_t *sq, const match_t *m,
                       int fasta_header, int color)
 {
    const char *str = sq->string;
    if (a->compact) {                                              /* seeq.c:134 */
-      fprintf(stdout, "%ld:%ld-%ld:%ld", (long)f->line, (long)m->start, (long)m->end - 1, (long)m->dist);
-      fputc('\n', stdout);
+      put_long((long)f->line, ':'); put_long((long)m->start, '-'); put_long((long)m->end - 1, ':');
+      put_long((long)m->dist, '\n');
       return;
    }
-   if (a->showline) fprintf(stdout, "%ld ", (long)f->line);
-   if (a->showpos)  fprintf(stdout, "%ld-%ld ", (long)m->start, (long)m->end - 1);
-   if (a->showdist) fprintf(stdout, "%ld ", (long)m->dist);
-   if (fasta_header) fprintf(stdout, "%s\n", f->info);
+   if (a->showline) put_long((long)f->line, ' ');
+   if (a->showpos)  { put_long((long)m->start, '-'); put_long((long)m->end - 1, ' '); }
+   if (a->showdist) put_long((long)m->dist, ' ');
+   if (fasta_header) { put_str(f->info); putc_unlocked('\n', stdout); }
    const size_t len = strlen(str);
    if (a->matchonly) {
       put_range(str, m->start, m->end < len ? m->end : len);
@@ -401,21 +414,21 @@ static void print_hit(const struct seeqarg_t *a, const seeqfile_t *f, const seeq
    } else if (a->endline) {
       if (m->end < len) put_range(str, m->end, len);
    } else if (a->split) {
-      put_range(str, 0, m->start); fputc('\t', stdout);
-      put_range(str, m->start, m->end); fputc('\t', stdout);
+      put_range(str, 0, m->start); putc_unlocked('\t', stdout);
+      put_range(str, m->start, m->end); putc_unlocked('\t', stdout);
       if (m->end < len) put_range(str, m->end, len);
    } else if (a->printline) {
       if (color) {
          put_range(str, 0, m->start);
-         fputs(m->dist ? BOLDRED : BOLDGREEN, stdout);
+         put_str(m->dist ? BOLDRED : BOLDGREEN);
          put_range(str, m->start, m->end);
-         fputs(RESET, stdout);
-         fputs(str + m->end, stdout);
+         put_str(RESET);
+         if (m->end < len) put_range(str, m->end, len);
       } else {
-         fputs(str, stdout);
+         put_range(str, 0, len);
       }
    }
-   fputc('\n', stdout);
+   putc_unlocked('\n', stdout);
 }
 
 int seeq(char *expression, char *input, struct seeqarg_t args)
@@ -454,9 +467,9 @@ int seeq(char *expression, char *input, struct seeqarg_t args)
       long rv;
       if (args.invert) {
          while ((rv = seeqFileMatch(f, sq, opt, SQ_NOMATCH)) > 0) {    /* seeq.c:125-129 */
-            if (args.showline) fprintf(stdout, "%ld ", (long)f->line);
-            if (fasta_header) fprintf(stdout, "%s\n", f->info);
-            fprintf(stdout, "%s\n", sq->string);
+            if (args.showline) put_long((long)f->line, ' ');
+            if (fasta_header) { put_str(f->info); putc_unlocked('\n', stdout); }
+            put_str(sq->string); putc_unlocked('\n', stdout);
          }
       } else {
          while ((rv = seeqFileMatch(f, sq, opt, SQ_MATCH)) > 0) {      /* seeq.c:131-176 */

@@ -153,5 +153,7 @@ int main(int argc, char **argv)
    args.non_dna   = v[F_X];
    args.all       = v[F_A];
    args.memory    = (size_t)v[F_Y] * 1024 * 1024;
+   static char obuf[1 << 20];
+   setvbuf(stdout, obuf, _IOFBF, sizeof obuf);             /* nothing has been written to stdout yet */
    return seeq(expr, input, args);
 }
