@@ -90,7 +90,7 @@ struct Counters {
    uint32_t dirty;          /* k_stream: the text holds bytes outside {ACGTN, acgtn, '\n'}: its hit lines need verifying */
    uint64_t need_records;   /* total */
    uint32_t prev_hit_line;  /* k_stream: line number of the last hit line of the previous segment (a line can span segments) */
-   uint32_t pad3;
+   uint32_t seg_last_nl;    /* k_stream: segment-relative offset + 1 of the last newline of the segment (0: none) */
 };
 
 struct ScanArgs {
@@ -116,6 +116,8 @@ struct ScanArgs {
    uint32_t       use_nh;       /* record slots / line verdicts come from the per-line counts nh[]: 1 = ALL, COUNTMATCH;
                                    2 = superset filter (k_dfa); 3 = k_stream (superset only when Counters.dirty,
                                    hit list may repeat a line: hit_start = 0xFFFFFFFF marks a repeat) */
+   uint32_t       pos_bias;     /* k_stream: seg_base here is the segment's base minus this (multiple of 128) */
+   uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    Counters      *cnt;
 };
 
@@ -686,6 +688,7 @@ struct seeqdev_scan {
    uint32_t *tile_cl, *tile_hits; size_t cap_ftiles;
    uint32_t *wg_hits;             /* [MAX_FUSED_GRID] */
    uint32_t *wg_part;             /* [3 * MAX_FUSED_GRID] */
+   uint32_t *wg_lastnl;           /* [MAX_FUSED_GRID] k_stream: last newline seen by each wave */
    uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
    const seeqdev_pattern *eq_pat; int eq_options;
    double avg_line;               /* average bytes per line incl. newline (hint or sampled) */
@@ -749,6 +752,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
    if (e == hipSuccess) e = hipMalloc((void **)&s->wg_hits, MAX_FUSED_GRID * sizeof(uint32_t));
    if (e == hipSuccess) e = hipMalloc((void **)&s->wg_part, 3 * MAX_FUSED_GRID * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipMalloc((void **)&s->wg_lastnl, MAX_FUSED_GRID * sizeof(uint32_t));
    {
       const char *pe = getenv("SEEQ_PATH");
       s->force_path = pe ? (!strcmp(pe, "generic") ? 1 : !strcmp(pe, "fused") ? 2 : 0) : 0;
@@ -765,7 +769,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
 {
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
-   void *bufs[] = {s->rec_off, s->wg_hits, s->wg_part, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+   void *bufs[] = {s->rec_off, s->wg_hits, s->wg_part, s->wg_lastnl, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
@@ -1161,7 +1165,7 @@ static int run_segments(seeqdev_scan *s)
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
-         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part;
+         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = use_stream ? s->wg_lastnl : nullptr;
          { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
          if (use_dfa) {
@@ -1174,7 +1178,7 @@ static int run_segments(seeqdev_scan *s)
             /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
             uint64_t room = 0xFFFFFFF0ull - a.seg_len;
             if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;
-            pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room);
+            pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room) & ~127u;     /* chunk boundaries stay multiples of the chunk */
             f.pos_bias = pos_bias;
          }
          if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
@@ -1203,6 +1207,8 @@ static int run_segments(seeqdev_scan *s)
             else hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
+         a.pos_bias = pos_bias;
+         a.stream_ch = use_stream ? (uint32_t)stream_ch : 0u;
       } else {
       /* ---- K0: newline index ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[0], s->stream), EIO);

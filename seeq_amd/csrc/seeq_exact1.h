@@ -109,7 +109,21 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       fused_state_t<W> st;
       st.init(m);
       uint32_t streak = tau1, nhits = 0, best_d = tau1, best_end = 0, pos = 0;
-      if (hit_col && trusted && !done) { const uint32_t col = hit_col[k]; pos = col > 32 ? col - 32 : 0; }
+      /* Window walk (k_stream, clean text, lines that end inside the segment): only the candidate chunks of the
+         line are scanned -- the first entry and the repeats of the line that follow it in the hit list, each from
+         32 columns before the candidate to the end of its chunk, on while the last 32 columns still hold a
+         sub-threshold score (such a tail is what hides a hit from the next lane's walk), then a jump to the next
+         candidate with a fresh column.  A chromosome-long line costs its hits, not its length. */
+      bool win = false;
+      uint32_t wend = 0, knext = k + 1;                    /* end of the current window (column), next hit-list entry */
+      int32_t lastsub = -0x40000000;                       /* column of the last score <= tau seen */
+      if (hit_col && trusted && !done) {
+         const uint32_t col = hit_col[k];
+         pos = col > 32 ? col - 32 : 0;
+         const uint32_t lastnl = c->seg_last_nl;           /* a newline at or after the line's start: the line ends in this segment */
+         win = a.stream_ch != 0 && lastnl != 0 && (int64_t)hs - (int64_t)a.pos_bias < (int64_t)lastnl;
+         wend = (((hs + col) | (a.stream_ch - 1u)) + 1u) - hs;
+      }
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
       uint32_t out_cap = 0, line_no = 0;
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                   const bool upd = !skip && streak < best_d && (streak < cur || streak == 0);
                   best_d = upd ? streak : best_d;
                   best_end = upd ? pos + t4 + cc : best_end;
+                  lastsub = cur < tau1 && !skip ? (int32_t)(pos + t4 + cc) : lastsub;
                   streak = skip ? streak : cur;
                   done = done || term;
                }
@@ -179,6 +194,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                const uint32_t cur = term ? tau1 : sc;
                const bool stop = streak < cur, zero = streak == 0;
                const uint32_t p = pos + t4 + cc;
+               lastsub = act && cur < tau1 ? (int32_t)p : lastsub;
                bool end = term;
                const bool emit = act && (stop ? !latch : zero);
                latch = act ? (stop ? true : zero) : latch;
@@ -210,6 +226,27 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
             }
          }
          pos += 64;
+         if (win && !done) {
+            /* A score <= tau in the last 32 columns of a chunk (or inside the chunk the walk stands in) may have put
+               that chunk's lane into the accepting state before it could report: the chunk has to be scanned whole. */
+            const int32_t b = (int32_t)(((hs + pos) & ~(a.stream_ch - 1u)) - hs);      /* start of the chunk holding `pos` */
+            if (lastsub >= b - 32 && b + (int32_t)a.stream_ch > (int32_t)wend) wend = (uint32_t)(b + (int32_t)a.stream_ch);
+            if (pos >= wend) {
+               /* the window is done and the columns behind are clean: nothing can hide before the next candidate */
+               for (;;) {
+                  if (!(knext < nhl && a.hit_start[knext] == 0xFFFFFFFFu)) { done = true; break; }   /* no candidate left */
+                  const uint32_t cpos = hit_col[knext++];                 /* position of the repeat's first hit */
+                  const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs;
+                  if (ccol > pos + 32) {                                  /* jump: fresh column 32 columns before it */
+                     pos = ccol - 32; wend = cend;
+                     st.init(m); streak = tau1; latch = false; lastsub = -0x40000000;
+                     break;
+                  }
+                  if (cend > wend) wend = cend;                           /* adjacent or behind: the walk just goes on */
+                  if (wend > pos) break;
+               }
+            }
+         }
       }
       if (k < nhl) {
          if (MODE == SQ_MODE_COUNT) {

@@ -60,6 +60,7 @@ struct FusedArgs {
    uint32_t       slice_cap;   /* entries per workgroup slice = cap_tmp / grid  */
    uint32_t      *wg_hits;     /* per slice (workgroup of k_fused / wave of k_direct): entries stored */
    uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31}               */
+   uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */
    uint32_t       debug;       /* profiling experiments only (SEEQ_FUSED_DEBUG): 1 = skip the per-line scan */
    const uint16_t *dfa;        /* k_dfa: transition table, dfa_rows x 8 u16 (seeq_dfa.h) */
    uint32_t       dfa_rows;
@@ -484,8 +485,9 @@ __global__ __launch_bounds__(64 * NW) void k_fused(FusedArgs a)
 __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslices)
 {
    __shared__ uint32_t s_red[4][4];
-   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0;
+   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0;
    for (uint32_t i = threadIdx.x; i < nslices; i += 256) {
+      if (a.wg_lastnl) { const uint32_t l = a.wg_lastnl[i]; lastnl = l > lastnl ? l : lastnl; }
       lines += a.wg_part[3 * i + 0];
       hdrs += a.wg_part[3 * i + 1];
       const uint32_t h = a.wg_part[3 * i + 2];
@@ -501,8 +503,12 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       const uint32_t o = __shfl_xor(mx, d, 64);
       mx = o > mx ? o : mx;
       ovf |= __shfl_xor(ovf, d, 64);
+      const uint32_t ol = __shfl_xor(lastnl, d, 64);
+      lastnl = ol > lastnl ? ol : lastnl;
    }
+   __shared__ uint32_t s_last[4];
    const int w = threadIdx.x >> 6;
+   if ((threadIdx.x & 63) == 0) s_last[w] = lastnl;
    if ((threadIdx.x & 63) == 0) { s_red[w][0] = lines; s_red[w][1] = hdrs; s_red[w][2] = hits; s_red[w][3] = mx | (ovf << 31); }
    __syncthreads();
    if (threadIdx.x == 0) {
@@ -522,6 +528,9 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       if (ovf) { atomicOr(&c->overflow, 2u); hits = 0; }
       c->seg_nhitlines = hits;
       c->seg_tmp_hits = 0;
+      lastnl = 0;
+      for (int k = 0; k < 4; k++) lastnl = s_last[k] > lastnl ? s_last[k] : lastnl;
+      c->seg_last_nl = lastnl;
    }
 }
 

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    const uint32_t ten = 0x0Au;
 
    const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
-   uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0;    /* wave-uniform */
+   uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0, wv_lastnl = 0;    /* wave-uniform */
    bool wv_overflow = false;
    uint32_t wv_dirty = 0;
    uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
@@ -290,17 +290,23 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          tot_d = (uint32_t)__builtin_amdgcn_readlane((int)incl_d, 63);
          hd_extra = extra && a.text[0] == '>' ? 1u : 0u;                /* (first_seg: the buffer starts at byte 0) */
       }
+      /* last newline per lane (tile-relative + 2 = start of the next line + 1; 0: none) and its prefix maximum */
+      uint32_t incl_last = 0;
+      if (tot_n) {                                        /* wave-uniform */
+         uint32_t my_last = 0;
+#pragma unroll
+         for (int r = 0; r < NM; r++)
+            if (nmask[r]) my_last = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
+         incl_last = wave_incl_max_u32(my_last);
+         /* the segment's last newline decides which line runs on into the next segment (k_exact1) */
+         wv_lastnl = tile * TB + (uint32_t)__builtin_amdgcn_readlane((int)incl_last, 63) - 1u;
+      }
       /* ---- ordered compaction of the hit lines: per-wave slice, no atomics ---- */
       if (tot_h) {
          if (slice_pos + tot_h <= a.slice_cap) {
             /* Where does the line of a hit start?  After the last newline before it: in my chunk, else in a
                lower lane's chunk (prefix maximum), else before the tile -- then the entry carries the hit
                position and k_stream_bounds searches backwards.  Offsets are tile-relative, +1 so 0 = none. */
-            uint32_t my_last = 0;
-#pragma unroll
-            for (int r = 0; r < NM; r++)
-               if (nmask[r]) my_last = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
-            const uint32_t incl_last = wave_incl_max_u32(my_last);
             uint32_t before = stream_from_prev_lane(incl_last, 0u);        /* start+1 of the line my chunk begins in */
             if (extra && before == 0) before = 1;                          /* ... the buffer starts here */
             if (lane_hits) {
@@ -347,6 +353,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[3 * gwave + 0] = wv_lines;
       a.wg_part[3 * gwave + 1] = wv_hdrs;
+      a.wg_lastnl[gwave] = wv_lastnl;                     /* offset + 1 of the last newline this wave saw */
       a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
    }
 }
@@ -381,7 +388,11 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit
    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
       const uint32_t ln = a.hit_line[k];
       const uint32_t prev = k ? a.hit_line[k - 1] : c->prev_hit_line;
-      if (ln == prev) { a.hit_start[k] = 0xFFFFFFFFu; continue; }
+      if (ln == prev) {                                   /* a repeat: keep the candidate's position for k_exact1's window walk */
+         hit_col[k] = a.nh[k] ? a.hit_start[k] : a.hit_start[k] + hit_col[k];
+         a.hit_start[k] = 0xFFFFFFFFu;
+         continue;
+      }
       if (!a.nh[k]) continue;                             /* k_stream already found the start of the line */
       uint64_t q = a.seg_base + a.hit_start[k];          /* a byte of the line; never '\n' */
       /* backwards to the byte after the previous '\n' (or the start of the buffer) */

@@ -671,3 +671,40 @@ def test_device_pointer_alignment(gpu, capi, oracle):
                 assert np.array_equal(sc.records(got["nrecords"]).astype(np.uint64), exp["records"]), (off, cut, mo)
     sc.close()
     pat.close()
+
+
+def test_long_lines_window_walk(gpu, capi, oracle):
+    """Chromosome-like input: a few lines of 0.3 - 2 MB with sparse planted hits (plus runs of adjacent hits, hits in
+    the last bytes of a chunk and right behind a chunk boundary) between ordinary reads.  On such text the exact pass
+    walks candidate windows instead of whole lines; records, counts and line numbers must still equal the oracle's."""
+    from seeq_amd import device as dev
+    rng = random.Random(99)
+    pat, tau = PAT20, 3
+
+    def dna(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+
+    lines = []
+    for n in (2_000_000, 150, 300_000, 151, 1_000_000, 150):
+        t = list(dna(n))
+        if n > 1000:
+            spots = sorted(rng.sample(range(200, n - 200), 40))
+            spots += [s + rng.choice([21, 25, 40, 100, 129]) for s in spots[:10]]          # neighbours: same / next chunk
+            spots += [128 * rng.randrange(2, n // 128 - 2) + rng.choice([-30, -20, -2, 0, 3, 100, 120]) for _ in range(30)]
+            for p in spots:
+                c = _mutate(rng, pat, rng.randrange(0, tau + 2))
+                t[p:p + len(c)] = list(c)
+        elif rng.random() < 0.5:
+            t[20:40] = list(pat)
+        lines.append("".join(t)[:n])
+    buf = ("\n".join(lines) + "\n").encode()
+    for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+        exp = oracle.buffer_scan(pat, tau, buf, mo)
+        got = _scan(capi, pat, tau, buf, mo, dev.WANT_RECORDS)
+        assert got["kernel"] == "k_stream"
+        assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], mo
+        assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), mo
+    expa = oracle.buffer_scan(pat, tau, buf, SQ_ALL)
+    assert len(expa["records"]) > 100
+    c2 = _scan(capi, pat, tau, buf, 0, dev.WANT_COUNTMATCH)
+    assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
