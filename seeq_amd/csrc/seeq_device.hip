@@ -1137,6 +1137,7 @@ static int run_segments(seeqdev_scan *s)
    if (s->prof) s->prof_segs = nseg;
    for (size_t sg = 0; sg < nseg; sg++) {
       hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
+      uint32_t stream_ntiles = 0;
       ScanArgs a;
       memset(&a, 0, sizeof a);
       a.text = (const uint8_t *)s->text;
@@ -1162,6 +1163,7 @@ static int run_segments(seeqdev_scan *s)
          f.tile_bytes = tile_bytes;
          f.halo = halo;
          f.ntiles = (uint32_t)(((uint64_t)a.seg_len + tile_bytes - 1) / tile_bytes);
+         stream_ntiles = f.ntiles;
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
@@ -1235,7 +1237,8 @@ static int run_segments(seeqdev_scan *s)
          const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
          if (grid_hits == 0) grid_hits = 1;
-         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a, s->hit_col);   /* hit position -> line start; repeats dropped */
+         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a, s->hit_col,
+                                            fasta ? (const uint32_t *)nullptr : (const uint32_t *)s->tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
          uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? s->tmp : nullptr;   /* COUNT -> EMIT */
          /* ---- K4: hits per hit line ---- */

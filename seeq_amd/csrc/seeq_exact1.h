@@ -120,8 +120,10 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       if (hit_col && trusted && !done) {
          const uint32_t col = hit_col[k];
          pos = col > 32 ? col - 32 : 0;
-         const uint32_t lastnl = c->seg_last_nl;           /* a newline at or after the line's start: the line ends in this segment */
-         win = a.stream_ch != 0 && lastnl != 0 && (int64_t)hs - (int64_t)a.pos_bias < (int64_t)lastnl;
+         /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
+         const uint32_t lastnl = c->seg_last_nl;
+         const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
+         win = a.stream_ch != 0 && (last_seg || (lastnl != 0 && (int64_t)hs - (int64_t)a.pos_bias < (int64_t)lastnl));
          wend = (((hs + col) | (a.stream_ch - 1u)) + 1u) - hs;
       }
       bool latch = false;

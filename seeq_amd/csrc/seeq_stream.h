@@ -380,11 +380,34 @@ __global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t *h
 /* After the reorder: hit_start[k] holds the (biased) position of the first hit of a line, hit_line[k] its
  * line number, both ascending.  Turn the position into the start of its line (the exact pass scans whole
  * lines), and drop the repeats of a line (hit_start = 0xFFFFFFFF: k_exact1 skips the entry, nh = 0). */
-__global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit_col)
+/* Offset just after the last '\n' in text[lo, hi), or ~0 when there is none (16 bytes per step, backwards). */
+__device__ __forceinline__ uint64_t stream_line_start_in(const uint8_t *text, uint64_t lo, uint64_t hi)
+{
+   uint64_t q = hi;
+   while (q >= lo + 16) {
+      const fused_v4u v = *reinterpret_cast<const fused_v4u_unaligned *>(text + q - 16);
+      const uint32_t g3 = nl_flags(v.w), g2 = nl_flags(v.z), g1 = nl_flags(v.y), g0 = nl_flags(v.x);
+      if (g3 | g2 | g1 | g0) {
+         uint32_t byte;                                    /* index of the LAST newline among the 16 bytes */
+         if (g3) byte = 12 + ((31 - (uint32_t)__builtin_clz(g3)) >> 3);
+         else if (g2) byte = 8 + ((31 - (uint32_t)__builtin_clz(g2)) >> 3);
+         else if (g1) byte = 4 + ((31 - (uint32_t)__builtin_clz(g1)) >> 3);
+         else byte = (31 - (uint32_t)__builtin_clz(g0)) >> 3;
+         return q - 16 + byte + 1;
+      }
+      q -= 16;
+   }
+   while (q > lo) { if (text[q - 1] == '\n') return q; q--; }
+   return ~(uint64_t)0;
+}
+
+__global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit_col, const uint32_t *tile_cl, uint32_t ntiles,
+                                                       uint32_t tile_bytes)
 {
    Counters *c = a.cnt;
    const uint32_t nhl = c->seg_nhitlines;
    const uint32_t stride = gridDim.x * 256;
+   const uint64_t segb = a.seg_base + a.pos_bias;         /* the segment proper (a.seg_base is the biased base) */
    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
       const uint32_t ln = a.hit_line[k];
       const uint32_t prev = k ? a.hit_line[k - 1] : c->prev_hit_line;
@@ -394,27 +417,31 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit
          continue;
       }
       if (!a.nh[k]) continue;                             /* k_stream already found the start of the line */
-      uint64_t q = a.seg_base + a.hit_start[k];          /* a byte of the line; never '\n' */
-      /* backwards to the byte after the previous '\n' (or the start of the buffer) */
-      while (q >= 16) {
-         const fused_v4u v = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + q - 16);
-         const uint32_t g3 = nl_flags(v.w), g2 = nl_flags(v.z), g1 = nl_flags(v.y), g0 = nl_flags(v.x);
-         if (g3 | g2 | g1 | g0) {
-            uint32_t byte;                                 /* index of the LAST newline among the 16 bytes */
-            if (g3) byte = 12 + ((31 - (uint32_t)__builtin_clz(g3)) >> 3);
-            else if (g2) byte = 8 + ((31 - (uint32_t)__builtin_clz(g2)) >> 3);
-            else if (g1) byte = 4 + ((31 - (uint32_t)__builtin_clz(g1)) >> 3);
-            else byte = (31 - (uint32_t)__builtin_clz(g0)) >> 3;
-            q = q - 16 + byte + 1;
-            goto found;
+      const uint64_t hp = a.seg_base + a.hit_start[k];   /* a byte of the line (inside the segment); never '\n' */
+      /* backwards to the byte after the previous '\n': first inside the hit's tile, then -- chromosome-long lines --
+         tile by tile through the per-tile line counts (tile_cl[] holds their exclusive prefix: 4 bytes per 8 KB of
+         text), and only when the line starts before the segment through the text in front of it */
+      uint64_t q = ~(uint64_t)0;
+      uint64_t floor_ = segb;                              /* nothing searched below this yet */
+      if (tile_cl && hp >= segb) {
+         uint32_t t = (uint32_t)((hp - segb) / tile_bytes);
+         q = stream_line_start_in(a.text, segb + (uint64_t)t * tile_bytes, hp);
+         const uint32_t total = c->seg_nlines - c->seg_nheaders;
+         while (q == ~(uint64_t)0 && t > 0) {
+            t--;
+            const uint32_t cnt = (t + 1 < ntiles ? tile_cl[t + 1] : total) - tile_cl[t] - (t == 0 && a.first_seg ? 1u : 0u);
+            if (cnt) q = stream_line_start_in(a.text, segb + (uint64_t)t * tile_bytes, segb + (uint64_t)(t + 1) * tile_bytes);
          }
-         q -= 16;
+      } else {
+         floor_ = hp;
       }
-      while (q > 0 && a.text[q - 1] != '\n') q--;
-found:
+      if (q == ~(uint64_t)0) {                            /* the line starts before the segment (or at byte 0) */
+         q = stream_line_start_in(a.text, 0, floor_ < hp ? floor_ : hp);
+         if (q == ~(uint64_t)0) q = 0;
+      }
       if (q < a.seg_base) { atomicOr(&c->overflow, 8u); a.hit_start[k] = 0xFFFFFFFFu; }
       else {
-         hit_col[k] = (uint32_t)(a.seg_base + a.hit_start[k] - q);
+         hit_col[k] = (uint32_t)(hp - q);
          a.hit_start[k] = (uint32_t)(q - a.seg_base);
       }
    }
