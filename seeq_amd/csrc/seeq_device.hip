@@ -1167,7 +1167,7 @@ static int run_segments(seeqdev_scan *s)
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
-         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = use_stream ? s->wg_lastnl : nullptr;
+         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = use_stream && s->avg_line > 600.0 ? s->wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
          { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
          if (use_dfa) {
@@ -1210,7 +1210,9 @@ static int run_segments(seeqdev_scan *s)
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
          a.pos_bias = pos_bias;
-         a.stream_ch = use_stream ? (uint32_t)stream_ch : 0u;
+         /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
+            read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
+         a.stream_ch = use_stream && s->avg_line > 600.0 ? (uint32_t)stream_ch : 0u;
       } else {
       /* ---- K0: newline index ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[0], s->stream), EIO);
@@ -1243,8 +1245,13 @@ static int run_segments(seeqdev_scan *s)
          uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? s->tmp : nullptr;   /* COUNT -> EMIT */
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
-            if (use_fused && !generic_exact && fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
-            else if (use_fused && !generic_exact) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1>), dim3(grid_hits), dim3(WG), 0, s->stream, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
+            if (use_fused && !generic_exact) {
+               const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
+#define SEEQ_COUNT1(WW, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, WW, -1, WK>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol, ecache)
+               if (fw == 2) { if (a.stream_ch) SEEQ_COUNT1(2, true); else SEEQ_COUNT1(2, false); }
+               else { if (a.stream_ch) SEEQ_COUNT1(1, true); else SEEQ_COUNT1(1, false); }
+#undef SEEQ_COUNT1
+            }
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
             /* lines with >= 1 verified hit: with 0/1 verdicts that is the scan total (seg_nrec) -- no extra pass */
             if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
@@ -1256,9 +1263,14 @@ static int run_segments(seeqdev_scan *s)
             if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
                const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
-#define SEEQ_EMIT1(WW, OO) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol, ecache)
-               if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST); else SEEQ_EMIT1(2, -1); }
-               else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST); else SEEQ_EMIT1(1, -1); }
+#define SEEQ_EMIT1(WW, OO, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO, WK>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol, ecache)
+               if (a.stream_ch) {
+                  if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST, true); else SEEQ_EMIT1(2, -1, true); }
+                  else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST, true); else SEEQ_EMIT1(1, -1, true); }
+               } else {
+                  if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST, false); else SEEQ_EMIT1(2, -1, false); }
+                  else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST, false); else SEEQ_EMIT1(1, -1, false); }
+               }
 #undef SEEQ_EMIT1
             }
             else {

@@ -71,7 +71,8 @@ template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st,
  * COUNT pass leaves the first two emissions {end, dist} of every line there (for SQ_BEST: the best one, and it then
  * scans the whole line instead of stopping at the first hit), and the EMIT pass only recovers the starts of lines
  * with <= 2 records instead of scanning them again. */
-template <int MODE, int W, int OPT>
+/* WALK: compile the window walk in (long-line inputs); without it the per-character loop carries no walk state */
+template <int MODE, int W, int OPT, bool WALK>
 __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
 {
    __shared__ __align__(8) uint32_t s_eqf[256 * W];
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
    const bool caching = MODE == SQ_MODE_COUNT && cache != nullptr && a.want == SEEQDEV_WANT_RECORDS;
    const bool count_best = caching && match_opt == SQ_BEST;
    const bool cache_ok = MODE == SQ_MODE_EMIT && cache != nullptr && by_nh && !(trusted && count_any);
+   const bool walk = WALK && trusted && hit_col != nullptr && a.stream_ch != 0;     /* window walk (below); kernel-uniform */
    uint8_t *row = s_blk + threadIdx.x * EXACT1_ROW;
    const uint32_t stride = gridDim.x * 256;
    /* wave-uniform trip count so that every lane of a wave takes part in the wave-level votes */
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                   const bool upd = !skip && streak < best_d && (streak < cur || streak == 0);
                   best_d = upd ? streak : best_d;
                   best_end = upd ? pos + t4 + cc : best_end;
-                  lastsub = cur < tau1 && !skip ? (int32_t)(pos + t4 + cc) : lastsub;
+                  if (walk) lastsub = cur < tau1 && !skip ? (int32_t)(pos + t4 + cc) : lastsub;
                   streak = skip ? streak : cur;
                   done = done || term;
                }
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                const uint32_t cur = term ? tau1 : sc;
                const bool stop = streak < cur, zero = streak == 0;
                const uint32_t p = pos + t4 + cc;
-               lastsub = act && cur < tau1 ? (int32_t)p : lastsub;
+               if (walk) lastsub = act && cur < tau1 ? (int32_t)p : lastsub;
                bool end = term;
                const bool emit = act && (stop ? !latch : zero);
                latch = act ? (stop ? true : zero) : latch;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
             }
          }
          pos += 64;
-         if (win && !done) {
+         if (walk && win && !done) {
             /* A score <= tau in the last 32 columns of a chunk (or inside the chunk the walk stands in) may have put
                that chunk's lane into the accepting state before it could report: the chunk has to be scanned whole. */
             const int32_t b = (int32_t)(((hs + pos) & ~(a.stream_ch - 1u)) - hs);      /* start of the chunk holding `pos` */

@@ -292,14 +292,14 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       }
       /* last newline per lane (tile-relative + 2 = start of the next line + 1; 0: none) and its prefix maximum */
       uint32_t incl_last = 0;
-      if (tot_n) {                                        /* wave-uniform */
+      if (tot_n && (tot_h || a.wg_lastnl)) {              /* wave-uniform */
          uint32_t my_last = 0;
 #pragma unroll
          for (int r = 0; r < NM; r++)
             if (nmask[r]) my_last = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
          incl_last = wave_incl_max_u32(my_last);
          /* the segment's last newline decides which line runs on into the next segment (k_exact1) */
-         wv_lastnl = tile * TB + (uint32_t)__builtin_amdgcn_readlane((int)incl_last, 63) - 1u;
+         if (a.wg_lastnl) wv_lastnl = tile * TB + (uint32_t)__builtin_amdgcn_readlane((int)incl_last, 63) - 1u;
       }
       /* ---- ordered compaction of the hit lines: per-wave slice, no atomics ---- */
       if (tot_h) {
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[3 * gwave + 0] = wv_lines;
       a.wg_part[3 * gwave + 1] = wv_hdrs;
-      a.wg_lastnl[gwave] = wv_lastnl;                     /* offset + 1 of the last newline this wave saw */
+      if (a.wg_lastnl) a.wg_lastnl[gwave] = wv_lastnl;    /* offset + 1 of the last newline this wave saw */
       a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
    }
 }
