@@ -37,18 +37,23 @@ for _ in range(58):                                      # planted copies with 0
         c[int(rng.integers(0, len(c)))] = b"ACGT"[int(rng.integers(0, 4))]
     if (p % L) < L - 40:
         text[p:p + len(c)] = torch.from_numpy(c).to(d)
+FA = 0
+if "--fasta" in sys.argv:                                # a header line in front of every chromosome (SEEQDEV_FASTA)
+    FA = dev.SEEQDEV_FASTA
+    for i in range(nlines):
+        text[i * L:i * L + 7] = torch.from_numpy(np.frombuffer((">chr%02d\n" % i).encode(), dtype=np.uint8).copy()).to(d)
 torch.cuda.synchronize()
 
 P = dev.Pattern(PATTERN, TAU)
 sc = dev.Scanner()
 sc.set_profiling(True)
-out = {"shape": "%d lines x %d MiB random DNA, 58 planted copies" % (nlines, mib), "bytes": int(text.numel())}
+out = {"shape": "%d lines x %d MiB random DNA, 58 planted copies%s" % (nlines, mib, ", FASTA headers" if FA else ""), "bytes": int(text.numel())}
 for name, opt, want in (("count_lines", 0, dev.WANT_COUNTLINES), ("count_hits", 0, dev.WANT_COUNTMATCH),
                         ("best", dev.SQ_BEST, dev.WANT_RECORDS), ("all", dev.SQ_ALL, dev.WANT_RECORDS)):
-    sc.scan_tensor(P, text, opt, want)
+    sc.scan_tensor(P, text, opt | FA, want)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    cnt = sc.scan_tensor(P, text, opt, want)
+    cnt = sc.scan_tensor(P, text, opt | FA, want)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out[name] = {"ms": dt * 1e3, "gb_per_s": text.numel() / dt / 1e9, "matching_lines": int(cnt["nmatchlines"]),
@@ -60,7 +65,7 @@ sample = torch.cat([text[L - k:L], text[2 * L - k:2 * L]]).contiguous()
 host = sample.cpu().numpy()
 exp = Oracle().buffer_scan(PATTERN, TAU, host, dev.SQ_ALL)
 s2 = dev.Scanner()
-got = s2.scan_tensor(P, sample, dev.SQ_ALL, dev.WANT_RECORDS)
+got = s2.scan_tensor(P, sample, dev.SQ_ALL, dev.WANT_RECORDS)      # (sample without the header bytes: plain lines)
 out["oracle_sample_check"] = bool(np.array_equal(s2.records(got["nrecords"]).astype(np.uint64), exp["records"]))
 if "--ref" in sys.argv and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "seeq_ref")):
     f = "/dev/shm/chrom.txt"

@@ -91,6 +91,8 @@ struct Counters {
    uint64_t need_records;   /* total */
    uint32_t prev_hit_line;  /* k_stream: line number of the last hit line of the previous segment (a line can span segments) */
    uint32_t seg_last_nl;    /* k_stream: segment-relative offset + 1 of the last newline of the segment (0: none) */
+   uint32_t seg_dirty_tiles; /* k_stream, long-line mode: tiles of the segment that hold a non-alphabet byte */
+   uint32_t pad4;
 };
 
 struct ScanArgs {
@@ -117,6 +119,8 @@ struct ScanArgs {
                                    2 = superset filter (k_dfa); 3 = k_stream (superset only when Counters.dirty,
                                    hit list may repeat a line: hit_start = 0xFFFFFFFF marks a repeat) */
    uint32_t       pos_bias;     /* k_stream: seg_base here is the segment's base minus this (multiple of 128) */
+   const uint32_t *tile_dirty;  /* k_stream, long-line mode: exclusive prefix of the per-tile "holds a non-alphabet byte" flags */
+   uint32_t       stream_ntiles, stream_tile_bytes;
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    Counters      *cnt;
 };
@@ -685,7 +689,7 @@ struct seeqdev_scan {
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
    uint32_t *hit_start, *hit_line, *nh, *hit_col; uint4 *tmp; size_t cap_hitlines;
    /* fused path */
-   uint32_t *tile_cl, *tile_hits; size_t cap_ftiles;
+   uint32_t *tile_cl, *tile_hits, *tile_dirty; size_t cap_ftiles;
    uint32_t *wg_hits;             /* [MAX_FUSED_GRID] */
    uint32_t *wg_part;             /* [3 * MAX_FUSED_GRID] */
    uint32_t *wg_lastnl;           /* [MAX_FUSED_GRID] k_stream: last newline seen by each wave */
@@ -770,7 +774,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
    void *bufs[] = {s->rec_off, s->wg_hits, s->wg_part, s->wg_lastnl, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
-                   s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->d_eqtab,
+                   s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->tile_dirty, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
@@ -797,6 +801,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
       const size_t ftiles = seg / FUSED_MIN_TILE + 2;
       if (ftiles > s->cap_ftiles) {
          if (ws_alloc((void **)&s->tile_cl, ftiles * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->tile_dirty, ftiles * sizeof(uint32_t))) return -1;
          if (ws_alloc((void **)&s->tile_hits, ftiles * sizeof(uint32_t))) return -1;
          s->cap_ftiles = ftiles;
       }
@@ -986,7 +991,7 @@ static int run_segments(seeqdev_scan *s)
    bool use_direct = false, use_dfa = false;
    const int stream_wu = pat->wlen + pat->tau - 1 <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
-   bool stream_ilp2 = false;
+   bool stream_ilp2 = false, stream_ll = false;
    size_t dfa_lds = 0;
    if (use_fused) {
       const char *ke = getenv("SEEQ_FUSED_KERNEL");
@@ -1020,10 +1025,15 @@ static int run_segments(seeqdev_scan *s)
          nw = STREAM_NW;
          tile_bytes = 64u * (uint32_t)stream_ch;
          { const char *ie = getenv("SEEQ_STREAM_ILP"); stream_ilp2 = stream_ch == 128 && !(ie && atoi(ie) == 1); }
-         stream_fn = fasta ? (stream_wu == 6 ? (const void *)k_stream<128, 6, true, true> : (const void *)k_stream<128, 8, true, true>)
-                   : stream_ch == 128 ? (stream_ilp2 ? (stream_wu == 6 ? (const void *)k_stream<128, 6, true, false> : (const void *)k_stream<128, 8, true, false>)
-                                                     : (stream_wu == 6 ? (const void *)k_stream<128, 6, false, false> : (const void *)k_stream<128, 8, false, false>))
-                                      : (stream_wu == 6 ? (const void *)k_stream<64, 6, false, false> : (const void *)k_stream<64, 8, false, false>);
+         stream_ll = s->avg_line > 600.0 && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
+#define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
+         stream_fn = stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
+                                        : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true) : SEEQ_STREAM_FN(128, 8, true, false, true)))
+                   : fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, false) : SEEQ_STREAM_FN(128, 8, true, true, false))
+                   : stream_ch == 128 ? (stream_ilp2 ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false) : SEEQ_STREAM_FN(128, 8, true, false, false))
+                                                     : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, false, false, false) : SEEQ_STREAM_FN(128, 8, false, false, false)))
+                                      : (stream_wu == 6 ? SEEQ_STREAM_FN(64, 6, false, false, false) : SEEQ_STREAM_FN(64, 8, false, false, false));
+#undef SEEQ_STREAM_FN
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          HIP_TRY(hipFuncSetAttribute(stream_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dfa_lds), EIO);
          int per_cu = 0;
@@ -1167,7 +1177,8 @@ static int run_segments(seeqdev_scan *s)
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
-         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = use_stream && s->avg_line > 600.0 ? s->wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
+         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = stream_ll ? s->wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
+         f.tile_dirty = f.wg_lastnl ? s->tile_dirty : nullptr;
          { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
          if (use_dfa) {
@@ -1188,10 +1199,12 @@ static int run_segments(seeqdev_scan *s)
          f.slice_cap = f.cap_tmp / nslices;
          if (use_stream) {
 #define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f)
-            if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true); }
-            else if (stream_ch == 128 && stream_ilp2) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, false); }
-            else if (stream_ch == 128) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, false, false); else SEEQ_STREAM_LAUNCH(128, 8, false, false); }
-            else { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(64, 6, false, false); else SEEQ_STREAM_LAUNCH(64, 8, false, false); }
+            if (stream_ll && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true, true); }
+            else if (stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true); }
+            else if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false); }
+            else if (stream_ch == 128 && stream_ilp2) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false); }
+            else if (stream_ch == 128) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, false, false, false); else SEEQ_STREAM_LAUNCH(128, 8, false, false, false); }
+            else { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(64, 6, false, false, false); else SEEQ_STREAM_LAUNCH(64, 8, false, false, false); }
 #undef SEEQ_STREAM_LAUNCH
          }
          else if (use_dfa) hipLaunchKernelGGL(k_dfa, dim3(fgrid), dim3(64 * DFA_NW), dfa_lds, s->stream, f);
@@ -1205,14 +1218,16 @@ static int run_segments(seeqdev_scan *s)
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
             launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
             launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
+            if (f.tile_dirty) launch_scan<0>(s, f.tile_dirty, f.tile_dirty, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_dirty_tiles);
             if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line, s->nh, s->hit_col);
             else hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
          a.pos_bias = pos_bias;
+         a.tile_dirty = f.tile_dirty; a.stream_ntiles = f.ntiles; a.stream_tile_bytes = tile_bytes;
          /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
             read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
-         a.stream_ch = use_stream && s->avg_line > 600.0 ? (uint32_t)stream_ch : 0u;
+         a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;
       } else {
       /* ---- K0: newline index ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[0], s->stream), EIO);
@@ -1240,7 +1255,7 @@ static int run_segments(seeqdev_scan *s)
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
          if (grid_hits == 0) grid_hits = 1;
          if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a, s->hit_col,
-                                            fasta ? (const uint32_t *)nullptr : (const uint32_t *)s->tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
+                                            (const uint32_t *)s->tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
          uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? s->tmp : nullptr;   /* COUNT -> EMIT */
          /* ---- K4: hits per hit line ---- */

@@ -51,6 +51,35 @@ __device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *text, uint64_t
    return (uint32_t)((int)i - jj);
 }
 
+/* Only alphabet bytes (A C G T N, either case, newline) in text[lo, hi)?  The window walk may skip such a stretch of
+ * a line: no byte in it ends the line (SQ_FAIL), and k_stream's verdict "no hit ends in it" is exact.  Whole tiles are
+ * answered by the exclusive prefix of k_stream's per-tile flags, the partial tiles at both ends by reading the bytes. */
+__device__ __forceinline__ bool exact1_bytes_clean(const uint8_t *text, uint64_t lo, uint64_t hi)
+{
+   uint32_t bad = 0;
+   uint64_t p = lo;
+   for (; p + 16 <= hi && !bad; p += 16) {
+      const fused_v4u v = *reinterpret_cast<const fused_v4u_unaligned *>(text + p);
+      bad = fused_bad4(v.x) | fused_bad4(v.y) | fused_bad4(v.z) | fused_bad4(v.w);
+   }
+   for (; p < hi && !bad; p++) bad = fused_bad4(0x0A0A0A00u | text[p]);
+   return bad == 0;
+}
+
+__device__ __forceinline__ bool exact1_clean(const ScanArgs &a, uint64_t lo, uint64_t hi)
+{
+   if (hi <= lo) return true;
+   if (!a.cnt->dirty) return true;                        /* nothing outside the alphabet in the text scanned so far */
+   const uint64_t segb = a.seg_base + a.pos_bias;         /* the segment proper */
+   if (!a.tile_dirty || lo < segb) return false;
+   const uint64_t TB = a.stream_tile_bytes;
+   const uint64_t t_lo = (lo - segb + TB - 1) / TB, t_hi = (hi - segb) / TB;          /* whole tiles [t_lo, t_hi) */
+   if (t_lo >= t_hi) return exact1_bytes_clean(a.text, lo, hi);
+   const uint32_t d_hi = t_hi < a.stream_ntiles ? a.tile_dirty[t_hi] : a.cnt->seg_dirty_tiles;
+   if (d_hi != a.tile_dirty[t_lo]) return false;
+   return exact1_bytes_clean(a.text, lo, segb + t_lo * TB) && exact1_bytes_clean(a.text, segb + t_hi * TB, hi);
+}
+
 template <int W> __device__ __forceinline__ void exact1_take(fused_state_t<W> &st, const fused_state_t<W> &s2, bool take);
 template <> __device__ __forceinline__ void exact1_take<1>(fused_state_t<1> &st, const fused_state_t<1> &s2, bool take)
 {
@@ -93,7 +122,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
    const bool caching = MODE == SQ_MODE_COUNT && cache != nullptr && a.want == SEEQDEV_WANT_RECORDS;
    const bool count_best = caching && match_opt == SQ_BEST;
    const bool cache_ok = MODE == SQ_MODE_EMIT && cache != nullptr && by_nh && !(trusted && count_any);
-   const bool walk = WALK && trusted && hit_col != nullptr && a.stream_ch != 0;     /* window walk (below); kernel-uniform */
+   const bool walk = WALK && a.use_nh == 3 && hit_col != nullptr && a.stream_ch != 0;     /* window walk (below); kernel-uniform */
    uint8_t *row = s_blk + threadIdx.x * EXACT1_ROW;
    const uint32_t stride = gridDim.x * 256;
    /* wave-uniform trip count so that every lane of a wave takes part in the wave-level votes */
@@ -119,13 +148,14 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       bool win = false;
       uint32_t wend = 0, knext = k + 1;                    /* end of the current window (column), next hit-list entry */
       int32_t lastsub = -0x40000000;                       /* column of the last score <= tau seen */
-      if (hit_col && trusted && !done) {
+      if (hit_col && (trusted || walk) && !done) {
          const uint32_t col = hit_col[k];
-         pos = col > 32 ? col - 32 : 0;
+         /* nothing ends the line before the first candidate (clean text), so the scan may start just before it */
+         if (col > 32 && (trusted || exact1_clean(a, off, off + col - 32))) pos = col - 32;
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
-         win = a.stream_ch != 0 && (last_seg || (lastnl != 0 && (int64_t)hs - (int64_t)a.pos_bias < (int64_t)lastnl));
+         win = walk && (last_seg || (lastnl != 0 && (int64_t)hs - (int64_t)a.pos_bias < (int64_t)lastnl));
          wend = (((hs + col) | (a.stream_ch - 1u)) + 1u) - hs;
       }
       bool latch = false;
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
                   if (!(knext < nhl && a.hit_start[knext] == 0xFFFFFFFFu)) { done = true; break; }   /* no candidate left */
                   const uint32_t cpos = hit_col[knext++];                 /* position of the repeat's first hit */
                   const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs;
-                  if (ccol > pos + 32) {                                  /* jump: fresh column 32 columns before it */
+                  if (ccol > pos + 32 && exact1_clean(a, off + pos, off + ccol - 32)) {   /* jump: fresh column 32 columns before it */
                      pos = ccol - 32; wend = cend;
                      st.init(m); streak = tau1; latch = false; lastsub = -0x40000000;
                      break;

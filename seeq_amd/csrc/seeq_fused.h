@@ -60,6 +60,7 @@ struct FusedArgs {
    uint32_t       slice_cap;   /* entries per workgroup slice = cap_tmp / grid  */
    uint32_t      *wg_hits;     /* per slice (workgroup of k_fused / wave of k_direct): entries stored */
    uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31}               */
+   uint32_t      *tile_dirty;  /* k_stream, long-line mode: per tile, 1 when it holds a byte outside the alphabet (then its exclusive prefix); else NULL */
    uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */
    uint32_t       debug;       /* profiling experiments only (SEEQ_FUSED_DEBUG): 1 = skip the per-line scan */
    const uint16_t *dfa;        /* k_dfa: transition table, dfa_rows x 8 u16 (seeq_dfa.h) */
@@ -85,6 +86,15 @@ __device__ __forceinline__ void fused_step(uint32_t eq, uint32_t &pv, uint32_t &
        : "=v"(mh2), "+v"(score) : "v"(mh) : "vcc");
    pv = mh2 | ~(d0 | ph2);
    mv = ph2 & d0;
+}
+
+/* alphabet check of four characters: nonzero when a byte is outside {ACGTN, acgtn, '\n'} (k_stream's table columns
+ * are exact for those; any other byte aliases onto one of them) */
+__device__ __forceinline__ uint32_t fused_bad4(uint32_t w)
+{
+   /* canonical byte of each table column (A C T G . \n . N); the case-folded text must equal it */
+   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, (w & 0x0E0E0E0Eu) >> 1);
+   return (w & 0xDFDFDFDFu) ^ canon;
 }
 
 /* Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts

@@ -57,14 +57,6 @@ __device__ __forceinline__ void stream_warm4(uint32_t &state, uint32_t w)
    STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad;
 }
 
-/* alphabet check of four characters: nonzero when a byte is outside {ACGTN, acgtn, '\n'} */
-__device__ __forceinline__ uint32_t stream_bad4(uint32_t w)
-{
-   /* canonical byte of each table column (A C T G . \n . N); the case-folded text must equal it */
-   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, (w & 0x0E0E0E0Eu) >> 1);
-   return (w & 0xDFDFDFDFu) ^ canon;
-}
-
 /* four owned characters: walk, first-hit mask, newline mask */
 __device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_t &hm, uint32_t &nm,
                                             uint32_t acc_new, uint32_t ten)
@@ -126,7 +118,9 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
 /* FA: FASTA input (SEEQDEV_FASTA): a line that starts with '>' is a header -- not counted, never a hit line
  * (reference seeq.c:367-374).  Headers are found per NEWLINE (is the byte after it a '>'?), so the walk itself is
  * unchanged; candidates inside a header are discarded by the exact pass, which looks at the first byte of the line. */
-template <int CH, int WU, bool ILP2, bool FA>
+/* LL: long-line mode -- per-tile "dirty" flags and the segment's last newline for the window walk of the exact pass
+ * (kept out of the read-length kernel: its tile loop has no register to spare). */
+template <int CH, int WU, bool ILP2, bool FA, bool LL>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
@@ -181,11 +175,12 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       {
          uint32_t bad = 0;
 #pragma unroll
-         for (int q = 0; q < NQ; q++) bad |= stream_bad4(v[q].x) | stream_bad4(v[q].y) | stream_bad4(v[q].z) | stream_bad4(v[q].w);
+         for (int q = 0; q < NQ; q++) bad |= fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);
          /* a byte outside the alphabet anywhere in the tile: the scan's verdicts need verifying */
          uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(__any(bad != 0) ? 1 : 0);
          asm volatile("" : "+s"(flag));                   /* pinned here: the walk below needs the registers */
          wv_dirty |= flag;
+         if (LL && lane == 0) a.tile_dirty[tile] = flag;
       }
       uint32_t hmask[NM], nmask[NM];
       if (ILP2 && CH == 128) {
@@ -292,14 +287,14 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       }
       /* last newline per lane (tile-relative + 2 = start of the next line + 1; 0: none) and its prefix maximum */
       uint32_t incl_last = 0;
-      if (tot_n && (tot_h || a.wg_lastnl)) {              /* wave-uniform */
+      if (tot_n && (tot_h || LL)) {                       /* wave-uniform */
          uint32_t my_last = 0;
 #pragma unroll
          for (int r = 0; r < NM; r++)
             if (nmask[r]) my_last = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
          incl_last = wave_incl_max_u32(my_last);
          /* the segment's last newline decides which line runs on into the next segment (k_exact1) */
-         if (a.wg_lastnl) wv_lastnl = tile * TB + (uint32_t)__builtin_amdgcn_readlane((int)incl_last, 63) - 1u;
+         if (LL) wv_lastnl = tile * TB + (uint32_t)__builtin_amdgcn_readlane((int)incl_last, 63) - 1u;
       }
       /* ---- ordered compaction of the hit lines: per-wave slice, no atomics ---- */
       if (tot_h) {
@@ -353,7 +348,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[3 * gwave + 0] = wv_lines;
       a.wg_part[3 * gwave + 1] = wv_hdrs;
-      if (a.wg_lastnl) a.wg_lastnl[gwave] = wv_lastnl;    /* offset + 1 of the last newline this wave saw */
+      if (LL) a.wg_lastnl[gwave] = wv_lastnl;    /* offset + 1 of the last newline this wave saw */
       a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
    }
 }
@@ -429,7 +424,9 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit
          const uint32_t total = c->seg_nlines - c->seg_nheaders;
          while (q == ~(uint64_t)0 && t > 0) {
             t--;
-            const uint32_t cnt = (t + 1 < ntiles ? tile_cl[t + 1] : total) - tile_cl[t] - (t == 0 && a.first_seg ? 1u : 0u);
+            /* counted line starts of the tile (> 0: it holds a newline that starts a line); tile 0 carries the
+               corrections for the line at byte 0 / a FASTA header there: just look into it */
+            const uint32_t cnt = t == 0 ? 1u : (t + 1 < ntiles ? tile_cl[t + 1] : total) - tile_cl[t];
             if (cnt) q = stream_line_start_in(a.text, segb + (uint64_t)t * tile_bytes, segb + (uint64_t)(t + 1) * tile_bytes);
          }
       } else {

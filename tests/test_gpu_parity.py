@@ -708,3 +708,28 @@ def test_long_lines_window_walk(gpu, capi, oracle):
     assert len(expa["records"]) > 100
     c2 = _scan(capi, pat, tau, buf, 0, dev.WANT_COUNTMATCH)
     assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
+    # the same lines as FASTA records (headers make the text "dirty": the walk has to prove every stretch it skips
+    # clean), and with non-DNA bytes inside the long lines (SQ_FAIL: everything behind such a byte is dead)
+    fa = []
+    for i, ln in enumerate(lines):
+        fa.append(">chr%d %s" % (i, pat if i % 2 else "len=%d" % len(ln)))
+        fa.append(ln)
+    dirty = list(lines)
+    for i in (0, 2, 4):
+        t = list(dirty[i])
+        for p in rng.sample(range(len(t) // 3, len(t)), 3):
+            t[p] = rng.choice("!*RYJ+.")
+        dirty[i] = "".join(t)
+    for text_lines, fasta in ((fa, True), (dirty, False)):
+        b2 = ("\n".join(text_lines) + "\n").encode()
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = oracle.buffer_scan(pat, tau, b2, mo, fasta=fasta)
+            got = _scan(capi, pat, tau, b2, mo, dev.WANT_RECORDS, fasta)
+            assert got["kernel"] == "k_stream"
+            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (fasta, mo)
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (fasta, mo)
+        expa = oracle.buffer_scan(pat, tau, b2, SQ_ALL, fasta=fasta)
+        c1 = _scan(capi, pat, tau, b2, 0, dev.WANT_COUNTLINES, fasta)
+        c2 = _scan(capi, pat, tau, b2, 0, dev.WANT_COUNTMATCH, fasta)
+        assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], fasta
+        assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], fasta
