@@ -5,6 +5,7 @@ from oracle.pyoracle import Oracle, SQ_ALL, SQ_BEST, SQ_FIRST
 from seeq_amd import device as dev
 from test_gpu_parity import _mutate
 o = Oracle()
+LONG = len(sys.argv) > 1 and sys.argv[1] == "long"      # long lines: the LL variant of k_stream + the window walk of k_exact1
 tot = 0; ks = {}
 for seed in range(100, 112):
     rng = random.Random(seed)
@@ -21,15 +22,16 @@ for seed in range(100, 112):
         pattern, core = "".join(parts), "".join(plain)
         tau = rng.randint(0, min(4, m - 1, 33 - m))
         lines = []
-        for _ in range(3000):
-            n = rng.choice([0, 2, 19, 50, 100, 151, 151, 151, 260, 700])
+        for _ in range(120 if LONG else 3000):
+            n = rng.choice([0, 151, 2000, 8191, 8192, 8300, 20000, 70000]) if LONG else rng.choice([0, 2, 19, 50, 100, 151, 151, 151, 260, 700])
             t = [rng.choice("ACGT") for _ in range(n)]
-            if n >= m and rng.random() < 0.35:
-                c = _mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
-                p = rng.randrange(0, n - len(c) + 1) if n >= len(c) else 0
-                t[p:p + len(c)] = list(c)
+            for _rep in range(1 + (n // 900 if LONG else 0)):
+                if n >= m and rng.random() < (0.8 if LONG else 0.35):
+                    c = _mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
+                    p = rng.randrange(0, n - len(c) + 1) if n >= len(c) else 0
+                    t[p:p + len(c)] = list(c)
             if rng.random() < 0.03 and n: t[rng.randrange(n)] = "N"
-            if seed % 3 == 0 and rng.random() < 0.01 and n: t[rng.randrange(n)] = rng.choice("!*+BJXZ.\t\r@>")
+            if seed % 3 == 0 and rng.random() < (0.3 if LONG else 0.01) and n: t[rng.randrange(n)] = rng.choice("!*+BJXZ.\t\r@>")
             lines.append("".join(t)[:n])
         fasta = seed % 4 == 1
         if fasta:

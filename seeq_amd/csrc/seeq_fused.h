@@ -92,9 +92,12 @@ __device__ __forceinline__ void fused_step(uint32_t eq, uint32_t &pv, uint32_t &
  * are exact for those; any other byte aliases onto one of them) */
 __device__ __forceinline__ uint32_t fused_bad4(uint32_t w)
 {
-   /* canonical byte of each table column (A C T G . \n . N); the case-folded text must equal it */
-   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, (w & 0x0E0E0E0Eu) >> 1);
-   return (w & 0xDFDFDFDFu) ^ canon;
+   /* canonical byte of each table column (A C T G . \n . N); the text must equal it -- letters in either case,
+      the newline exactly ('*' = 0x2A is '\n' with the case bit set: it must NOT pass) */
+   const uint32_t idx = (w & 0x0E0E0E0Eu) >> 1;
+   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx);
+   const uint32_t fold = __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDFDFDFu, idx);      /* per column: case-fold mask */
+   return (w & fold) ^ canon;
 }
 
 /* Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts

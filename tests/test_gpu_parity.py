@@ -181,7 +181,8 @@ def test_edge_buffers(gpu, capi, oracle, path):
     from seeq_amd import device as dev
     rng = random.Random(3)
     ragged = b"".join((b"ACGT" * rng.randint(0, 60))[:rng.randint(0, 200)] + b"\n" for _ in range(3000))
-    cases = [b"", b"\n", b"\n\n\n", b"ACGT", b"ACGT\n", b"\nACGT", b"ACGT\n\nACGT\n", b"ACGT\0ACGT\nACGT",
+    star = b"TTTT*ACGT\nACGT*TTTT\nAC*GT\n" * 50          # '*' (newline with the case bit set) must count as non-DNA
+    cases = [star, b"", b"\n", b"\n\n\n", b"ACGT", b"ACGT\n", b"\nACGT", b"ACGT\n\nACGT\n", b"ACGT\0ACGT\nACGT",
              b"AC\rGT\r\nACGT\r\n", b"A" * 5000 + b"\n" + b"ACGT" * 3, b"\n" * 70000 + b"ACGT\n",
              bytes(range(256)) * 3, ragged, b"T" * 4090 + b"ACGT\nACGT" + b"T" * 4090 + b"AC\nGT\n",
              (b"ACGT" * 300 + b"\n") * 40]
@@ -733,3 +734,23 @@ def test_long_lines_window_walk(gpu, capi, oracle):
         c2 = _scan(capi, pat, tau, b2, 0, dev.WANT_COUNTMATCH, fasta)
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], fasta
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], fasta
+
+
+def test_every_byte_value_alone(gpu, capi, oracle):
+    """One foreign byte value at a time in otherwise clean text, right in front of a perfect copy of the pattern:
+    k_stream's alphabet check must flag exactly the bytes that are not A C G T N (either case) or newline -- each of
+    the 256 values gets its own scan, so no other byte can raise the flag for it."""
+    from seeq_amd import device as dev
+    pat = dev.Pattern(PAT20, 3)
+    sc = dev.Scanner()
+    for b in range(256):
+        buf = (b"TTTTTTTT" + bytes([b]) + PAT20.encode() + b"TT\n" + b"ACGTACGTAC" + bytes([b]) + b"\n") * 40
+        for opt, want in ((0, dev.WANT_COUNTLINES), (SQ_ALL, dev.WANT_RECORDS)):
+            exp = oracle.buffer_scan(PAT20, 3, buf, opt)
+            got = sc.scan_host(pat, buf, opt, want)
+            assert sc.last_kernel() == "k_stream"
+            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], b
+            if want == dev.WANT_RECORDS:
+                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), b
+    sc.close()
+    pat.close()
