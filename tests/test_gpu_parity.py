@@ -754,3 +754,43 @@ def test_every_byte_value_alone(gpu, capi, oracle):
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), b
     sc.close()
     pat.close()
+
+
+def test_stream_fuzz_long_lines(gpu, capi, oracle):
+    """Random patterns over long lines (up to 70 000 bytes, many planted hits per line, some with a non-DNA byte or as
+    FASTA records): the long-line variant of k_stream and the window walk of the exact pass against the oracle."""
+    from seeq_amd import device as dev
+    rng = random.Random(4242)
+    seen = {}
+    for it in range(12):
+        m = rng.choice([6, 12, 18, 20, 25, 30])
+        pattern = "".join(rng.choice("ACGT") if rng.random() > 0.1 else rng.choice(["N", "[AC]", "[GT]"]) for _ in range(m))
+        core = dev.plain_pattern(pattern).replace("N", "A")
+        tau = rng.randint(0, min(4, m - 1, 33 - m))
+        fasta, dirty = it % 4 == 1, it % 4 == 2
+        lines = []
+        for _ in range(60):
+            n = rng.choice([0, 151, 2000, 8191, 8192, 8300, 20000, 70000])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            for _rep in range(1 + n // 900):
+                if n >= m and rng.random() < 0.8:
+                    c = _mutate(rng, core, rng.randint(0, tau + 2))
+                    p = rng.randrange(0, n - len(c) + 1) if n >= len(c) else 0
+                    t[p:p + len(c)] = list(c)
+            if dirty and n and rng.random() < 0.4:
+                t[rng.randrange(n)] = rng.choice("!*+BJXZ.\t\r@>")
+            s = "".join(t)[:n]
+            if fasta and rng.random() < 0.4:
+                lines.append(">rec %d %s" % (len(lines), core))
+            lines.append(s)
+        buf = ("\n".join(lines) + ("\n" if it % 2 else "")).encode()
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = oracle.buffer_scan(pattern, tau, buf, mo, fasta=fasta)
+            got = _scan(capi, pattern, tau, buf, mo, dev.WANT_RECORDS, fasta)
+            seen[got["kernel"]] = seen.get(got["kernel"], 0) + 1
+            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (it, pattern, tau, mo)
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (it, pattern, tau, mo)
+        expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL, fasta=fasta)
+        c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH, fasta)
+        assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (it, pattern, tau)
+    assert seen.get("k_stream", 0) >= 24, seen
