@@ -794,3 +794,24 @@ def test_stream_fuzz_long_lines(gpu, capi, oracle):
         c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH, fasta)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (it, pattern, tau)
     assert seen.get("k_stream", 0) >= 24, seen
+
+
+def test_long_string_match(gpu, capi, oracle):
+    """seeqStringMatch on a chromosome-sized string (3 MB, sparse hits): served by the batched line scan (line 1 of
+    the buffer) instead of the one-lane single-line kernels; same hits as the oracle, also with a '\\n' or a non-DNA
+    byte in the middle (everything behind it is not part of the string's matchable prefix) and under SQ_CONVERT."""
+    rng = random.Random(31)
+    n = 3_000_000
+    t = [rng.choice("ACGT") for _ in range(n)]
+    for p in sorted(rng.sample(range(100, n - 100), 60)):
+        c = _mutate(rng, PAT20, rng.randrange(0, 5))
+        t[p:p + len(c)] = list(c)
+    base = "".join(t)
+    cut = n // 2
+    variants = [(base, 0), (base[:cut] + "\n" + base[cut + 1:], 0), (base[:cut] + "R" + base[cut + 1:], 0),
+                (base[:cut] + "R" + base[cut + 1:], SQ_CONVERT), (base.lower(), SQ_IGNORE)]
+    s = SQ(capi, PAT20, 3)
+    for text, nd in variants:
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            assert s.match(text, mo | nd) == oracle.string_match(PAT20, 3, text, mo | nd), (mo, nd, text[cut - 2:cut + 2])
+    s.close()
