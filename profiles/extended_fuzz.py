@@ -7,7 +7,8 @@ from test_gpu_parity import _mutate
 o = Oracle()
 LONG = len(sys.argv) > 1 and sys.argv[1] == "long"      # long lines: the LL variant of k_stream + the window walk of k_exact1
 tot = 0; ks = {}
-for seed in range(100, 112):
+BASE = int(os.environ.get("FUZZ_SEED", "100"))          # FUZZ_SEED=<n>: another set of 12 seeds
+for seed in range(BASE, BASE + 12):
     rng = random.Random(seed)
     for it in range(25):
         m = rng.choice([4, 6, 9, 12, 15, 18, 20, 22, 25, 28, 30])
