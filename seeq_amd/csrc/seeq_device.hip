@@ -82,7 +82,7 @@ struct Counters {
    uint64_t records;
    uint64_t headers;
    /* workspace overflow report */
-   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text */
+   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
    uint32_t seg_tmp_hits;   /* k_fused: hit lines of this segment (summed per workgroup) */
@@ -721,6 +721,7 @@ struct seeqdev_scan {
    size_t seg_bytes;           /* segment size */
    bool user_reserved;         /* caller sized the per-line workspace: trust it */
    bool no_stream;             /* k_stream met a line it cannot address (starts > 1 GiB before its segment): use the per-line kernels */
+   bool force_ll;              /* a read-length looking buffer had hits inside very long lines: use k_stream's long-line variant */
    bool no_stream_nd;          /* SQ_CONVERT / SQ_IGNORE: the text has non-DNA bytes, k_stream (exact for clean text only) is off */
 };
 
@@ -1025,7 +1026,7 @@ static int run_segments(seeqdev_scan *s)
          nw = STREAM_NW;
          tile_bytes = 64u * (uint32_t)stream_ch;
          { const char *ie = getenv("SEEQ_STREAM_ILP"); stream_ilp2 = stream_ch == 128 && !(ie && atoi(ie) == 1); }
-         stream_ll = s->avg_line > 600.0 && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
+         stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
 #define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
          stream_fn = stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
                                         : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true) : SEEQ_STREAM_FN(128, 8, true, false, true)))
@@ -1381,6 +1382,7 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
       if (h.overflow & 2u) nhl = (size_t)h.need_hitlines + (h.need_hitlines >> 3) + 64;
       if (h.overflow & 8u) s->no_stream = true;
       if (h.overflow & 16u) s->no_stream_nd = true;
+      if (h.overflow & 32u) s->force_ll = true;
       if (h.overflow & 4u) {
          /* need_records keeps counting after the overflow, so it is the total of this run. */
          nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;

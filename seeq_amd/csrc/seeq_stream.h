@@ -336,14 +336,16 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          a.tile_cl[tile] = tot_n + extra - tot_d - hd_extra;    /* counted lines: headers excluded */
          a.tile_hits[tile] = tot_h;
       }
+      if (!LL && CH == 128 && ILP2 && tot_h && !tot_n) wv_dirty |= 2u;   /* a hit inside a line of >= a whole tile: ask for the long-line variant (of this configuration) */
       wv_lines += tot_n + extra;
       wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;
    }
-   if (wv_dirty && lane == 0) {
+   if ((wv_dirty & 1u) && lane == 0) {
       atomicOr(&a.cnt->dirty, 1u);
       if (a.options & MASK_NONDNA) atomicOr(&a.cnt->overflow, 16u);   /* SQ_CONVERT / SQ_IGNORE: only exact on clean text -> re-run */
    }
+   if ((wv_dirty & 2u) && lane == 0) atomicOr(&a.cnt->overflow, 32u);     /* re-run once with the long-line variant (then kept) */
    if (lane == 0) {
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[3 * gwave + 0] = wv_lines;

@@ -815,3 +815,24 @@ def test_long_string_match(gpu, capi, oracle):
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
             assert s.match(text, mo | nd) == oracle.string_match(PAT20, 3, text, mo | nd), (mo, nd, text[cut - 2:cut + 2])
     s.close()
+
+
+def test_mixed_reads_and_long_line(gpu, capi, oracle):
+    """A file of reads (the sampled average line is short: the read-length kernels are chosen) with one 2 MB line
+    that has hits: the scan notices, re-runs itself once with the long-line variant, and the results are the oracle's."""
+    from seeq_amd import device as dev
+    rng = random.Random(8)
+    reads = ["".join(rng.choice("ACGT") for _ in range(150)) for _ in range(3000)]
+    for i in range(0, 3000, 17):
+        reads[i] = reads[i][:40] + _mutate(rng, PAT20, rng.randrange(0, 4)) + reads[i][60:]
+    big = [rng.choice("ACGT") for _ in range(2_000_000)]
+    for p in rng.sample(range(1000, 1_999_000), 25):
+        big[p:p + 20] = list(_mutate(rng, PAT20, rng.randrange(0, 4)))[:20]
+    lines = reads[:2000] + ["".join(big)] + reads[2000:]
+    buf = ("\n".join(lines) + "\n").encode()
+    for mo in (SQ_BEST, SQ_ALL):
+        exp = oracle.buffer_scan(PAT20, 3, buf, mo)
+        got = _scan(capi, PAT20, 3, buf, mo, dev.WANT_RECORDS)
+        assert got["kernel"] == "k_stream"
+        assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], mo
+        assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), mo
