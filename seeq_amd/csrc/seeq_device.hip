@@ -835,7 +835,8 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
    if (s->cap_chunks > largest) largest = s->cap_chunks;
    if (s->cap_hitlines > largest) largest = s->cap_hitlines;
    if (s->cap_ftiles > largest) largest = s->cap_ftiles;
-   const size_t nb = largest / SCAN_BLOCK + 2;
+   size_t nb = largest / SCAN_BLOCK + 2;
+   if (3 * (s->cap_ftiles / SCAN_BLOCK + 2) > nb) nb = 3 * (s->cap_ftiles / SCAN_BLOCK + 2);   /* launch_scanset: three tile arrays at once */
    if (nb > s->cap_scan_ws) {
       if (ws_alloc((void **)&s->scan_ws, nb * sizeof(uint32_t))) return -1;
       s->cap_scan_ws = nb;
@@ -874,6 +875,66 @@ extern "C" int seeqdevScanLastTimes(const seeqdev_scan_t *s, float ms[4])
    return 0;
 }
 
+/* Up to three u32 arrays of the same host-known length scanned in place by ONE set of three launches (the per-tile
+ * arrays of the one-pass kernels): blockIdx.y selects the array, bsum has one region of `nb` partial sums per array. */
+struct ScanSet { uint32_t *arr[3]; uint32_t *total[3]; };
+
+__global__ __launch_bounds__(WG) void k_scanset_reduce(ScanSet ss, uint32_t *bsum, uint32_t n, uint32_t nb)
+{
+   __shared__ uint32_t s_wave[4];
+   const uint32_t *in = ss.arr[blockIdx.y];
+   const uint32_t base = blockIdx.x * SCAN_BLOCK;
+   uint32_t v = 0;
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      if (i < n) v += in[i];
+   }
+   uint32_t tot;
+   block_excl_scan(v, &tot, s_wave);
+   if (threadIdx.x == 0) bsum[blockIdx.y * nb + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(WG) void k_scanset_top(ScanSet ss, uint32_t *bsum, uint32_t nb)
+{
+   __shared__ uint32_t s_wave[4];
+   uint32_t *b = bsum + blockIdx.x * nb;
+   uint32_t running = 0;
+   for (uint32_t b0 = 0; b0 < nb; b0 += WG) {
+      const uint32_t i = b0 + threadIdx.x;
+      const uint32_t v = i < nb ? b[i] : 0;
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan(v, &tot, s_wave);
+      if (i < nb) b[i] = running + ex;
+      running += tot;
+      __syncthreads();
+   }
+   if (threadIdx.x == 0 && ss.total[blockIdx.x]) *ss.total[blockIdx.x] = running;
+}
+
+__global__ __launch_bounds__(WG) void k_scanset_apply(ScanSet ss, const uint32_t *bsum, uint32_t n, uint32_t nb)
+{
+   __shared__ uint32_t s_wave[4];
+   uint32_t *arr = ss.arr[blockIdx.y];
+   const uint32_t base = blockIdx.x * SCAN_BLOCK;
+   uint32_t item[SCAN_ITEMS];
+   uint32_t v = 0;
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      item[k] = i < n ? arr[i] : 0;
+      v += item[k];
+   }
+   uint32_t tot;
+   uint32_t ex = block_excl_scan(v, &tot, s_wave) + bsum[blockIdx.y * nb + blockIdx.x];
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      if (i < n) arr[i] = ex;
+      ex += item[k];
+   }
+}
+
 /* ---- launch helpers ------------------------------------------------------- */
 template <int XF>
 static void launch_scan(seeqdev_scan *s, const void *in, uint32_t *out, size_t cap_items, const uint32_t *n_ptr,
@@ -885,6 +946,17 @@ static void launch_scan(seeqdev_scan *s, const void *in, uint32_t *out, size_t c
    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WG), 0, s->stream, s->scan_ws, n_ptr, add, shift, total_out);
    hipLaunchKernelGGL(k_scan_apply<XF>, dim3(nb), dim3(WG), 0, s->stream, in, out, (const uint32_t *)s->scan_ws,
                       n_ptr, add, shift);
+}
+
+static void launch_scanset(seeqdev_scan *s, uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t n, uint32_t *t0, uint32_t *t1, uint32_t *t2)
+{
+   const unsigned nb = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+   if (nb == 0) return;
+   ScanSet ss = {{a0, a1, a2}, {t0, t1, t2}};
+   const unsigned na = a2 ? 3 : a1 ? 2 : 1;
+   hipLaunchKernelGGL(k_scanset_reduce, dim3(nb, na), dim3(WG), 0, s->stream, ss, s->scan_ws, n, nb);
+   hipLaunchKernelGGL(k_scanset_top, dim3(na), dim3(WG), 0, s->stream, ss, s->scan_ws, nb);
+   hipLaunchKernelGGL(k_scanset_apply, dim3(nb, na), dim3(WG), 0, s->stream, ss, (const uint32_t *)s->scan_ws, n, nb);
 }
 
 /* The tile_cnt scan has a host-known length (ntiles); a dedicated small kernel
@@ -1217,9 +1289,7 @@ static int run_segments(seeqdev_scan *s)
          if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
          hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, s->stream, f, (uint32_t)nslices);
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
-            launch_scan<0>(s, f.tile_hits, f.tile_hits, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
-            launch_scan<0>(s, f.tile_cl, f.tile_cl, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_tmp_hits);
-            if (f.tile_dirty) launch_scan<0>(s, f.tile_dirty, f.tile_dirty, f.ntiles, nullptr, f.ntiles, 0u, &c->seg_dirty_tiles);
+            launch_scanset(s, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
             if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line, s->nh, s->hit_col);
             else hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
          }
