@@ -1321,7 +1321,7 @@ static int run_segments(seeqdev_scan *s)
       if (want != SEEQDEV_WANT_COUNTLINES || superset) {
          /* ---- K3: compaction ---- */
          if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, s->stream, a);
-         hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, s->stream, a);
+         if (!use_fused) hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, s->stream, a);   /* the fused paths: done by k_fused_post */
          const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
          if (grid_hits == 0) grid_hits = 1;
