@@ -120,6 +120,7 @@ struct ScanArgs {
                                    hit list may repeat a line: hit_start = 0xFFFFFFFF marks a repeat) */
    uint32_t       pos_bias;     /* k_stream: seg_base here is the segment's base minus this (multiple of 128) */
    const uint32_t *tile_dirty;  /* k_stream, long-line mode: exclusive prefix of the per-tile "holds a non-alphabet byte" flags */
+   const uint64_t *tile_dmask;  /* ... and per tile one bit per 128-byte chunk */
    uint32_t       stream_ntiles, stream_tile_bytes;
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    Counters      *cnt;
@@ -689,7 +690,7 @@ struct seeqdev_scan {
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
    uint32_t *hit_start, *hit_line, *nh, *hit_col; uint4 *tmp; size_t cap_hitlines;
    /* fused path */
-   uint32_t *tile_cl, *tile_hits, *tile_dirty; size_t cap_ftiles;
+   uint32_t *tile_cl, *tile_hits, *tile_dirty; uint64_t *tile_dmask; size_t cap_ftiles;
    uint32_t *wg_hits;             /* [MAX_FUSED_GRID] */
    uint32_t *wg_part;             /* [3 * MAX_FUSED_GRID] */
    uint32_t *wg_lastnl;           /* [MAX_FUSED_GRID] k_stream: last newline seen by each wave */
@@ -775,7 +776,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
    void *bufs[] = {s->rec_off, s->wg_hits, s->wg_part, s->wg_lastnl, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
-                   s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->tile_dirty, s->d_eqtab,
+                   s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->tile_dirty, s->tile_dmask, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
@@ -803,6 +804,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
       if (ftiles > s->cap_ftiles) {
          if (ws_alloc((void **)&s->tile_cl, ftiles * sizeof(uint32_t))) return -1;
          if (ws_alloc((void **)&s->tile_dirty, ftiles * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->tile_dmask, ftiles * sizeof(uint64_t))) return -1;
          if (ws_alloc((void **)&s->tile_hits, ftiles * sizeof(uint32_t))) return -1;
          s->cap_ftiles = ftiles;
       }
@@ -1252,6 +1254,7 @@ static int run_segments(seeqdev_scan *s)
          f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
          f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = stream_ll ? s->wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
          f.tile_dirty = f.wg_lastnl ? s->tile_dirty : nullptr;
+         f.tile_dmask = f.wg_lastnl ? s->tile_dmask : nullptr;
          { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
          if (use_dfa) {
@@ -1295,7 +1298,7 @@ static int run_segments(seeqdev_scan *s)
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
          a.pos_bias = pos_bias;
-         a.tile_dirty = f.tile_dirty; a.stream_ntiles = f.ntiles; a.stream_tile_bytes = tile_bytes;
+         a.tile_dirty = f.tile_dirty; a.tile_dmask = f.tile_dmask; a.stream_ntiles = f.ntiles; a.stream_tile_bytes = tile_bytes;
          /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
             read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
          a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;

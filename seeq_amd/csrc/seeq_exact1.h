@@ -58,12 +58,31 @@ __device__ __forceinline__ bool exact1_bytes_clean(const uint8_t *text, uint64_t
 {
    uint32_t bad = 0;
    uint64_t p = lo;
+   for (; p + 128 <= hi && !bad; p += 128) {              /* eight independent loads per step: latency, not bytes, is the cost */
+      fused_v4u v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(text + p + 16 * q);
+#pragma unroll
+      for (int q = 0; q < 8; q++) bad |= fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);
+   }
    for (; p + 16 <= hi && !bad; p += 16) {
       const fused_v4u v = *reinterpret_cast<const fused_v4u_unaligned *>(text + p);
       bad = fused_bad4(v.x) | fused_bad4(v.y) | fused_bad4(v.z) | fused_bad4(v.w);
    }
    for (; p < hi && !bad; p++) bad = fused_bad4(0x0A0A0A00u | text[p]);
    return bad == 0;
+}
+
+/* text[x, y) inside ONE tile (base tb): whole 128-byte chunks by the tile's chunk mask, the partial chunks by bytes */
+__device__ __forceinline__ bool exact1_clean_in_tile(const ScanArgs &a, uint64_t tb, uint64_t dmask, uint64_t x, uint64_t y)
+{
+   if (y <= x) return true;
+   const uint64_t c_lo = (x - tb + 127) >> 7, c_hi = (y - tb) >> 7;          /* whole chunks [c_lo, c_hi) */
+   if (c_lo >= c_hi) return exact1_bytes_clean(a.text, x, y);
+   const uint64_t below_hi = c_hi >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << c_hi) - 1);
+   const uint64_t below_lo = ((uint64_t)1 << c_lo) - 1;                      /* c_lo < c_hi <= 64 */
+   if (dmask & below_hi & ~below_lo) return false;
+   return exact1_bytes_clean(a.text, x, tb + (c_lo << 7)) && exact1_bytes_clean(a.text, tb + (c_hi << 7), y);
 }
 
 __device__ __forceinline__ bool exact1_clean(const ScanArgs &a, uint64_t lo, uint64_t hi)
@@ -74,10 +93,19 @@ __device__ __forceinline__ bool exact1_clean(const ScanArgs &a, uint64_t lo, uin
    if (!a.tile_dirty || lo < segb) return false;
    const uint64_t TB = a.stream_tile_bytes;
    const uint64_t t_lo = (lo - segb + TB - 1) / TB, t_hi = (hi - segb) / TB;          /* whole tiles [t_lo, t_hi) */
-   if (t_lo >= t_hi) return exact1_bytes_clean(a.text, lo, hi);
+   const uint64_t t_first = (lo - segb) / TB;
+   if (t_lo >= t_hi) {                                    /* no whole tile: one or two partial tiles */
+      if (t_first == t_hi || t_hi >= a.stream_ntiles)
+         return exact1_clean_in_tile(a, segb + t_first * TB, a.tile_dmask[t_first], lo, hi);
+      return exact1_clean_in_tile(a, segb + t_first * TB, a.tile_dmask[t_first], lo, segb + t_hi * TB) &&
+             exact1_clean_in_tile(a, segb + t_hi * TB, a.tile_dmask[t_hi], segb + t_hi * TB, hi);
+   }
    const uint32_t d_hi = t_hi < a.stream_ntiles ? a.tile_dirty[t_hi] : a.cnt->seg_dirty_tiles;
    if (d_hi != a.tile_dirty[t_lo]) return false;
-   return exact1_bytes_clean(a.text, lo, segb + t_lo * TB) && exact1_bytes_clean(a.text, segb + t_hi * TB, hi);
+   if (t_first < t_lo && !exact1_clean_in_tile(a, segb + t_first * TB, a.tile_dmask[t_first], lo, segb + t_lo * TB)) return false;
+   if (t_hi < a.stream_ntiles && hi > segb + t_hi * TB &&
+       !exact1_clean_in_tile(a, segb + t_hi * TB, a.tile_dmask[t_hi], segb + t_hi * TB, hi)) return false;
+   return true;
 }
 
 template <int W> __device__ __forceinline__ void exact1_take(fused_state_t<W> &st, const fused_state_t<W> &s2, bool take);

@@ -61,6 +61,7 @@ struct FusedArgs {
    uint32_t      *wg_hits;     /* per slice (workgroup of k_fused / wave of k_direct): entries stored */
    uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31}               */
    uint32_t      *tile_dirty;  /* k_stream, long-line mode: per tile, 1 when it holds a byte outside the alphabet (then its exclusive prefix); else NULL */
+   uint64_t      *tile_dmask;  /* k_stream, long-line mode: per tile, one bit per 128-byte chunk (lane) that holds a non-alphabet byte */
    uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */
    uint32_t       debug;       /* profiling experiments only (SEEQ_FUSED_DEBUG): 1 = skip the per-line scan */
    const uint16_t *dfa;        /* k_dfa: transition table, dfa_rows x 8 u16 (seeq_dfa.h) */

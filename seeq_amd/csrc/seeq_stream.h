@@ -177,10 +177,11 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 #pragma unroll
          for (int q = 0; q < NQ; q++) bad |= fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);
          /* a byte outside the alphabet anywhere in the tile: the scan's verdicts need verifying */
-         uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(__any(bad != 0) ? 1 : 0);
+         const uint64_t badlanes = __ballot(bad != 0);
+         uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(badlanes != 0 ? 1 : 0);
          asm volatile("" : "+s"(flag));                   /* pinned here: the walk below needs the registers */
          wv_dirty |= flag;
-         if (LL && lane == 0) a.tile_dirty[tile] = flag;
+         if (LL && lane == 0) { a.tile_dirty[tile] = flag; a.tile_dmask[tile] = badlanes; }
       }
       uint32_t hmask[NM], nmask[NM];
       if (ILP2 && CH == 128) {
