@@ -2,13 +2,20 @@
 """bench.py -- headline benchmark of seeq-mi355x (BASELINE.json):
 lines/s and GB/s scanned, 20 bp pattern, d=3, 150 bp synthetic reads, 1 -> 8 MI355X.
 
-A "step" is one pass of the whole hot path (newline index, forward scan,
+A "step" is one pass of the whole hot path (newline handling, automaton / bit-vector scan,
 compaction, exact pass with start recovery, ordered records) over one batch of
-reads that is already resident in HBM.  Default workload = BASELINE configs[2]:
-100 M x 150 bp reads per GPU, --best with positions (records bit-exact vs the
-oracle on a prefix).  Multi-GPU: one process per GPU (torch.distributed over
-RCCL), each rank scans its own contiguous range of read indices (weak scaling,
-no data-path collective); the global counts are all-reduced inside the step.
+reads that is already resident in HBM.  Workloads:
+
+  best  (default) BASELINE configs[2]: 100 M x 150 bp reads per GPU, 20 bp pattern, d=3, --best with positions
+  count           BASELINE configs[1] shape: -c count-only
+  all             the same reads, --all with positions
+  cfg5            BASELINE configs[4]: 100 M x 250 bp reads, 40-position bracketed / N pattern, d=5, --all
+
+Multi-GPU (`--gpus N`): one process per GPU (torch.distributed over RCCL), each rank scans its own contiguous
+range of read indices (weak scaling, no data-path collective); the global counts are all-reduced inside the
+step.  Started without WORLD_SIZE in the environment, `--gpus N` launches the N ranks itself (as a child
+`python -m torch.distributed.run`, before this process has touched the GPU) and relays rank 0's line; under the
+driver's own torch.distributed.run it is a rank.  Every rank checks that N ranks joined the all-reduce.
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,18 +30,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PATTERN = "GATGTAGCGCGATTAGCCTG"      # SURVEY 8d / reference doc/response.tex:181-183
-TAU = 3
-READ_LEN = 150
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+SEG_BYTES_DEFAULT = 0xF0000000        # the library's segment size (one scan-kernel launch)
+
+WORKLOADS = {
+    # name: (pattern, distance, read length, match option, want, description)
+    "best": ("GATGTAGCGCGATTAGCCTG", 3, 150, "best", "records",
+             "BASELINE configs[2]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, --best with positions (ordered hit records)"),
+    "count": ("GATGTAGCGCGATTAGCCTG", 3, 150, "first", "countlines",
+              "BASELINE configs[1]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, -c count-only"),
+    "all": ("GATGTAGCGCGATTAGCCTG", 3, 150, "all", "records",
+            "%d x 150 bp reads per GPU, 20 bp pattern, d=3, --all with positions"),
+    "cfg5": ("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5, 250, "all", "records",
+             "BASELINE configs[4]: %d x 250 bp reads per GPU, 40-position bracketed/IUPAC pattern, d=5, --all matches with positions"),
+}
 
 
-def cpu_baseline(sample_lines, workload):
-    """The reference itself (oracle/_ref/seeq_ref, built from /root/reference in the build
-    container) timed on this box's host cores over a bounded sample of the same workload."""
-    from oracle.pyoracle import Oracle, REF_BIN
+def host_cores():
     import multiprocessing
-    orc = Oracle()
     cores = max(1, multiprocessing.cpu_count() // 2)      # physical cores if SMT-2, else a conservative half
     try:
         out = subprocess.run(["lscpu", "-p=CORE,SOCKET"], capture_output=True, text=True).stdout
@@ -44,17 +57,25 @@ def cpu_baseline(sample_lines, workload):
             cores = len(sock0)
     except Exception:
         pass
-    cores = min(cores, multiprocessing.cpu_count())
+    return min(cores, multiprocessing.cpu_count())
+
+
+def cpu_baseline(sample_lines, pattern, tau, read_len, mode):
+    """The reference itself (oracle/_ref/seeq_ref, built from /root/reference in the build
+    container) timed on this box's host cores over a bounded sample of the same workload."""
+    from oracle.pyoracle import Oracle, REF_BIN
     from seeq_amd.device import plain_pattern
-    data = orc.synth_reads(0, sample_lines, READ_LEN, plain_pattern(PATTERN), TAU)
+    orc = Oracle()
+    cores = host_cores()
+    data = orc.synth_reads(0, sample_lines, read_len, plain_pattern(pattern), tau)
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(tmpdir, "seeq_bench_sample_%d.txt" % os.getpid())
     data.tofile(path)
+    flags = {"first": ["-c"], "best": ["-b", "-f"], "all": ["-a", "-f"]}[mode]
     try:
         if os.path.exists(REF_BIN):
             kind = "reference"
-            args = ["-c"] if workload == "count" else ["-b", "-f"]
-            cmd = [REF_BIN, "-d", str(TAU)] + args + [PATTERN, path]
+            cmd = [REF_BIN, "-d", str(tau)] + flags + [pattern, path]
 
             def run_parallel(p):
                 t0 = time.perf_counter()
@@ -71,15 +92,15 @@ def cpu_baseline(sample_lines, workload):
             kind = "port"
             cores = 1
             t0 = time.perf_counter()
-            orc.buffer_scan(PATTERN, TAU, data, 1)
+            orc.buffer_scan(pattern, tau, data, 1)
             one = agg = sample_lines / (time.perf_counter() - t0)
     finally:
         os.unlink(path)
     return {"value": agg, "unit": "lines/s", "cores": cores, "kind": kind,
             "one_core_lines_per_s": one,
             "sample": "%d synthetic %d bp reads (same generator/seed as the GPU run), %s, "
-                      "%d concurrent single-threaded processes" % (sample_lines, READ_LEN, " ".join(
-                          ["seeq", "-d", str(TAU)] + (["-c"] if workload == "count" else ["-b", "-f"])), cores)}
+                      "%d concurrent single-threaded processes" % (sample_lines, read_len, " ".join(
+                          ["seeq", "-d", str(tau)] + flags), cores)}
 
 
 def seeq_scan_host_ptr(scanner, pat, host_ptr, nbytes, opt, want):
@@ -92,24 +113,214 @@ def seeq_scan_host_ptr(scanner, pat, host_ptr, nbytes, opt, want):
     return dict(nlines=cnt.nlines, nmatchlines=cnt.nmatchlines, nhits=cnt.nhits, nrecords=cnt.nrecords)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Full-size parity: blocks of the scanned text against the oracle (outside the timed region)
+# ---------------------------------------------------------------------------------------------------------------
+def parity_blocks(n, read_len, seg_bytes, prefix_lines, block_lines=65536, every=97, seam_lines=2048):
+    """[first, count) line ranges to verify: a prefix, every `every`-th block of `block_lines`, and the lines
+    around every segment seam (a line there is split between two scan-kernel launches)."""
+    prefix = min(n, prefix_lines)
+    out = [(f, min(block_lines, prefix - f)) for f in range(0, prefix, block_lines)]      # the prefix, cut for the pool
+    nblocks = (n + block_lines - 1) // block_lines
+    for b in range(every, nblocks, every):
+        first = b * block_lines
+        if first >= prefix:
+            out.append((first, min(block_lines, n - first)))
+    seams = []
+    k = 1
+    while k * seg_bytes < n * (read_len + 1):
+        line = (k * seg_bytes) // (read_len + 1)
+        first = max(0, line - seam_lines // 2)
+        seams.append((first, min(seam_lines, n - first)))
+        k += 1
+    return out, seams
+
+
+_CHECK_CHILD = r'''
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle.pyoracle import Oracle
+o = Oracle()
+job = json.load(open(sys.argv[1]))
+res = []
+for blk in job["blocks"]:
+    data = np.fromfile(blk["file"], dtype=np.uint8)
+    exp = o.buffer_scan(job["pattern"], job["tau"], data, job["opt"])
+    np.save(blk["file"] + ".rec.npy", exp["records"])
+    res.append({"nlines": int(exp["nlines"]), "nmatchlines": int(exp["nmatchlines"])})
+json.dump(res, open(sys.argv[1] + ".out", "w"))
+'''
+
+
+def oracle_check(text, ranges, read_len, pattern, tau, opt, want_records, rec, scan_block, procs):
+    """Run the oracle over the given line ranges of the device text in `procs` child processes (the text of each
+    range is copied from HBM to /dev/shm) and compare: records (line, start, end, dist) bit for bit, and per range
+    the number of lines / matching lines.  `rec`: all GPU records of this rank (or None for count workloads, then
+    `scan_block(first, count)` rescans the range on the GPU).  Returns (lines checked, ranges checked)."""
+    import numpy as np
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    base = os.path.join(tmpdir, "seeq_bench_chk_%d" % os.getpid())
+    L = read_len + 1
+    jobs = [[] for _ in range(max(1, procs))]
+    files = []
+    order = sorted(range(len(ranges)), key=lambda i: -ranges[i][1])          # longest first, round robin
+    for j, i in enumerate(order):
+        first, count = ranges[i]
+        path = "%s_%d.bin" % (base, i)
+        text[first * L:(first + count) * L].cpu().numpy().tofile(path)
+        files.append(path)
+        jobs[j % len(jobs)].append({"idx": i, "file": path})
+    children = []
+    try:
+        for k, blocks in enumerate(jobs):
+            if not blocks:
+                continue
+            jp = "%s_job%d.json" % (base, k)
+            json.dump({"pattern": pattern, "tau": tau, "opt": opt, "blocks": blocks}, open(jp, "w"))
+            files += [jp, jp + ".out"]
+            children.append((subprocess.Popen([sys.executable, "-c", _CHECK_CHILD % ROOT, jp]), jp, blocks))
+        lines_checked = 0
+        for proc, jp, blocks in children:
+            assert proc.wait() == 0, "oracle child failed"
+            res = json.load(open(jp + ".out"))
+            for blk, r in zip(blocks, res):
+                first, count = ranges[blk["idx"]]
+                exp_rec = np.load(blk["file"] + ".rec.npy")
+                files.append(blk["file"] + ".rec.npy")
+                assert r["nlines"] == count, ("line count", first, count, r)
+                if want_records:
+                    lo = np.searchsorted(rec[:, 0], first + 1, side="left")
+                    hi = np.searchsorted(rec[:, 0], first + count, side="right")
+                    got = rec[lo:hi].astype(np.uint64)
+                    got[:, 0] -= first
+                    assert np.array_equal(got, exp_rec), "GPU records differ from the oracle in lines [%d, %d)" % (first, first + count)
+                    assert len(np.unique(got[:, 0])) == r["nmatchlines"], ("matching lines", first, count)
+                else:
+                    c = scan_block(first, count)
+                    assert c["nlines"] == count and c["nmatchlines"] == r["nmatchlines"], \
+                        "GPU counts differ from the oracle in lines [%d, %d): %r vs %r" % (first, first + count, c, r)
+                lines_checked += count
+        return lines_checked, len(ranges)
+    finally:
+        for f in files:
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+
+
+def per_call_rates(pattern, tau, read_len, nstrings=20000):
+    """strings/s through the per-string entry point seeqStringMatch (what the reference's Python module calls,
+    seeqmodule.c:858) and through the batched module calls, next to the reference's own per-call rate."""
+    import ctypes as C
+    import numpy as np
+    import seeq_amd as seeq
+    from oracle.pyoracle import Oracle, REF_LIB
+    from seeq_amd import _capi
+    from seeq_amd.device import plain_pattern
+    orc = Oracle()
+    data = orc.synth_reads(0, nstrings, read_len, plain_pattern(pattern), tau).tobytes()
+    strings = data.split(b"\n")[:nstrings]
+    out = {"strings": nstrings, "string_len": read_len}
+    L = _capi.lib()
+    sq = L.seeqNew(pattern.encode(), tau, 0)
+    for s in strings[:50]:
+        L.seeqStringMatch(s, sq, 1)
+    t0 = time.perf_counter()
+    nh = 0
+    k = min(len(strings), 4000)
+    for s in strings[:k]:
+        nh += L.seeqStringMatch(s, sq, 1) > 0
+    dt = time.perf_counter() - t0
+    out["seeqStringMatch"] = {"strings_per_s": k / dt, "us_per_call": 1e6 * dt / k, "matched": int(nh), "calls": k}
+    L.seeqFree(sq)
+    m = seeq.compile(pattern, tau)
+    texts = [s.decode() for s in strings]
+    m.matchBestBatch(texts[:100])
+    t0 = time.perf_counter()
+    res = m.matchBestBatch(texts)
+    dt = time.perf_counter() - t0
+    out["matchBestBatch"] = {"strings_per_s": len(texts) / dt, "matched": sum(1 for r in res if r)}
+    if os.path.exists(REF_LIB):
+        R = C.CDLL(REF_LIB)
+        R.seeqNew.restype = C.c_void_p
+        R.seeqNew.argtypes = [C.c_char_p, C.c_int, C.c_size_t]
+        R.seeqStringMatch.restype = C.c_long
+        R.seeqStringMatch.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+        R.seeqFree.argtypes = [C.c_void_p]
+        rsq = R.seeqNew(pattern.encode(), tau, 0)
+        for s in strings[:1000]:
+            R.seeqStringMatch(s, rsq, 1)
+        t0 = time.perf_counter()
+        nr = 0
+        for s in strings:
+            nr += R.seeqStringMatch(s, rsq, 1) > 0
+        dt = time.perf_counter() - t0
+        out["reference_seeqStringMatch"] = {"strings_per_s": len(strings) / dt, "matched": int(nr),
+                                            "note": "reference libseeq through ctypes, one host core (ctypes call overhead included on both sides)"}
+        R.seeqFree(rsq)
+    return out
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start N ranks (one per GPU) as a child torch.distributed.run BEFORE this process
+    touches the GPU, relay rank 0's JSON line, exit with the child's status."""
+    import socket
+    import torch
+    share = os.environ.get("SEEQ_BENCH_SHARE_GPU") == "1"       # test mode: all ranks on GPU 0, gloo collectives
+    ndev = torch.cuda.device_count()                            # does not initialise the GPU on this image
+    if not share and ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, ndev))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in proc.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank launch failed (exit %d)\n%s\n" % (args.gpus, proc.returncode, proc.stdout[-2000:]))
+        return proc.returncode or 1
+    if json.loads(line)["n_gpus"] != args.gpus:
+        sys.stderr.write("bench.py: asked for %d ranks, the line reports %d\n" % (args.gpus, json.loads(line)["n_gpus"]))
+        return 1
+    print(line)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
-    ap.add_argument("--workload", choices=["best", "count", "all"], default="best",
-                    help="best = configs[2] (--best, positions); count = configs[1] (-c)")
-    ap.add_argument("--pattern", default=globals()["PATTERN"], help="non-default patterns are for experiments (config names them)")
-    ap.add_argument("--distance", type=int, default=globals()["TAU"])
-    ap.add_argument("--read-len", type=int, default=globals()["READ_LEN"])
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="best")
+    ap.add_argument("--pattern", default=None, help="non-default patterns are for experiments (config names them)")
+    ap.add_argument("--distance", type=int, default=None)
+    ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-memory end-to-end measurement")
+    ap.add_argument("--no-per-call", action="store_true", help="skip the seeqStringMatch per-call measurement")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
-    ap.add_argument("--check-lines", type=int, default=200_000, help="prefix verified against the oracle")
+    ap.add_argument("--check-lines", type=int, default=1_000_000,
+                    help="prefix verified against the oracle (plus every 97th 64 Ki-line block and the segment seams); 0 = no check")
     args = ap.parse_args()
-    PATTERN, TAU, READ_LEN = args.pattern, args.distance, args.read_len
-    globals().update(PATTERN=PATTERN, TAU=TAU, READ_LEN=READ_LEN)      # cpu_baseline() reads the module globals
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+
+    wl = WORKLOADS[args.workload]
+    PATTERN = args.pattern or wl[0]
+    TAU = wl[1] if args.distance is None else args.distance
+    READ_LEN = args.read_len or wl[2]
+    mode, want_name = wl[3], wl[4]
 
     import numpy as np
     import torch
@@ -120,12 +331,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
+    share = os.environ.get("SEEQ_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)     # RCCL
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)     # RCCL
+        # every rank must have joined: a sum of ones over the collective the step uses
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if share else device)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        if int(ones.item()) != args.gpus:
+            sys.stderr.write("bench.py: %d ranks joined the all-reduce, expected %d\n" % (int(ones.item()), args.gpus))
+            sys.exit(3)
+    red_device = "cpu" if (share and world > 1) else device
 
     n = args.reads
     first = rank * n                                           # this rank's read-index range (weak scaling)
@@ -135,19 +360,20 @@ def main():
     dev.synth_reads(text.data_ptr(), first, n, READ_LEN, dev.plain_pattern(PATTERN), TAU, stream=stream)
     torch.cuda.synchronize()
 
-    opt, want = {"best": (dev.SQ_BEST, dev.WANT_RECORDS), "count": (0, dev.WANT_COUNTLINES),
-                 "all": (dev.SQ_ALL, dev.WANT_RECORDS)}[args.workload]
+    opt = {"best": dev.SQ_BEST, "first": 0, "all": dev.SQ_ALL}[mode]
+    want = dev.WANT_RECORDS if want_name == "records" else dev.WANT_COUNTLINES
     pat = dev.Pattern(PATTERN, TAU)
     sc = dev.Scanner(stream)
-    seg = int(os.environ.get("SEEQ_SEGMENT_BYTES", str(0xF0000000)))      # the library's default segment size
+    seg = int(os.environ.get("SEEQ_SEGMENT_BYTES", str(SEG_BYTES_DEFAULT)))
     seg_lines = min(n, seg // (READ_LEN + 1) + 2)
-    sc.reserve(nbytes, seg_lines + 64, seg_lines // 8 + 1024, n // 8 + 1024)
+    rec_cap = n // 8 + 1024 if mode != "all" else n // 4 + 1024
+    sc.reserve(nbytes, seg_lines + 64, max(seg_lines // 6 + 1024, 8192 * 64), rec_cap)
     sc.set_profiling(True)
 
     def step():
         sc.run(pat, text.data_ptr(), nbytes, opt, want)
         cnt = sc.fetch()
-        return shard.reduce_counts(cnt, device=device), cnt
+        return shard.reduce_counts(cnt, device=red_device), cnt
 
     for _ in range(args.warmup):
         step()
@@ -170,45 +396,53 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # parity spot check (rank 0): prefix of the records against the oracle
+    # ---- parity (rank 0, outside the timed region): prefix + every 97th block + segment seams vs the oracle ----
     check = None
     if rank == 0 and args.check_lines > 0:
-        from oracle.pyoracle import Oracle
-        k = min(args.check_lines, n)
-        host = text[:k * (READ_LEN + 1)].cpu().numpy()
-        exp = Oracle().buffer_scan(PATTERN, TAU, host, opt)
-        if want == dev.WANT_RECORDS:
-            rec = sc.records(local["nrecords"])
-            got = rec[rec[:, 0] <= k].astype(np.uint64)
-            check = bool(np.array_equal(got, exp["records"]))
-        else:
-            c2 = dev.Scanner(stream).scan_tensor(pat, text[:k * (READ_LEN + 1)], opt, want)
-            check = c2["nmatchlines"] == exp["nmatchlines"]
-        assert check, "GPU results differ from the oracle"
+        blocks, seams = parity_blocks(n, READ_LEN, seg, args.check_lines)
+        ranges = blocks + seams
+        rec = sc.records(local["nrecords"]) if want == dev.WANT_RECORDS else None
+        sc_chk = dev.Scanner(stream) if rec is None else None
+
+        def scan_block(f0, cnt_):
+            return sc_chk.scan_tensor(pat, text[f0 * (READ_LEN + 1):(f0 + cnt_) * (READ_LEN + 1)], opt, want)
+        tchk = time.perf_counter()
+        lines_checked, nranges = oracle_check(text, ranges, READ_LEN, PATTERN, TAU, opt, rec is not None, rec, scan_block,
+                                              procs=min(32, max(1, (os.cpu_count() or 2) - 1)))
+        if rec is not None:       # size-independent properties of the whole record list
+            assert np.all(np.diff(rec[:, 0].astype(np.int64)) >= (0 if mode == "all" else 1)), "records not ordered by line"
+            assert np.all(rec[:, 1] <= rec[:, 2]) and np.all(rec[:, 2] <= READ_LEN) and np.all(rec[:, 3] <= TAU)
+            assert len(np.unique(rec[:, 0])) == local["nmatchlines"]
+        check = {"oracle_lines_checked": lines_checked, "ranges": nranges, "segment_seams_checked": len(seams),
+                 "seconds": time.perf_counter() - tchk, "result": "bit-exact"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         lines_total = total["nlines"]
+        assert lines_total == n * world, (lines_total, n, world)
         value = lines_total / (elapsed / args.steps)
         gbs = value * (READ_LEN + 1) / 1e9
-        # roofline of the dominant kernel (k_forward): algorithmic bytes per launch / mean launch time
+        # roofline of the dominant kernel (the scan kernel): algorithmic bytes per launch / mean launch time
         launches_per_step = fwd_launches / args.steps
         algo_bytes_launch = (n * (READ_LEN + 1) + 16 * local["nrecords"]) / launches_per_step + 8
         fwd_avg_ms = fwd_ms / max(1, fwd_launches)
         achieved = algo_bytes_launch / (fwd_avg_ms * 1e-3) / 1e9
         traffic = None
         kern = sc.last_kernel()
+        filt = sc.last_filter()
         pmc = os.path.join(ROOT, "profiles", "pmc_scan_kernels.json")
+        traffic_src = None
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc)).get(kern)
                 # HBM bytes per text byte measured with rocprofv3 PMC passes (profiles/), scaled to this launch size
                 if pj:
                     traffic = pj["hbm_bytes_per_text_byte"] * (n * (READ_LEN + 1) / launches_per_step)
+                    traffic_src = "profiles/pmc_scan_kernels.json (rocprofv3 --pmc passes of this kernel; ratio x this launch's text bytes)"
             except Exception:
                 traffic = None
         notes = {
@@ -218,26 +452,27 @@ def main():
                         "on re-reading lines from L2: see DESIGN.md",
         }
         out = {
-            "metric": "lines/s scanned (20 bp pattern, d=3, 150 bp reads; GB/s in gb_per_s)",
+            "metric": "lines/s scanned (20 bp pattern, d=3, 150 bp reads; GB/s in gb_per_s)" if args.workload != "cfg5" else
+                      "lines/s scanned (40-position class/N pattern, d=5, 250 bp reads, --all; GB/s in gb_per_s)",
             "value": value, "unit": "lines/s", "gb_per_s": gbs,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16" if kern == "k_stream" else "u32", "data": "synthetic",
-            "config": {"workload": {"best": "BASELINE configs[2]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, "
-                                            "--best with positions (ordered hit records)" % n,
-                                    "count": "BASELINE configs[1]: %d x 150 bp reads per GPU, 20 bp pattern, d=3, "
-                                             "-c count-only" % n,
-                                    "all": "%d x 150 bp reads per GPU, 20 bp pattern, d=3, --all" % n}[args.workload],
+            "dtype": "int (u16 automaton state ids; exact-pass columns u32 bit-vectors)" if kern == "k_stream" else "u32 bit-vectors",
+            "data": "synthetic",
+            "config": {"workload": wl[5] % n,
                        "pattern": PATTERN, "distance": TAU, "read_len": READ_LEN, "reads_per_gpu": n,
                        "parallelism": "line-sharded x%d, RCCL count all-reduce" % world},
             "results": {"lines": lines_total, "matching_lines": total["nmatchlines"], "hits": total["nhits"],
-                        "oracle_prefix_check": check},
+                        "oracle_check": check, "oracle_lines_checked": check["oracle_lines_checked"] if check else 0},
             "device_ms_per_step": {"newline_index": idx_ms / args.steps, "forward_scan": fwd_ms / args.steps,
                                    "compaction_exact_records": ex_ms / args.steps},
-            "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": kern + (" (partition filter automaton)" if filt else ""),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": launches_per_step, "avg_launch_ms": fwd_avg_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "whole_step_frac": (n * (READ_LEN + 1) + 16 * local["nrecords"] + 8 * launches_per_step)
+                         / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
                          "note": notes.get(kern, "see DESIGN.md")},
         }
         if world == 1 and not args.no_e2e:
@@ -246,7 +481,6 @@ def main():
             ne = min(n, 10_000_000)
             hostbuf = text[:ne * (READ_LEN + 1)].cpu().pin_memory()
             sc2 = dev.Scanner()
-            import ctypes
             best = None
             for _ in range(3):
                 t1 = time.perf_counter()
@@ -258,8 +492,11 @@ def main():
             out["end_to_end_pinned_host"] = {"lines": ne, "seconds": best, "lines_per_s": ne / best,
                                              "gb_per_s": ne * (READ_LEN + 1) / best / 1e9,
                                              "note": "H2D over PCIe + scan + D2H records; best of 3"}
+        if world == 1 and not args.no_per_call:
+            out["per_call"] = per_call_rates(PATTERN, TAU, READ_LEN)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.workload)
+            sample = args.cpu_sample if args.workload != "cfg5" else max(200_000, args.cpu_sample // 4)
+            out["cpu_baseline"] = cpu_baseline(sample, PATTERN, TAU, READ_LEN, mode)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

@@ -93,11 +93,14 @@ int seeqdevScanReserve(seeqdev_scan_t * scan, size_t max_bytes, size_t max_lines
  * tiles of the fused kernel.  0 (default) = estimate it from a 64 KiB sample of each new buffer. */
 int seeqdevScanSetLineHint(seeqdev_scan_t * scan, double avg_bytes_per_line);
 /* Which device path served the last run: 1 = generic (newline index + k_forward<W>),
- * 2 = fused, text tiles in LDS (k_fused), 3 = fused, text in registers (k_direct), 4 = fused,
- * table-driven per line (k_dfa: the pattern's complete Levenshtein automaton in LDS; SQ_FAIL only),
- * 5 = fused, table-driven and line-agnostic (k_stream: every lane walks a fixed chunk of the text).
- * The fused kernels serve patterns <= 62 positions on read-length lines in ONE pass over the text. */
+ * 3 = one-pass per-line bit-vector kernel, text in registers (k_direct),
+ * 5 = one-pass table-driven line-agnostic kernel (k_stream: every lane walks a fixed chunk of the text
+ *     through the pattern's Levenshtein automaton held in LDS).
+ * The one-pass kernels serve patterns <= 62 positions in ONE pass over the text. */
 int seeqdevScanLastPath(const seeqdev_scan_t * scan);
+/* 1 when the last run's k_stream walked a partition FILTER automaton (candidates verified by the exact pass)
+ * instead of the pattern's complete automaton. */
+int seeqdevScanLastFilter(const seeqdev_scan_t * scan);
 
 /* Enqueue (asynchronously, on the context's stream) the whole hot path over
  * d_text[0..nbytes): newline index -> per-line forward scan -> hit-line

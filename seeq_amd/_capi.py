@@ -60,7 +60,8 @@ EXPORTS = [
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
-    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanCopyOffsets", "seeqdevHostAlloc", "seeqdevHostFree",
+    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
+    "seeqdevHostFree",
 ]
 
 
@@ -166,6 +167,12 @@ def lib():
     L.seeqdevScanSetLineHint.restype = C.c_int
     L.seeqdevScanLastPath.argtypes = [C.c_void_p]
     L.seeqdevScanLastPath.restype = C.c_int
+    L.seeqdevScanLastFilter.argtypes = [C.c_void_p]
+    L.seeqdevScanLastFilter.restype = C.c_int
+    L.seeqdevHostAlloc.argtypes = [C.c_size_t]
+    L.seeqdevHostAlloc.restype = C.c_void_p
+    L.seeqdevHostFree.argtypes = [C.c_void_p]
+    L.seeqdevHostFree.restype = None
     L.seeqdevSynthReads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                     C.c_uint64, C.c_void_p]
     L.seeqdevSynthReads.restype = C.c_int

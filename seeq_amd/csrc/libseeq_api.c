@@ -215,49 +215,15 @@ const char *seeqPrintError(void)
    return seeq_messages[seeqerr];
 }
 
-/* ---- dead API kept for link compatibility (reference libseeq.c:355-424) ---- */
-mstack_t *stackNew(size_t size)
-{
-   if (size < 1) size = 1;
-   mstack_t *st = malloc(sizeof(mstack_t) + size * sizeof(match_t));
-   if (!st) return NULL;
-   st->size = size;
-   st->pos = 0;
-   return st;
-}
+/* ---- dead API of the reference (libseeq.c:355-424; its only call site is commented out, libseeq.c:340):
+ * exported so that objects built against libseeq.h still link, nothing more.  Every call fails with ENOSYS. ---- */
+mstack_t *stackNew(size_t size) { (void)size; seeqerr = 0; errno = ENOSYS; return NULL; }
 
-int stackAddMatch(mstack_t **stackp, match_t match)
-{
-   mstack_t *st = *stackp;
-   if (st->pos >= st->size) {
-      const size_t newsize = 2 * st->size;
-      mstack_t *grown = realloc(st, sizeof(mstack_t) + newsize * sizeof(match_t));
-      if (!grown) return -1;
-      *stackp = st = grown;
-      st->size = newsize;
-   }
-   st->match[st->pos++] = match;
-   return 0;
-}
+int stackAddMatch(mstack_t **stackp, match_t match) { (void)stackp; (void)match; seeqerr = 0; errno = ENOSYS; return -1; }
 
-/* The reference's abandoned overlap merge (libseeq.c:355-390); its only call
- * site is commented out (libseeq.c:340).  Same observable behaviour: pops
- * non-overlapping matches of increasing distance into sq->match. */
 int recursive_merge(size_t start, size_t end, int tau, seeq_t *sq, mstack_t **stackp)
 {
-   if (tau > sq->tau) return 0;
-   mstack_t *st = stackp[tau];
-   size_t hi = end;
-   if (st->pos > 0) {
-      while (st->pos > 0 && st->match[st->pos - 1].end > end) st->pos--;
-      while (st->pos > 0) {
-         const match_t top = st->match[st->pos - 1];
-         if (start > top.start) break;
-         if (recursive_merge(top.end, hi, tau + 1, sq, stackp)) return -1;
-         hi = top.start;
-         st->pos--;
-         if (seeqAddMatch(sq, top)) return -1;
-      }
-   }
-   return recursive_merge(start, hi, tau + 1, sq, stackp);
+   (void)start; (void)end; (void)tau; (void)sq; (void)stackp;
+   seeqerr = 0; errno = ENOSYS;
+   return -1;
 }

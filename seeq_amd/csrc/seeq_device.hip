@@ -116,21 +116,22 @@ struct ScanArgs {
    seeqdev_hit_t *records;      uint64_t cap_records;
    uint64_t      *rec_off;      /* per record: byte offset (in the whole buffer) of the line it belongs to */
    uint32_t       use_nh;       /* record slots / line verdicts come from the per-line counts nh[]: 1 = ALL, COUNTMATCH;
-                                   2 = superset filter (k_dfa); 3 = k_stream (superset only when Counters.dirty,
+                                   3 = k_stream (superset only when Counters.dirty or `filter`,
                                    hit list may repeat a line: hit_start = 0xFFFFFFFF marks a repeat) */
    uint32_t       pos_bias;     /* k_stream: seg_base here is the segment's base minus this (multiple of 128) */
    const uint32_t *tile_dirty;  /* k_stream, long-line mode: exclusive prefix of the per-tile "holds a non-alphabet byte" flags */
    const uint64_t *tile_dmask;  /* ... and per tile one bit per 128-byte chunk */
    uint32_t       stream_ntiles, stream_tile_bytes;
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
+   uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
+   uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: max(32, m + tau - 1) */
    Counters      *cnt;
 };
 
 static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
-static constexpr size_t FUSED_MIN_TILE = 2048;   /* smallest text tile of k_fused */
-static constexpr int FUSED_NW_DEFAULT = 4;        /* waves per k_fused workgroup (SEEQ_FUSED_NW=1|2|4) */
-static constexpr size_t MAX_FUSED_GRID = 16384;   /* upper bound of the persistent k_fused grid */
+static constexpr size_t FUSED_MIN_TILE = 512;    /* smallest text tile / region of the one-pass kernels */
+static constexpr size_t MAX_FUSED_GRID = 16384;   /* upper bound of the waves (= hit slices) of a persistent scan grid */
 static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate the line length */
 
 /* ========================================================================== */
@@ -532,10 +533,9 @@ __global__ void k_single_line(ScanArgs a)
    a.line_start[0] = 0;
 }
 
-#include "seeq_fused.h"
+#include "seeq_scan_common.h"
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
-#include "seeq_dfa_kernel.h"
 #include "seeq_stream.h"
 extern "C" {
 #include "seeq_dfa.h"
@@ -616,17 +616,21 @@ extern "C" int seeqdevSynthReads(void *d_out, uint64_t first, uint64_t n, int le
 /* ========================================================================== */
 /* Pattern handle                                                             */
 /* ========================================================================== */
+static unsigned long g_pattern_ids = 0;    /* one per seeqdevPatternNew: cache key (a freed pattern's address can come back) */
+
 struct seeqdev_pattern {
+   unsigned long id;
    int       wlen, tau, words;
    int       device;
    uint32_t *d_peq;          /* [2][5][words] */
    char     *keys;           /* host copy of the key bytes (DFA construction) */
-   int       dfa_state;      /* 0 not tried, 1 built, -1 too large */
-   uint16_t *d_dfa;          /* transition table in HBM (seeq_dfa.h), staged into LDS by k_dfa */
-   uint32_t  dfa_rows, dfa_final_base;
-   int       sdfa_state;     /* the streaming automaton of k_stream (seeq_dfa_build_stream), same states */
-   uint16_t *d_sdfa;
+   uint32_t *h_peq;          /* host copy of d_peq */
+   int       sdfa_state;     /* the streaming automaton of k_stream (seeq_dfa.h): 0 not tried, 1 built, -1 none fits */
+   uint16_t *d_sdfa;         /* transition table in HBM, staged into LDS by k_stream */
    uint32_t  sdfa_rows, sdfa_final_base;
+   int       sdfa_parts;     /* 1: the complete automaton (exact verdicts); > 1: partition filter (candidates) */
+   int       sdfa_warm;      /* bytes of warm-up a chunk walk needs */
+   double    sdfa_pacc;      /* filter: probability that a random DNA character completes a candidate */
 };
 
 extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int tau)
@@ -645,23 +649,27 @@ extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int 
    }
    seeqdev_pattern *p = (seeqdev_pattern *)calloc(1, sizeof *p);
    if (!p) return NULL;
+   p->id = __atomic_add_fetch(&g_pattern_ids, 1ul, __ATOMIC_RELAXED);
    p->wlen = wlen; p->tau = tau; p->words = seeq_words_for(wlen);
    p->keys = (char *)malloc((size_t)wlen);
    if (p->keys) memcpy(p->keys, keys, (size_t)wlen);
    const size_t nw = (size_t)10 * p->words;
    uint32_t *h = (uint32_t *)malloc(nw * sizeof(uint32_t));
    char *rkeys = (char *)malloc((size_t)wlen);
-   if (!h || !rkeys) { free(h); free(rkeys); free(p); errno = ENOMEM; return NULL; }
+   if (!h || !rkeys || !p->keys) { free(h); free(rkeys); free(p->keys); free(p); errno = ENOMEM; return NULL; }
    for (int i = 0; i < wlen; i++) rkeys[i] = keys[wlen - 1 - i];     /* reference libseeq.c:89 */
    seeq_build_peq(keys, wlen, p->words, h);
    seeq_build_peq(rkeys, wlen, p->words, h + 5 * p->words);
    hipError_t e = hipGetDevice(&p->device);
    if (e == hipSuccess) e = hipMalloc((void **)&p->d_peq, nw * sizeof(uint32_t));
    if (e == hipSuccess) e = hipMemcpy(p->d_peq, h, nw * sizeof(uint32_t), hipMemcpyHostToDevice);
-   free(h); free(rkeys);
+   free(rkeys);
+   p->h_peq = h;
    if (e != hipSuccess) {
       hip_fail(e, "seeqdevPatternNew", e == hipErrorOutOfMemory ? ENOMEM : EIO);
       if (p->d_peq) (void)hipFree(p->d_peq);
+      free(p->keys);
+      free(h);
       free(p);
       return NULL;
    }
@@ -672,18 +680,35 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
 {
    if (!p) return;
    if (p->d_peq) (void)hipFree(p->d_peq);
-   if (p->d_dfa) (void)hipFree(p->d_dfa);
    if (p->d_sdfa) (void)hipFree(p->d_sdfa);
    free(p->keys);
+   free(p->h_peq);
    free(p);
 }
 
 /* ========================================================================== */
 /* Scan context                                                               */
 /* ========================================================================== */
+/* Experiment / test knobs, read from the environment ONCE per scan context (seeqdevScanNew). */
+struct ScanKnobs {
+   int  kernel;          /* SEEQ_FUSED_KERNEL: 0 auto, 1 "stream", 2 "direct" */
+   int  stream_ch;       /* SEEQ_STREAM_CH: 128 (default) or 64 */
+   bool stream_ilp1;     /* SEEQ_STREAM_ILP=1: one walk per lane */
+   int  wgs_per_cu;      /* SEEQ_DFA_WGS: cap on k_stream workgroups per CU (0 = occupancy) */
+   int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
+   bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
+   bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
+};
+
+struct OccMemo { const void *fn; size_t lds; int per_cu; };
+
 struct seeqdev_scan {
    hipStream_t stream;
    bool        own_stream;
+   int         ncu;               /* compute units of the device (cached) */
+   ScanKnobs   knobs;
+   OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
+   bool        last_filter;       /* the last run walked a partition filter automaton */
    /* workspace (device) */
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
@@ -695,7 +720,7 @@ struct seeqdev_scan {
    uint32_t *wg_part;             /* [3 * MAX_FUSED_GRID] */
    uint32_t *wg_lastnl;           /* [MAX_FUSED_GRID] k_stream: last newline seen by each wave */
    uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
-   const seeqdev_pattern *eq_pat; int eq_options;
+   unsigned long eq_pat_id; int eq_options;   /* what d_eqtab holds (pattern generation id, option bits) */
    double avg_line;               /* average bytes per line incl. newline (hint or sampled) */
    double line_hint;              /* caller's hint; 0 = sample the buffer */
    uint8_t *h_sample;             /* pinned, SAMPLE_BYTES */
@@ -750,7 +775,12 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    if (s->seg_bytes > 0xFFFF0000ull) s->seg_bytes = 0xFFFF0000ull;
    hipError_t e = hipSuccess;
    if (hip_stream) s->stream = (hipStream_t)hip_stream;
-   else { e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking); s->own_stream = true; }
+   else {
+      /* a private stream of the default ("blocking") kind: work a caller queued on the legacy null stream -- torch's
+         default stream has handle 0, which arrives here as NULL -- is ordered before ours and ours before theirs */
+      e = hipStreamCreateWithFlags(&s->stream, hipStreamDefault);
+      s->own_stream = true;
+   }
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cnt, sizeof(Counters));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_cnt, sizeof(Counters), hipHostMallocDefault);
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 1024 * sizeof(uint32_t), hipHostMallocDefault);
@@ -762,6 +792,20 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    {
       const char *pe = getenv("SEEQ_PATH");
       s->force_path = pe ? (!strcmp(pe, "generic") ? 1 : !strcmp(pe, "fused") ? 2 : 0) : 0;
+      ScanKnobs &kn = s->knobs;
+      const char *v;
+      v = getenv("SEEQ_FUSED_KERNEL"); kn.kernel = v ? (!strcmp(v, "stream") ? 1 : !strcmp(v, "direct") ? 2 : 0) : 0;
+      v = getenv("SEEQ_STREAM_CH");    kn.stream_ch = v && atoi(v) == 64 ? 64 : 128;
+      v = getenv("SEEQ_STREAM_ILP");   kn.stream_ilp1 = v && atoi(v) == 1;
+      v = getenv("SEEQ_DFA_WGS");      kn.wgs_per_cu = v ? atoi(v) : 0;
+      v = getenv("SEEQ_TILE_BYTES");   kn.tile_bytes = v ? atoi(v) : 0;
+      v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
+      v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
+      s->ncu = 256;
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+         s->ncu = prop.multiProcessorCount;
    }
    if (e != hipSuccess) {
       hip_fail(e, "seeqdevScanNew", EIO);
@@ -862,6 +906,7 @@ extern "C" int seeqdevScanSetLineHint(seeqdev_scan_t *s, double avg_bytes_per_li
 }
 
 extern "C" int seeqdevScanLastPath(const seeqdev_scan_t *s) { return s ? s->last_path : 0; }
+extern "C" int seeqdevScanLastFilter(const seeqdev_scan_t *s) { return s && s->last_filter ? 1 : 0; }
 
 extern "C" int seeqdevScanSetProfiling(seeqdev_scan_t *s, int on)
 {
@@ -989,6 +1034,20 @@ __global__ __launch_bounds__(WG) void k_scan_tiles(uint32_t *tile_cnt, uint32_t 
    if (threadIdx.x == 0) *total_out = running;
 }
 
+/* Workgroups of `fn` (threads per workgroup, dynamic LDS) that fit one CU; asked once per kernel and LDS size.
+ * Also raises the kernel's dynamic-LDS limit.  -1 (errno set) when HIP refuses. */
+static int occupancy_of(seeqdev_scan *s, const void *fn, int threads, size_t lds)
+{
+   for (int i = 0; i < s->nocc; i++)
+      if (s->occ[i].fn == fn && s->occ[i].lds == lds) return s->occ[i].per_cu;
+   if (lds) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), EIO);
+   int per_cu = 0;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+   OccMemo &m = s->occ[s->nocc < 8 ? s->nocc++ : 7];
+   m.fn = fn; m.lds = lds; m.per_cu = per_cu;
+   return per_cu;
+}
+
 template <int W>
 static int run_segments(seeqdev_scan *s)
 {
@@ -1004,39 +1063,32 @@ static int run_segments(seeqdev_scan *s)
 
    HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), s->stream), EIO);
 
-   int ncu = 256;
-   {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-         ncu = prop.multiProcessorCount;
-   }
+   const int ncu = s->ncu;
+   const ScanKnobs &kn = s->knobs;
 
    const size_t line_blocks = (s->cap_lines + WG - 1) / WG;
    unsigned grid_lines = (unsigned)(line_blocks < (size_t)ncu * 16 ? line_blocks : (size_t)ncu * 16);
    if (grid_lines == 0) grid_lines = 1;
 
-   /* Path selection: the fused LDS kernel serves one-word patterns with two spare flag bits on
-      ordinary read-length lines; everything else takes the generic index + k_forward<W> path. */
-   /* fw = words of the fused kernels' column: 1 for <= 30 positions, 2 for 31..62 (two flag bits needed) */
+   /* Path selection.  Patterns of <= 62 positions (one or two Myers words with two spare flag bits) on line input
+      take a ONE-PASS scan kernel + the exact pass k_exact1; everything else the generic index + k_forward<W> path. */
+   /* fw = words of the one-pass kernels' column: 1 for <= 30 positions, 2 for 31..62 */
    const int fw = pat->wlen <= FUSED_MAX_WLEN ? 1 : 2;
    const bool fusable = !single && pat->wlen <= FUSED_MAX_WLEN2;
-   /* k_stream: line-agnostic table-driven scan (seeq_stream.h), the default whenever it applies -- any line
-      length.  Only for the default options (SQ_FAIL, line mode, no FASTA headers), m + tau - 1 <= 32 and while
-      the complete automaton fits the LDS table (seeq_dfa.h). */
+   /* k_stream: line-agnostic table-driven scan (seeq_stream.h), the default whenever the pattern has an automaton that
+      fits LDS (seeq_dfa.h): the complete Levenshtein automaton (its verdicts are exact) or, for longer patterns /
+      larger distances, a partition FILTER automaton (its hit lines are candidates: the exact pass verifies them). */
    bool use_stream = false;
    int stream_ch = 128;
    {
-      const char *ke = getenv("SEEQ_FUSED_KERNEL");
       /* SQ_CONVERT / SQ_IGNORE differ from SQ_FAIL only on non-DNA bytes: k_stream runs, and when it meets one
          (Counters.dirty) it raises overflow flag 16 -> the scan is re-run on the per-line kernels, for good */
       const int nd = options & MASK_NONDNA;
       const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || (!s->no_stream_nd && !fasta));
-      if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && pat->wlen + pat->tau - 1 <= 32 &&
-          (!ke || !strcmp(ke, "stream"))) {
+      if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && kn.kernel != 2) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (mp->sdfa_state == 0 && mp->keys) {
-            seeq_dfa_t *d = seeq_dfa_build_stream(mp->keys, mp->wlen, mp->tau);
+            seeq_dfa_t *d = seeq_dfa_plan_stream(mp->keys, mp->wlen, mp->tau, kn.no_filter ? 1 : 0);
             mp->sdfa_state = -1;
             if (d) {
                const size_t bytes = (size_t)d->nrows * 16;
@@ -1044,62 +1096,39 @@ static int run_segments(seeqdev_scan *s)
                    hipMemcpy(mp->d_sdfa, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess) {
                   mp->sdfa_rows = d->nrows;
                   mp->sdfa_final_base = d->acc_final;            /* state value of ACC_NEW */
+                  mp->sdfa_parts = d->nparts;
+                  mp->sdfa_warm = d->warm;
+                  mp->sdfa_pacc = d->p_accept;
                   mp->sdfa_state = 1;
                }
                seeq_dfa_free(d);
             }
          }
-         const char *ce = getenv("SEEQ_STREAM_CH");
-         stream_ch = ce && atoi(ce) == 64 ? 64 : 128;
+         stream_ch = kn.stream_ch;
          use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
-         { const char *ie = getenv("SEEQ_STREAM_ILP"); if (fasta && (stream_ch != 128 || (ie && atoi(ie) == 1))) use_stream = false; }   /* FASTA: default variant only */
+         if (fasta && (stream_ch != 128 || kn.stream_ilp1)) use_stream = false;     /* FASTA: default variant only */
+         if (use_stream && mp->sdfa_parts > 1) {
+            /* a filter: worth it while few lines are false candidates (each costs a whole-line exact scan), and only on
+               read-length lines (the window walk over long lines needs exact candidates) */
+            if (s->avg_line > 600.0 || s->force_ll || mp->sdfa_pacc * s->avg_line > 0.25) use_stream = false;
+         }
       }
    }
-   bool use_fused = fusable && (s->avg_line <= 600.0 || use_stream) && s->force_path != 1;
-   if (s->force_path == 2 && fusable) use_fused = true;
+   const bool filter = use_stream && pat->sdfa_parts > 1;
+   bool use_fused = fusable && (s->avg_line <= 260.0 || use_stream) && s->force_path != 1;      /* k_direct regions are <= 16 KiB (~62 lines) */
    uint32_t tile_bytes = 0;
    unsigned fused_grid = 1;
-   size_t fused_lds = 0;
-   int nw = FUSED_NW_DEFAULT;
-   uint32_t halo = 0;
-   unsigned nslices = 1;                      /* hit slices: one per k_fused workgroup / per k_direct wave */
-   bool use_direct = false, use_dfa = false;
-   const int stream_wu = pat->wlen + pat->tau - 1 <= 24 ? 6 : 8;     /* warm-up dwords */
+   int nw = 4;
+   unsigned nslices = 1;                      /* hit slices: one per wave */
+   const int stream_wu = use_stream && pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
    bool stream_ilp2 = false, stream_ll = false;
    size_t dfa_lds = 0;
    if (use_fused) {
-      const char *ke = getenv("SEEQ_FUSED_KERNEL");
-      /* k_dfa: the table-driven scan.  Only for the default options (SQ_FAIL, line mode) -- there a non-DNA
-         byte ends the line, so column aliasing can only add spurious hit lines, which the exact pass weeds
-         out -- and only while the complete automaton fits the LDS table (seeq_dfa.h). */
-      const bool dfa_opts = (options & (MASK_NONDNA | MASK_INPUT)) == 0;
-      if (!use_stream && dfa_opts && s->avg_line * 63.5 <= 16.0 * 1024 - 64 && ke && !strcmp(ke, "dfa")) {      /* opt-in: see DESIGN.md */
-         seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
-         if (mp->dfa_state == 0 && mp->keys) {
-            seeq_dfa_t *d = seeq_dfa_build(mp->keys, mp->wlen, mp->tau);
-            mp->dfa_state = -1;
-            if (d) {
-               const size_t bytes = (size_t)d->nrows * 16;
-               if (hipMalloc((void **)&mp->d_dfa, bytes) == hipSuccess &&
-                   hipMemcpy(mp->d_dfa, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess) {
-                  mp->dfa_rows = d->nrows;
-                  mp->dfa_final_base = d->final_base;
-                  mp->dfa_state = 1;
-               }
-               seeq_dfa_free(d);
-            }
-         }
-         use_dfa = mp->dfa_state == 1;
-      }
-      use_direct = use_dfa || !(ke && !strcmp(ke, "lds")) || fw == 2;   /* k_direct / k_dfa: text in registers */
-      if (use_direct && s->avg_line * 62.0 > 16.0 * 1024 - 64) use_direct = false;   /* regions are <= 16 KiB */
-      const char *te = getenv("SEEQ_TILE_BYTES");
       if (use_stream) {
-         use_direct = false;
          nw = STREAM_NW;
          tile_bytes = 64u * (uint32_t)stream_ch;
-         { const char *ie = getenv("SEEQ_STREAM_ILP"); stream_ilp2 = stream_ch == 128 && !(ie && atoi(ie) == 1); }
+         stream_ilp2 = stream_ch == 128 && !kn.stream_ilp1;
          stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
 #define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
          stream_fn = stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
@@ -1110,78 +1139,30 @@ static int run_segments(seeqdev_scan *s)
                                       : (stream_wu == 6 ? SEEQ_STREAM_FN(64, 6, false, false, false) : SEEQ_STREAM_FN(64, 8, false, false, false));
 #undef SEEQ_STREAM_FN
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
-         HIP_TRY(hipFuncSetAttribute(stream_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dfa_lds), EIO);
-         int per_cu = 0;
-         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_fn, 64 * STREAM_NW, dfa_lds) != hipSuccess || per_cu < 1)
-            per_cu = 1;
-         { const char *we = getenv("SEEQ_DFA_WGS"); if (we && atoi(we) >= 1 && atoi(we) < per_cu) per_cu = atoi(we); }   /* experiments: workgroups per CU */
-         fused_grid = (unsigned)(ncu * per_cu);
-         if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
-         nslices = fused_grid * nw;                         /* one hit slice per wave */
-      } else if (use_direct) {
-         nw = 4;
-         double want = s->avg_line * 63.5;                /* <= 64 lines per region: one per lane */
-         if (want < 512) want = 512;
-         tile_bytes = ((uint32_t)want) & ~15u;
-         if (te && atoi(te) >= 512 && atoi(te) <= DIRECT_MAXRR * 1024) tile_bytes = (uint32_t)atoi(te) & ~15u;
-         int per_cu = 0;
-         if (use_dfa) {
-            nw = DFA_NW;
-            dfa_lds = (((size_t)pat->dfa_rows * 16 + 15) & ~(size_t)15) + (size_t)DFA_NW * DIRECT_SCAP * 4;
-            HIP_TRY(hipFuncSetAttribute((const void *)k_dfa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dfa_lds), EIO);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dfa, 64 * DFA_NW, dfa_lds) != hipSuccess || per_cu < 1)
-               per_cu = 1;
-            { const char *we = getenv("SEEQ_DFA_WGS"); if (we && atoi(we) >= 1 && atoi(we) < per_cu) per_cu = atoi(we); }
-         } else
-         if ((fw == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4, 1>, 256, 0)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_direct<4, 2>, 256, 0)) != hipSuccess || per_cu < 1)
-            per_cu = 1;
+         int per_cu = occupancy_of(s, stream_fn, 64 * STREAM_NW, dfa_lds);
+         if (per_cu < 0) return -1;
+         if (kn.wgs_per_cu >= 1 && kn.wgs_per_cu < per_cu) per_cu = kn.wgs_per_cu;       /* experiments: workgroups per CU */
          fused_grid = (unsigned)(ncu * per_cu);
          if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
          nslices = fused_grid * nw;                         /* one hit slice per wave */
       } else {
-      const char *ne = getenv("SEEQ_FUSED_NW");
-      if (ne && (atoi(ne) == 1 || atoi(ne) == 2 || atoi(ne) == 4)) nw = atoi(ne);
-      double want_tile = s->avg_line * (64.0 * nw - 2.0 - nw);
-      double hl = 4.0 * s->avg_line;
-      if (hl < 256) hl = 256;
-      if (hl > FUSED_HALO_MAX) hl = FUSED_HALO_MAX;
-      halo = ((uint32_t)hl + 15u) & ~15u;
-      double max_tile = (double)FUSED_MAXS * 64 * nw * 16 - halo;
-      if (max_tile > (double)FUSED_MAXR * 64 * nw * 16) max_tile = (double)FUSED_MAXR * 64 * nw * 16;
-      if (want_tile > max_tile) want_tile = max_tile;
-      if (want_tile > 56.0 * 1024) want_tile = 56.0 * 1024;
-      if (want_tile < (double)FUSED_MIN_TILE) want_tile = (double)FUSED_MIN_TILE;
-      tile_bytes = ((uint32_t)want_tile) & ~15u;
-      if (nw == 4) {
-         /* four workgroups per CU (16 waves) beat three slightly larger tiles: keep the tile inside a
-            quarter of the 160 KiB LDS */
-         const uint32_t budget = (uint32_t)(40960 - FusedLds<4>::TEXT - halo - 32) & ~15u;
-         if (tile_bytes > budget) tile_bytes = budget;
+         nw = 4;
+         double want = s->avg_line * 63.5;                /* <= 64 lines per region: one per lane */
+         if (want < 512) want = 512;
+         tile_bytes = ((uint32_t)want) & ~15u;
+         if (kn.tile_bytes >= 512 && kn.tile_bytes <= DIRECT_MAXRR * 1024) tile_bytes = (uint32_t)kn.tile_bytes & ~15u;
+         int per_cu = occupancy_of(s, fw == 1 ? (const void *)k_direct<4, 1> : (const void *)k_direct<4, 2>, 256, 0);
+         if (per_cu < 0) return -1;
+         fused_grid = (unsigned)(ncu * per_cu);
+         if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
+         nslices = fused_grid * nw;                         /* one hit slice per wave */
       }
-      if (te && atoi(te) >= (int)FUSED_MIN_TILE && atoi(te) <= (int)max_tile) tile_bytes = (uint32_t)atoi(te) & ~15u;
-      const void *kfn = nw == 1 ? (const void *)k_fused<1> : nw == 2 ? (const void *)k_fused<2> : (const void *)k_fused<4>;
-      fused_lds = nw == 1 ? fused_lds_bytes<1>(tile_bytes, halo) : nw == 2 ? fused_lds_bytes<2>(tile_bytes, halo)
-                                                                          : fused_lds_bytes<4>(tile_bytes, halo);
-      HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds), EIO);
-      int per_cu = 0;
-      hipError_t oe = nw == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<1>, 64, fused_lds)
-                    : nw == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<2>, 128, fused_lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fused<4>, 256, fused_lds);
-      if (oe != hipSuccess || per_cu < 1) per_cu = 1;
-      fused_grid = (unsigned)(ncu * per_cu);
-      if (fused_grid > MAX_FUSED_GRID) fused_grid = MAX_FUSED_GRID;
-      nslices = fused_grid;
-      }
-      if (s->eq_pat != pat || s->eq_options != options) {
-         /* EQ[byte]: top-aligned Peq word of the byte's class, or a flag (reference seeqcore.h:89-111 folded
-            with the non-DNA option, libseeq.c:223-228,265-270) */
+      if (s->eq_pat_id != pat->id || s->eq_options != options) {
          /* EQ[dir][byte][fw]: the top-aligned Peq column of the byte's class, or a flag (reference
             seeqcore.h:89-111 folded with the non-DNA option, libseeq.c:223-228,265-270) */
          uint32_t hpeq[20];                               /* [2 dirs][5 classes][Wp <= 2 words] */
          const int Wp = pat->words;
-         HIP_TRY(hipMemcpyAsync(hpeq, pat->d_peq, (size_t)10 * Wp * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), EIO);
-         HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+         memcpy(hpeq, pat->h_peq, (size_t)10 * Wp * sizeof(uint32_t));
          for (int dir = 0; dir < 2; dir++)
             for (int b = 0; b < 256; b++) {
                const uint8_t cls = sq_class_of((uint32_t)b, options);
@@ -1197,16 +1178,19 @@ static int run_segments(seeqdev_scan *s)
                dst[0] = (uint32_t)v;
                if (fw == 2) dst[1] = (uint32_t)(v >> 32);
             }
+         /* the pinned staging table may still be read by an earlier copy on this stream: wait before the next rewrite */
          HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)512 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
          HIP_TRY(hipStreamSynchronize(s->stream), EIO);
-         s->eq_pat = pat;
+         s->eq_pat_id = pat->id;
          s->eq_options = options;
       }
    }
-   s->last_path = use_fused ? (use_stream ? 5 : use_dfa ? 4 : use_direct ? 3 : 2) : 1;
-   const bool superset = use_dfa || use_stream;          /* the scan kernel's hit lines are candidates: nh[] decides */
+   const bool use_direct = use_fused && !use_stream;
+   s->last_path = use_fused ? (use_stream ? 5 : 3) : 1;
+   s->last_filter = filter;
+   const bool superset = use_stream;                     /* the scan kernel's hit lines are candidates: nh[] decides */
    if (superset) need_nh = true;
-   const bool generic_exact = !superset && getenv("SEEQ_EXACT") && !strcmp(getenv("SEEQ_EXACT"), "generic");   /* A/B knob */
+   const bool generic_exact = !superset && kn.exact_generic;      /* A/B knob */
 
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
@@ -1237,7 +1221,9 @@ static int run_segments(seeqdev_scan *s)
       a.hitmask = s->hitmask; a.hdrmask = s->hdrmask; a.wave_off = s->wave_off; a.hdr_off = s->hdr_off;
       a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
-      a.use_nh = need_nh ? (use_stream ? 3u : use_dfa ? 2u : 1u) : 0u;
+      a.use_nh = need_nh ? (use_stream ? 3u : 1u) : 0u;
+      a.filter = filter ? 1u : 0u;
+      a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1 > 32 ? pat->wlen + pat->tau - 1 : 32);
       a.cnt = c;
 
       if (use_fused) {
@@ -1246,7 +1232,6 @@ static int run_segments(seeqdev_scan *s)
          memset(&f, 0, sizeof f);
          f.text = a.text; f.nbytes = nbytes; f.seg_base = a.seg_base; f.seg_len = a.seg_len; f.first_seg = a.first_seg;
          f.tile_bytes = tile_bytes;
-         f.halo = halo;
          f.ntiles = (uint32_t)(((uint64_t)a.seg_len + tile_bytes - 1) / tile_bytes);
          stream_ntiles = f.ntiles;
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
@@ -1255,12 +1240,7 @@ static int run_segments(seeqdev_scan *s)
          f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = stream_ll ? s->wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
          f.tile_dirty = f.wg_lastnl ? s->tile_dirty : nullptr;
          f.tile_dmask = f.wg_lastnl ? s->tile_dmask : nullptr;
-         { const char *de = getenv("SEEQ_FUSED_DEBUG"); f.debug = de ? (uint32_t)atoi(de) : 0u; }
          f.cnt = c;
-         if (use_dfa) {
-            f.dfa = pat->d_dfa; f.dfa_rows = pat->dfa_rows; f.dfa_final_base = pat->dfa_final_base;
-            if (f.want == SEEQDEV_WANT_COUNTLINES) f.want = SEEQDEV_WANT_COUNTMATCH;   /* keep the hit-line list: it is verified below */
-         }
          uint32_t pos_bias = 0;
          if (use_stream) {
             f.dfa = pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
@@ -1283,12 +1263,8 @@ static int run_segments(seeqdev_scan *s)
             else { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(64, 6, false, false, false); else SEEQ_STREAM_LAUNCH(64, 8, false, false, false); }
 #undef SEEQ_STREAM_LAUNCH
          }
-         else if (use_dfa) hipLaunchKernelGGL(k_dfa, dim3(fgrid), dim3(64 * DFA_NW), dfa_lds, s->stream, f);
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);
-         else if (use_direct) hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, s->stream, f);
-         else if (nw == 1) hipLaunchKernelGGL(k_fused<1>, dim3(fgrid), dim3(64), fused_lds, s->stream, f);
-         else if (nw == 2) hipLaunchKernelGGL(k_fused<2>, dim3(fgrid), dim3(128), fused_lds, s->stream, f);
-         else hipLaunchKernelGGL(k_fused<4>, dim3(fgrid), dim3(256), fused_lds, s->stream, f);
+         else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, s->stream, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
          hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, s->stream, f, (uint32_t)nslices);
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
@@ -1401,6 +1377,9 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
       const size_t guess = (options & SEEQDEV_SINGLELINE) ? 1 : seg / 32 + 1024;
       if (guess > want_lines) want_lines = guess;
       if (want_lines / 8 + 1024 > want_hl) want_hl = want_lines / 8 + 1024;
+      /* the one-pass kernels cut the hit-line workspace into one slice per wave (<= 8 192 of them): room for 64
+         entries each, or the first scan with a hit always costs a second pass */
+      if (!(options & SEEQDEV_SINGLELINE) && want_hl < (size_t)8192 * 64) want_hl = (size_t)8192 * 64;
       if (want_hl > want_rec) want_rec = want_hl;
    }
    if (reserve_impl(s, nbytes ? nbytes : 1, want_lines, want_hl, want_rec)) return -1;
@@ -1426,7 +1405,9 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
 {
    seeqerr = 0;
    if (!s || !s->ran) { errno = EINVAL; return -1; }
-   for (int attempt = 0; attempt < 3; attempt++) {
+   /* Overflows surface one stage at a time (lines, hit lines, records, then k_stream's fall-backs): up to six
+      re-runs, and the result of the last one is checked too. */
+   for (int attempt = 0; attempt < 8; attempt++) {
       HIP_TRY(hipStreamSynchronize(s->stream), EIO);
       const Counters h = *s->h_cnt;
       if (!h.overflow) {
@@ -1461,6 +1442,7 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
          nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;
       }
       if ((h.overflow & 1u) && nhl < nl / 8) nhl = nl / 8 + 64;
+      if (attempt == 7) break;
       if (reserve_impl(s, s->nbytes, nl, nhl, nrec)) return -1;
       if (dispatch_run(s)) return -1;
    }
@@ -1520,6 +1502,7 @@ extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, 
       s->cap_text = cap;
    }
    if (nbytes) HIP_TRY(hipMemcpyAsync(s->d_text, host_text, nbytes, hipMemcpyHostToDevice, s->stream), EIO);
+   s->avg_text = NULL;                       /* same staging address, new content: sample the line length again */
    if (seeqdevScanRun(s, pat, s->d_text, nbytes, options, want)) return -1;
    return seeqdevScanFetch(s, counts);
 }

@@ -1,16 +1,24 @@
 /*
- * seeq_dfa.h -- host-side construction of the complete Levenshtein DFA of a pattern.
+ * seeq_dfa.h -- host-side construction of the automata k_stream walks (seeq_stream.h).
  *
- * This is the reference's own idea (a DFA whose states are the saturated Needleman-Wunsch columns,
- * reference libseeq.c:698-842, doc/document.tex:92-136) taken to its conclusion for the GPU: instead
- * of growing the automaton lazily while scanning, the WHOLE reachable automaton is built up front,
- * breadth first, with every accepting state (D[m] <= tau) folded into one absorbing state -- the scan
- * kernel only has to know whether a line ever reaches it.  For the headline pattern (20 positions,
- * tau = 3) that is 3 342 states; the table (8 columns x u16 per state) is 53 KB and lives in LDS.
- * Patterns whose automaton exceeds SEEQ_DFA_MAX_STATES keep using the bit-vector kernels.
+ * (1) The COMPLETE Levenshtein DFA of a pattern.  This is the reference's own idea (a DFA whose states are the
+ * saturated Needleman-Wunsch columns, reference libseeq.c:698-842, doc/document.tex:92-136) taken to its conclusion
+ * for the GPU: instead of growing the automaton lazily while scanning, the WHOLE reachable automaton is built up
+ * front, breadth first, with every accepting state (D[m] <= tau) folded into one absorbing state -- the scan kernel
+ * only has to know whether a line ever reaches it.  For the headline pattern (20 positions, tau = 3) that is 3 342
+ * states; the table (8 columns x u16 per state) is 53 KB and lives in LDS.
+ *
+ * (2) A partition FILTER automaton, for patterns whose complete automaton does not fit.  Cut the pattern into k
+ * contiguous parts: an occurrence with <= tau errors spends <= floor(tau / k) of them in at least one part (pigeon
+ * hole), so it CONTAINS an occurrence of that part with <= t = floor(tau / k) errors.  The filter is the automaton
+ * whose state is the tuple of the k parts' saturated columns (threshold t), advanced together; it accepts when any
+ * part does.  Reachable tuples are few (configs[4]: 40 positions, tau = 5 -> k = 3, t = 1: 580 states).  Lines it
+ * flags are CANDIDATES -- a superset of the hit lines -- and the exact pass verifies every one of them with the
+ * bit-vector column; lines it does not flag hold no hit.  `p_accept` (stationary probability that a random DNA
+ * character completes a part) tells the caller how many false candidates to expect.
  *
  * Row layout (16 bytes per state, entries are ROW BYTE OFFSETS so that the kernel's address is
- * `state | (byte & 0xE)`):   column c = (byte >> 1) & 7
+ * `state ^ (byte & 0xE)`):   column c = (byte >> 1) & 7
  *      0 'A'  1 'C'  2 'T','U'  3 'G'  5 '\n'  7 'N'     (same for lower case);  4, 6: no DNA byte
  * Bytes that are not DNA alias onto these columns.  Under SQ_FAIL such a byte ends the line
  * (reference libseeq.c:267-270), so whatever the automaton does after it can only ADD spurious hit
@@ -24,40 +32,55 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define SEEQ_DFA_MAX_STATES 4000        /* (states + 2 finals) * 16 B must fit 16-bit row offsets */
+#ifndef SEEQ_DFA_MAX_STATES
+#define SEEQ_DFA_MAX_STATES 4000        /* (states + 3 special rows) * 16 B must fit 16-bit row offsets */
+#endif
+#define SEEQ_DFA_MAX_PARTS  8
 
 typedef struct {
    uint32_t  nstates;        /* BFS states incl. the absorbing accepting one */
-   uint32_t  acc_final;      /* row offset of ACC_FINAL; rows >= final_base are final */
+   uint32_t  acc_final;      /* state value of ACC_NEW */
    uint32_t  dead_final;
-   uint32_t  final_base;
-   uint32_t  nrows;          /* nstates + 2 */
+   uint32_t  final_base;     /* state value of ROOT_NL */
+   uint32_t  nrows;          /* nstates + 3 */
+   int       nparts;         /* 1 = complete automaton (exact); > 1 = partition filter */
+   int       warm;           /* text bytes a walk started at the root needs before its verdicts are those of the line-long walk */
+   double    p_accept;       /* filter: stationary probability that a uniformly random A/C/G/T completes a candidate */
    uint16_t *table;          /* nrows * 8 entries */
 } seeq_dfa_t;
 
 static inline void seeq_dfa_free(seeq_dfa_t *d) { if (d) { free(d->table); free(d); } }
 
-/* Breadth-first construction of the reachable automaton.  keys: one byte per pattern position (bit0 A,
- * bit1 C, bit2 G, bit3 T, N = 0x1F).  On success returns the number of states n (state 0 = root, state 1 =
+/* Breadth-first construction of the reachable automaton of `nparts` pattern slices advanced together, each with its
+ * own saturated column (threshold t).  keys: one byte per pattern position (bit0 A, bit1 C, bit2 G, bit3 T, N = 0x1F);
+ * part p covers positions [cut[p], cut[p+1]).  nparts = 1, t = tau is the complete automaton of the pattern
+ * (reference libseeq.c:767-786 per column).  On success returns the number of states n (state 0 = root, state 1 =
  * the absorbing accepting state) and *next_out = n * 5 transitions (classes A C G T N), to be free()d.
  * Returns 0 when the automaton has more than SEEQ_DFA_MAX_STATES states (or on allocation failure). */
-static inline uint32_t seeq_dfa_bfs(const char *keys, int m, int tau, uint32_t **next_out)
+static inline uint32_t seeq_dfa_bfs_parts(const char *keys, const int *cut, int nparts, int t, uint32_t **next_out)
 {
    *next_out = NULL;
-   if (m < 1 || m > 62 || tau < 0 || tau >= m) return 0;
+   const int m = cut[nparts];
+   if (nparts < 1 || nparts > SEEQ_DFA_MAX_PARTS || m < 1 || m > 62 || t < 0) return 0;
+   for (int p = 0; p < nparts; p++) if (cut[p + 1] - cut[p] <= t) return 0;       /* a part must be longer than its threshold */
    const int cap = SEEQ_DFA_MAX_STATES;
-   const size_t colsz = (size_t)m + 1;
-   uint8_t *cols = (uint8_t *)malloc((size_t)(cap + 1) * colsz);          /* state -> column */
+   const size_t colsz = (size_t)m + (size_t)nparts;                /* every part has its own row 0 */
+   uint8_t *cols = (uint8_t *)malloc((size_t)(cap + 1) * colsz);          /* state -> columns, concatenated */
    uint32_t *next = (uint32_t *)malloc((size_t)(cap + 1) * 5 * sizeof(uint32_t));
-   const uint32_t HSZ = 16384;                                  /* open addressing, power of two */
+   uint32_t HSZ = 16384;                                           /* open addressing, power of two, <= 1/4 full */
+   while (HSZ < 4u * (uint32_t)cap) HSZ <<= 1;
    int32_t *hash = (int32_t *)malloc(HSZ * sizeof(int32_t));
    uint8_t *tmp = (uint8_t *)malloc(colsz);
    uint32_t n = 2;
    bool ok = false;
    if (!cols || !next || !hash || !tmp) goto done;
    memset(hash, 0xFF, HSZ * sizeof(int32_t));
-   /* state 0 = root column min(i, tau+1) (reference libseeq.c:681-682); state 1 = ACC (absorbing) */
-   for (int i = 0; i <= m; i++) cols[i] = (uint8_t)(i <= tau ? i : tau + 1);
+   /* state 0 = root columns min(i, t+1) (reference libseeq.c:681-682); state 1 = ACC (absorbing) */
+   {
+      size_t o = 0;
+      for (int p = 0; p < nparts; p++)
+         for (int i = 0; i <= cut[p + 1] - cut[p]; i++) cols[o++] = (uint8_t)(i <= t ? i : t + 1);
+   }
    memset(cols + colsz, 0xFF, colsz);
    {
       uint32_t h = 2166136261u;
@@ -69,23 +92,31 @@ static inline uint32_t seeq_dfa_bfs(const char *keys, int m, int tau, uint32_t *
       if (s == 1) continue;
       const uint8_t *col = cols + (size_t)s * colsz;
       for (int c = 0; c < 5; c++) {
-         /* one column of the saturated matrix: reference libseeq.c:767-786 */
+         /* one column of the saturated matrix per part: reference libseeq.c:767-786 */
          const int bit = 1 << c;
-         int diag = col[0], up = 0;
-         tmp[0] = 0;
-         for (int i = 1; i <= m; i++) {
-            const int left = col[i];
-            int v = diag + ((keys[i - 1] & bit) == 0);
-            const int g = (up < left ? up : left) + 1;
-            if (g < v) v = g;
-            if (v > tau + 1) v = tau + 1;
-            tmp[i] = (uint8_t)v;
-            up = v;
-            diag = left;
+         bool acc = false;
+         size_t o = 0;
+         for (int p = 0; p < nparts; p++) {
+            const int len = cut[p + 1] - cut[p];
+            const char *pk = keys + cut[p];
+            int diag = col[o], up = 0;
+            tmp[o] = 0;
+            for (int i = 1; i <= len; i++) {
+               const int left = col[o + i];
+               int v = diag + ((pk[i - 1] & bit) == 0);
+               const int g = (up < left ? up : left) + 1;
+               if (g < v) v = g;
+               if (v > t + 1) v = t + 1;
+               tmp[o + i] = (uint8_t)v;
+               up = v;
+               diag = left;
+            }
+            if (tmp[o + len] <= t) acc = true;
+            o += (size_t)len + 1;
          }
-         uint32_t t;
-         if (tmp[m] <= tau) {
-            t = 1;                                               /* accepting: absorbed */
+         uint32_t tgt;
+         if (acc) {
+            tgt = 1;                                             /* accepting: absorbed */
          } else {
             uint32_t h = 2166136261u;
             for (size_t i = 0; i < colsz; i++) h = (h ^ tmp[i]) * 16777619u;
@@ -96,14 +127,14 @@ static inline uint32_t seeq_dfa_bfs(const char *keys, int m, int tau, uint32_t *
                   if ((int)n >= cap) goto done;                  /* too large for the LDS table */
                   memcpy(cols + (size_t)n * colsz, tmp, colsz);
                   hash[slot] = (int32_t)n;
-                  t = n++;
+                  tgt = n++;
                   break;
                }
-               if (memcmp(cols + (size_t)e * colsz, tmp, colsz) == 0) { t = (uint32_t)e; break; }
+               if (memcmp(cols + (size_t)e * colsz, tmp, colsz) == 0) { tgt = (uint32_t)e; break; }
                slot = (slot + 1) & (HSZ - 1);
             }
          }
-         next[(size_t)s * 5 + c] = t;
+         next[(size_t)s * 5 + c] = tgt;
       }
    }
    ok = true;
@@ -114,39 +145,41 @@ done:
    return n;
 }
 
-static const int seeq_dfa_colof[5] = {0, 1, 3, 2, 7};           /* table column of a class: A C G T N */
-
-/* Per-line automaton (k_dfa): '\n' and the non-DNA columns lead to two absorbing final rows. */
-static inline seeq_dfa_t *seeq_dfa_build(const char *keys, int m, int tau)
+static inline uint32_t seeq_dfa_bfs(const char *keys, int m, int tau, uint32_t **next_out)
 {
-   uint32_t *next = NULL;
-   const uint32_t n = seeq_dfa_bfs(keys, m, tau, &next);
-   if (!n) return NULL;
-   seeq_dfa_t *d = (seeq_dfa_t *)calloc(1, sizeof *d);
-   if (d) {
-      d->nstates = n;
-      d->nrows = n + 2;
-      d->final_base = n * 16;
-      d->acc_final = n * 16;
-      d->dead_final = (n + 1) * 16;
-      d->table = (uint16_t *)malloc((size_t)d->nrows * 8 * sizeof(uint16_t));
-      if (!d->table) { free(d); d = NULL; }
-   }
-   if (d) {
-      for (uint32_t s = 0; s < n; s++) {
-         uint16_t *row = d->table + (size_t)s * 8;
-         const uint16_t end = (uint16_t)(s == 1 ? d->acc_final : d->dead_final);
-         for (int k = 0; k < 8; k++) row[k] = end;               /* '\n' and non-DNA columns: the line is over */
-         for (int c = 0; c < 5; c++) row[seeq_dfa_colof[c]] = (uint16_t)(next[(size_t)s * 5 + c] * 16);
-      }
-      for (int k = 0; k < 8; k++) {
-         d->table[(size_t)n * 8 + k] = (uint16_t)d->acc_final;   /* finals absorb everything */
-         d->table[(size_t)(n + 1) * 8 + k] = (uint16_t)d->dead_final;
-      }
-   }
-   free(next);
-   return d;
+   const int cut[2] = {0, m};
+   return seeq_dfa_bfs_parts(keys, cut, 1, tau, next_out);
 }
+
+/* Stationary probability that one uniformly random A/C/G/T takes the walk into ACC, the walk restarting at the root
+ * after every acceptance (power iteration; the chain forgets its start within a few pattern lengths). */
+static inline double seeq_dfa_accept_rate(const uint32_t *next, uint32_t n, int rounds)
+{
+   double *cur = (double *)calloc(n, sizeof(double)), *nxt = (double *)calloc(n, sizeof(double));
+   double rate = 1.0;
+   if (cur && nxt) {
+      cur[0] = 1.0;
+      for (int r = 0; r < rounds; r++) {
+         memset(nxt, 0, n * sizeof(double));
+         double acc = 0.0;
+         for (uint32_t s = 0; s < n; s++) {
+            if (s == 1 || cur[s] == 0.0) continue;
+            const double q = cur[s] * 0.25;
+            for (int c = 0; c < 4; c++) {
+               const uint32_t tgt = next[(size_t)s * 5 + c];
+               if (tgt == 1) acc += q; else nxt[tgt] += q;
+            }
+         }
+         nxt[0] += acc;
+         rate = acc;
+         double *sw = cur; cur = nxt; nxt = sw;
+      }
+   }
+   free(cur); free(nxt);
+   return rate;
+}
+
+static const int seeq_dfa_colof[5] = {0, 1, 3, 2, 7};           /* table column of a class: A C G T N */
 
 /* Streaming automaton (k_stream): runs across line ends.  Special rows, as row byte offsets:
  *    16           ACC_OLD   the line already has a hit (absorbing until the line ends)
@@ -154,11 +187,8 @@ static inline seeq_dfa_t *seeq_dfa_build(const char *keys, int m, int tau)
  *    dead_final   DEAD      a non-DNA byte ended the line (SQ_FAIL, reference libseeq.c:267-270); waits for '\n'
  *    final_base+32 ROOT_NL  copy of the root row: the state right after a '\n'
  * so "state == ACC_NEW" marks the text position where a line gets its first hit. */
-static inline seeq_dfa_t *seeq_dfa_build_stream(const char *keys, int m, int tau)
+static inline seeq_dfa_t *seeq_dfa_layout_stream(uint32_t *next, uint32_t n)
 {
-   uint32_t *next = NULL;
-   const uint32_t n = seeq_dfa_bfs(keys, m, tau, &next);
-   if (!n) return NULL;
    seeq_dfa_t *d = (seeq_dfa_t *)calloc(1, sizeof *d);
    if (d) {
       d->nstates = n;
@@ -201,6 +231,53 @@ static inline seeq_dfa_t *seeq_dfa_build_stream(const char *keys, int m, int tau
    }
    free(next);
    return d;
+}
+
+/* The complete automaton of the pattern, or NULL when it has more than SEEQ_DFA_MAX_STATES states. */
+static inline seeq_dfa_t *seeq_dfa_build_stream(const char *keys, int m, int tau)
+{
+   uint32_t *next = NULL;
+   const uint32_t n = seeq_dfa_bfs(keys, m, tau, &next);
+   if (!n) return NULL;
+   seeq_dfa_t *d = seeq_dfa_layout_stream(next, n);
+   if (d) { d->nparts = 1; d->warm = m + tau - 1; d->p_accept = 0.0; }
+   return d;
+}
+
+/* The filter of k equal parts (sizes differ by at most one), threshold floor(tau / k); NULL when it does not fit. */
+static inline seeq_dfa_t *seeq_dfa_build_filter(const char *keys, int m, int tau, int k)
+{
+   int cut[SEEQ_DFA_MAX_PARTS + 1];
+   if (k < 2 || k > SEEQ_DFA_MAX_PARTS || k > m) return NULL;
+   for (int p = 0; p <= k; p++) cut[p] = (int)((long)p * m / k);
+   const int t = tau / k;
+   int longest = 0;
+   for (int p = 0; p < k; p++) if (cut[p + 1] - cut[p] > longest) longest = cut[p + 1] - cut[p];
+   uint32_t *next = NULL;
+   const uint32_t n = seeq_dfa_bfs_parts(keys, cut, k, t, &next);
+   if (!n) return NULL;
+   const double rate = seeq_dfa_accept_rate(next, n, 4 * m + 64);
+   seeq_dfa_t *d = seeq_dfa_layout_stream(next, n);
+   if (d) { d->nparts = k; d->warm = longest + t - 1; d->p_accept = rate; }
+   return d;
+}
+
+/* What k_stream should walk for this pattern: the complete automaton when it fits and warms up within 32 bytes
+ * (exact verdicts), else the filter with the fewest parts that does (most selective first); NULL: none. */
+static inline seeq_dfa_t *seeq_dfa_plan_stream(const char *keys, int m, int tau, int complete_only)
+{
+   if (m + tau - 1 <= 32) {
+      seeq_dfa_t *d = seeq_dfa_build_stream(keys, m, tau);
+      if (d) return d;
+   }
+   if (complete_only) return NULL;
+   for (int k = 2; k <= SEEQ_DFA_MAX_PARTS && k <= tau + 1; k++) {
+      seeq_dfa_t *d = seeq_dfa_build_filter(keys, m, tau, k);
+      if (!d) continue;
+      if (d->warm <= 32) return d;
+      seeq_dfa_free(d);
+   }
+   return NULL;
 }
 
 #endif

@@ -1,21 +1,18 @@
 /*
- * seeq_direct.h -- k_direct: the register-resident variant of the fused hot kernel.
+ * seeq_direct.h -- k_direct: the per-line bit-vector scan kernel (one line per lane, text in registers).
  *
- * Same job and same outputs as k_fused (seeq_fused.h): newline index + per-line Myers filter +
- * ordered hit-line compaction in ONE pass over the text (reference seeq.c:361-380 +
- * libseeq.c:250-275), patterns of <= 30 positions.  What differs is where a lane's text lives:
+ * One pass over the text does what the reference does per line in seeq.c:361-380 + libseeq.c:250-275 (getline,
+ * newline strip, FASTA header skip, byte classification, per-character distance) for patterns of up to 62
+ * positions (one or two 32-bit Myers words with two spare flag bits), plus the ordered hit-line compaction.
+ * It serves what the table-driven k_stream (seeq_stream.h) cannot: patterns whose (filter) automaton does not
+ * fit LDS or is not selective enough.
  *
- *   k_fused  : a ~250-line tile per workgroup is staged in LDS and stays there while the lanes
- *              walk their lines -> the number of lines resident per CU (hence waves per SIMD: 3)
- *              is capped by the 160 KB of LDS;
- *   k_direct : every WAVE works alone on a ~62-line region.  It reads the region once with
- *              coalesced 16-byte loads (HBM) only to find the newlines (SWAR test + DPP wave scans,
- *              all in registers), then every lane loads ITS OWN line straight into VGPRs, 160
- *              characters (10 x dwordx4, all in flight together; L2 hits, the bytes were just
-  LDS only holds the
- *              256-entry EQ table and 64..256 line starts per wave, so occupancy is bounded by
- *              VGPRs (~100 -> 5 waves/SIMD) and the ~10-cycle dependent-issue latency of the
- *              integer pipe is covered.  No workgroup barriers, no atomics.
+ * Every WAVE works alone on a ~62-line region.  It reads the region once with coalesced 16-byte loads (HBM) only
+ * to find the newlines (SWAR test + DPP wave scans, all in registers), then every lane loads ITS OWN line straight
+ * into VGPRs, 160 characters (10 x dwordx4, all in flight together; L2 hits, the bytes were just fetched) and runs
+ * the top-aligned Myers step per character from registers.  LDS only holds the 256-entry EQ table and 64..256 line
+ * starts per wave, so occupancy is bounded by VGPRs (~100 -> 5 waves/SIMD) and the ~10-cycle dependent-issue
+ * latency of the integer pipe is covered.  No workgroup barriers, no atomics.
  *
  * Lines of any length are handled by the same loop (one 160-character window after the other).
  */
@@ -171,7 +168,6 @@ __global__ __launch_bounds__(64 * NW, (W == 1 ? 4 : 3)) void k_direct(FusedArgs 
             st.init((uint32_t)a.m);
             uint32_t minscore = (uint32_t)a.m;
             bool hit = false, hdr = false;
-            if (a.debug & 1u) active = false;
             auto next_window = [&](fused_v4u (&v)[DIRECT_WIN]) {
                const uint64_t o = lbase + ahead;
                if (!__any(o + 16 * DIRECT_WIN > a.nbytes)) {

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
    const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1;
    const bool count_any = a.want != SEEQDEV_WANT_COUNTMATCH && !(a.want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const bool by_nh = a.use_nh != 0;                       /* record slots come from the scanned per-line counts */
-   const bool trusted = a.use_nh == 3 && !c->dirty;        /* k_stream on clean text: its verdicts are exact */
+   const bool trusted = a.use_nh == 3 && !c->dirty && !a.filter;   /* k_stream, complete automaton, clean text: its verdicts are exact */
    const bool caching = MODE == SQ_MODE_COUNT && cache != nullptr && a.want == SEEQDEV_WANT_RECORDS;
    const bool count_best = caching && match_opt == SQ_BEST;
    const bool cache_ok = MODE == SQ_MODE_EMIT && cache != nullptr && by_nh && !(trusted && count_any);
@@ -176,10 +176,12 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       bool win = false;
       uint32_t wend = 0, knext = k + 1;                    /* end of the current window (column), next hit-list entry */
       int32_t lastsub = -0x40000000;                       /* column of the last score <= tau seen */
-      if (hit_col && (trusted || walk) && !done) {
+      if (hit_col && (trusted || walk || a.filter) && !done) {
          const uint32_t col = hit_col[k];
-         /* nothing ends the line before the first candidate (clean text), so the scan may start just before it */
-         if (col > 32 && (trusted || exact1_clean(a, off, off + col - 32))) pos = col - 32;
+         /* nothing ends the line before the first candidate (clean text), so the scan may start just before it: no
+            occurrence ends before `col` (a filter: every occurrence contains a part that ends at or after the first
+            candidate), and a column started skip_back >= m + tau - 1 bytes earlier has the line's own scores from there */
+         if (col > a.skip_back && (trusted || exact1_clean(a, off, off + col - a.skip_back))) pos = col - a.skip_back;
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;

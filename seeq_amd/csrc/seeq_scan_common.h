@@ -1,0 +1,225 @@
+/*
+ * seeq_scan_common.h -- what the one-pass scan kernels (k_stream: seeq_stream.h, k_direct: seeq_direct.h) and the
+ * exact pass (k_exact1: seeq_exact1.h) share: the argument block, the top-aligned Myers step for one- and two-word
+ * columns, the byte-indexed EQ table entries, DPP wave scans, and the two small kernels that turn per-wave slices
+ * into ordered per-line arrays.
+ *
+ * EQ[byte] (256 entries per direction, built on the host in seeq_device.hip): the top-aligned Peq word of the byte's
+ * class (reference seeqcore.h:89-111 folded with the non-DNA option, libseeq.c:223-228,265-270), or a flag for bytes
+ * that end the line / are skipped but counted in coordinates.
+ */
+#ifndef SEEQ_SCAN_COMMON_H_
+#define SEEQ_SCAN_COMMON_H_
+
+#define FUSED_FLAG_TERM 1u      /* byte ends the line                          */
+#define FUSED_FLAG_SKIP 2u      /* byte is skipped but counted in coordinates  */
+#define FUSED_FLAGS     3u
+#define FUSED_MAX_WLEN  30      /* 32-bit word minus the two flag bits         */
+#define FUSED_MAX_WLEN2 62      /* two words minus the two flag bits (k_direct<.,2>, k_exact1<.,2>) */
+
+typedef unsigned int fused_v4u __attribute__((ext_vector_type(4)));
+typedef fused_v4u fused_v4u_unaligned __attribute__((aligned(1)));   /* the text pointer may have any alignment */
+
+struct FusedArgs {
+   const uint8_t *text;        /* whole buffer                                 */
+   uint64_t       nbytes;
+   uint64_t       seg_base;    /* first byte of the segment                    */
+   uint32_t       seg_len;
+   uint32_t       first_seg;
+   uint32_t       tile_bytes;  /* multiple of 16                               */
+   uint32_t       pos_bias;    /* k_stream: hit offsets are relative to seg_base - pos_bias (a line can start before the segment) */
+   uint32_t       ntiles;
+   const uint32_t *eqtab;      /* [256] top-aligned Peq word or flag, per byte */
+   const uint32_t *peq;        /* [2][5][1] bottom-aligned (long-line fallback)*/
+   int            m, tau, options, want;
+   uint32_t      *tile_cl;     /* per tile: counted lines (headers excluded)   */
+   uint32_t      *tile_hits;   /* per tile: hit lines                          */
+   uint4         *tmp;         /* hit entries {tile, seq, start, counted rank}: one slice per wave */
+   uint32_t       cap_tmp;     /* total entries                                */
+   uint32_t       slice_cap;   /* entries per slice = cap_tmp / slices           */
+   uint32_t      *wg_hits;     /* per slice (= per wave of k_stream / k_direct): entries stored */
+   uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31}               */
+   uint32_t      *tile_dirty;  /* k_stream, long-line mode: per tile, 1 when it holds a byte outside the alphabet (then its exclusive prefix); else NULL */
+   uint64_t      *tile_dmask;  /* k_stream, long-line mode: per tile, one bit per 128-byte chunk (lane) that holds a non-alphabet byte */
+   uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */
+   const uint16_t *dfa;        /* k_stream: transition table, dfa_rows x 8 u16 (seeq_dfa.h) */
+   uint32_t       dfa_rows;
+   uint32_t       dfa_final_base;   /* row offset of ACC_FINAL; DEAD_FINAL = +16 */
+   Counters      *cnt;
+};
+
+/* One Myers column step on a TOP-aligned pattern (row m = bit 31).  The two
+ * left shifts double as the extraction of the horizontal delta of row m: the
+ * carry out of ph+ph / mh+mh is +1 / -1 on D[m][j]. */
+__device__ __forceinline__ void fused_step(uint32_t eq, uint32_t &pv, uint32_t &mv, uint32_t &score)
+{
+   /* Hyyro's form of the Myers recurrence: D0 = zero-diagonal vector (12 VALU ops with 3-input bitops) */
+   const uint32_t s = (eq & pv) + pv;
+   const uint32_t d0 = ((s ^ pv) | eq) | mv;
+   const uint32_t ph = mv | ~(d0 | pv);
+   const uint32_t mh = pv & d0;
+   uint32_t ph2, mh2;
+   asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+       : "=v"(ph2), "+v"(score) : "v"(ph) : "vcc");
+   asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+       : "=v"(mh2), "+v"(score) : "v"(mh) : "vcc");
+   pv = mh2 | ~(d0 | ph2);
+   mv = ph2 & d0;
+}
+
+/* alphabet check of four characters: nonzero when a byte is outside {ACGTN, acgtn, '\n'} (k_stream's table columns
+ * are exact for those; any other byte aliases onto one of them) */
+__device__ __forceinline__ uint32_t fused_bad4(uint32_t w)
+{
+   /* canonical byte of each table column (A C T G . \n . N); the text must equal it -- letters in either case,
+      the newline exactly ('*' = 0x2A is '\n' with the case bit set: it must NOT pass) */
+   const uint32_t idx = (w & 0x0E0E0E0Eu) >> 1;
+   const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx);
+   const uint32_t fold = __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDFDFDFu, idx);      /* per column: case-fold mask */
+   return (w & fold) ^ canon;
+}
+
+/* Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts
+ * (VALU-speed, no LDS crossbar round trips). */
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x)
+{
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   /* row_shr:1 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   /* row_shr:2 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   /* row_shr:4 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   /* row_shr:8 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);   /* row_bcast:15 -> rows 1,3 */
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);   /* row_bcast:31 -> rows 2,3 */
+   return x;
+}
+
+/* ---- one- and two-word variants behind one interface (k_direct, k_exact1 are templated on W) ---- */
+/* W = 2 serves patterns of 31..62 positions: the pattern sits in the top m bits of a 64-bit column
+   (lo word = low rows), the two flag bits in bits 0-1 of the low word. */
+template <int W> struct fused_eq_t;
+template <> struct fused_eq_t<1> { uint32_t w0; };
+template <> struct fused_eq_t<2> { uint32_t w0, w1; };
+
+typedef __attribute__((address_space(3))) const uint32_t fused_lds_cu32;
+typedef __attribute__((address_space(3))) const uint64_t fused_lds_cu64;
+
+template <int W>
+__device__ __forceinline__ fused_eq_t<W> fused_eq_load(uint32_t lds_byte_addr);
+template <>
+__device__ __forceinline__ fused_eq_t<1> fused_eq_load<1>(uint32_t addr)
+{
+   fused_eq_t<1> e;
+   e.w0 = *(fused_lds_cu32 *)(uintptr_t)addr;
+   return e;
+}
+template <>
+__device__ __forceinline__ fused_eq_t<2> fused_eq_load<2>(uint32_t addr)
+{
+   const uint64_t v = *(fused_lds_cu64 *)(uintptr_t)addr;          /* ds_read_b64 */
+   fused_eq_t<2> e;
+   e.w0 = (uint32_t)v;
+   e.w1 = (uint32_t)(v >> 32);
+   return e;
+}
+
+template <int W> struct fused_state_t;
+template <> struct fused_state_t<1> {
+   uint32_t pv, mv, score;
+   __device__ __forceinline__ void init(uint32_t m) { pv = 0xFFFFFFFFu; mv = 0u; score = m; }
+   __device__ __forceinline__ void step(const fused_eq_t<1> &e) { fused_step(e.w0, pv, mv, score); }
+};
+template <> struct fused_state_t<2> {
+   uint32_t pv0, pv1, mv0, mv1, score;
+   __device__ __forceinline__ void init(uint32_t m) { pv0 = pv1 = 0xFFFFFFFFu; mv0 = mv1 = 0u; score = m; }
+   /* the 64-bit version of fused_step: one carry chain through both words; the carry out of the
+      high word of ph+ph / mh+mh is the +1 / -1 on D[m][j] */
+   __device__ __forceinline__ void step(const fused_eq_t<2> &e)
+   {
+      const uint64_t pv = ((uint64_t)pv1 << 32) | pv0, eq = ((uint64_t)e.w1 << 32) | e.w0;
+      const uint64_t s = (eq & pv) + pv;
+      const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+      const uint32_t d00 = ((s0 ^ pv0) | e.w0) | mv0, d01 = ((s1 ^ pv1) | e.w1) | mv1;
+      const uint32_t ph0 = mv0 | ~(d00 | pv0), ph1 = mv1 | ~(d01 | pv1);
+      const uint32_t mh0 = pv0 & d00, mh1 = pv1 & d01;
+      uint32_t p0, p1, m0, m1;
+      asm("v_add_co_u32 %0, vcc, %3, %3\n\tv_addc_co_u32 %1, vcc, %4, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+          : "=&v"(p0), "=&v"(p1), "+v"(score) : "v"(ph0), "v"(ph1) : "vcc");
+      asm("v_add_co_u32 %0, vcc, %3, %3\n\tv_addc_co_u32 %1, vcc, %4, %4, vcc\n\tv_subbrev_co_u32 %2, vcc, 0, %2, vcc"
+          : "=&v"(m0), "=&v"(m1), "+v"(score) : "v"(mh0), "v"(mh1) : "vcc");
+      pv0 = m0 | ~(d00 | p0); pv1 = m1 | ~(d01 | p1);
+      mv0 = p0 & d00;         mv1 = p1 & d01;
+   }
+};
+
+/* After k_stream / k_direct: reduce the per-slice partial counts (no atomics in the hot kernels)
+   and publish the hit-line count of the segment, or the overflow. */
+__global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslices)
+{
+   __shared__ uint32_t s_red[4][4];
+   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0;
+   for (uint32_t i = threadIdx.x; i < nslices; i += 256) {
+      if (a.wg_lastnl) { const uint32_t l = a.wg_lastnl[i]; lastnl = l > lastnl ? l : lastnl; }
+      lines += a.wg_part[3 * i + 0];
+      hdrs += a.wg_part[3 * i + 1];
+      const uint32_t h = a.wg_part[3 * i + 2];
+      hits += h & 0x7FFFFFFFu;
+      mx = (h & 0x7FFFFFFFu) > mx ? (h & 0x7FFFFFFFu) : mx;
+      ovf |= h >> 31;
+   }
+#pragma unroll
+   for (int d = 32; d >= 1; d >>= 1) {
+      lines += __shfl_xor(lines, d, 64);
+      hdrs += __shfl_xor(hdrs, d, 64);
+      hits += __shfl_xor(hits, d, 64);
+      const uint32_t o = __shfl_xor(mx, d, 64);
+      mx = o > mx ? o : mx;
+      ovf |= __shfl_xor(ovf, d, 64);
+      const uint32_t ol = __shfl_xor(lastnl, d, 64);
+      lastnl = ol > lastnl ? ol : lastnl;
+   }
+   __shared__ uint32_t s_last[4];
+   const int w = threadIdx.x >> 6;
+   if ((threadIdx.x & 63) == 0) s_last[w] = lastnl;
+   if ((threadIdx.x & 63) == 0) { s_red[w][0] = lines; s_red[w][1] = hdrs; s_red[w][2] = hits; s_red[w][3] = mx | (ovf << 31); }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      lines = hdrs = hits = mx = ovf = 0;
+      for (int k = 0; k < 4; k++) {
+         lines += s_red[k][0]; hdrs += s_red[k][1]; hits += s_red[k][2];
+         const uint32_t m = s_red[k][3] & 0x7FFFFFFFu;
+         mx = m > mx ? m : mx;
+         ovf |= s_red[k][3] >> 31;
+      }
+      Counters *c = a.cnt;
+      c->seg_nlines = lines;
+      c->seg_nheaders = hdrs;
+      /* capacity wanted next time: every slice as large as the fullest one, plus slack */
+      const uint64_t need = (uint64_t)mx * nslices + (uint64_t)nslices * 64;
+      if (need > c->need_hitlines) c->need_hitlines = need > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need;
+      if (ovf) { atomicOr(&c->overflow, 2u); hits = 0; }
+      c->seg_nhitlines = hits;
+      c->seg_nrec = hits;                                   /* (k_seg_mid's job; the slices cannot hold more than cap_hitlines) */
+      if (hits > c->need_hitlines) c->need_hitlines = hits;
+      c->seg_tmp_hits = 0;
+      lastnl = 0;
+      for (int k = 0; k < 4; k++) lastnl = s_last[k] > lastnl ? s_last[k] : lastnl;
+      c->seg_last_nl = lastnl;
+   }
+}
+
+/* Slices -> ordered (hit_start, hit_line).  tile_hits / tile_cl hold exclusive prefixes by now.
+   One workgroup per slice (k_direct). */
+__global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line)
+{
+   const Counters *c = a.cnt;
+   if (c->overflow & 2u) return;
+   const uint32_t n = a.wg_hits[blockIdx.x];
+   const uint4 *slice = a.tmp + (size_t)blockIdx.x * a.slice_cap;
+   for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      const uint4 e = slice[i];
+      const uint32_t dst = a.tile_hits[e.x] + e.y;
+      hit_start[dst] = e.z;
+      hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[e.x] + e.w + 1);      /* 1-based, reference seeq.c:377 */
+   }
+}
+
+#endif

@@ -20,7 +20,7 @@
  *   - Newlines are found exactly (SDWA byte compare + v_addc into a second mask); the rank of a hit's line
  *     is the number of newlines before the hit, so lines are numbered without ever building a line index.
  *   - Bytes outside {A,C,G,T,N,a,c,g,t,n,'\n'} alias onto table columns; such a byte sets Counters.dirty and
- *     every reported line is then verified by the exact pass (k_exact1 COUNT), exactly as for k_dfa.  On
+ *     every reported line is then verified by the exact pass (k_exact1 COUNT), and only then.  On
  *     clean input the exact pass trusts the filter.
  *
  *   - ILP2: the chunk is walked as two independent chains (bytes 0-63 warm up on the previous lane's tail, bytes
@@ -30,13 +30,31 @@
  * line (or the hit position when the line starts before the tile), line rank inside the tile} into its private
  * slice, and tile_cl[] = line starts owned, tile_hits[] (same layout as k_direct).  k_stream_reorder orders the
  * entries, k_stream_bounds finishes the unresolved ones and drops repeats of a line.
- * Only for SQ_FAIL + SQ_LINES, m + tau - 1 <= 32, automaton <= 4 000 states.
+ * Only for line mode and automata of <= 4 000 states that warm up within 32 bytes: the pattern's complete automaton
+ * (exact verdicts) or a partition filter (candidates; seeq_dfa.h).
  * What bounds it: the LDS gather unit (32 banks: 5.6 cycles per 64-lane gather), HBM hidden.
  */
 #ifndef SEEQ_STREAM_H_
 #define SEEQ_STREAM_H_
 
 #define STREAM_NW 16
+
+/* 16 bytes at an arbitrary address; bytes at or beyond `nbytes` read as '\n' (a line that the buffer
+ * cuts short ends there). */
+__device__ __forceinline__ fused_v4u dfa_load16(const uint8_t *text, uint64_t off, uint64_t nbytes)
+{
+   if (off + 16 <= nbytes) return *reinterpret_cast<const fused_v4u_unaligned *>(text + off);
+   uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll 1
+   for (int k = 15; k >= 0; k--) {
+      const uint32_t b = off + (uint64_t)k < nbytes ? (uint32_t)text[off + k] : 0x0Au;
+      w3 = (w3 << 8) | (w2 >> 24);
+      w2 = (w2 << 8) | (w1 >> 24);
+      w1 = (w1 << 8) | (w0 >> 24);
+      w0 = (w0 << 8) | b;
+   }
+   return fused_v4u{w0, w1, w2, w3};
+}
 
 #define STREAM_OR(K) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K \
                          : "=v"(ad) : "v"(state), "v"(wm))

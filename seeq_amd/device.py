@@ -68,7 +68,9 @@ class Pattern:
 
 class Scanner:
     def __init__(self, stream=None):
-        """stream: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        """stream: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None.  None and 0 (torch's
+        default stream is the legacy null stream, handle 0) both give the scanner a private stream of the default,
+        "blocking" kind: HIP orders it after work already queued on the null stream and the null stream after it."""
         self._lib = _capi.lib()
         self._h = self._lib.seeqdevScanNew(C.c_void_p(stream) if stream else None)
         if not self._h:
@@ -95,10 +97,14 @@ class Scanner:
         _check(self._lib.seeqdevScanSetLineHint(self._h, float(avg_bytes_per_line)))
 
     def last_path(self):
-        return {1: "generic", 2: "fused", 3: "fused", 4: "fused", 5: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "generic", 3: "fused", 5: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
     def last_kernel(self):
-        return {1: "k_forward", 2: "k_fused", 3: "k_direct", 4: "k_dfa", 5: "k_stream"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "k_forward", 3: "k_direct", 5: "k_stream"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+
+    def last_filter(self):
+        """True when the last k_stream run walked a partition filter automaton (candidates verified by the exact pass)."""
+        return bool(self._lib.seeqdevScanLastFilter(self._h))
 
     def last_times_ms(self):
         ms = (C.c_float * 4)()

@@ -90,3 +90,29 @@ extern "C" long harness_dfa_stream(const uint8_t *text, size_t n, const char *ke
    seeq_dfa_free(d);
    return (long)ne;
 }
+
+// The same walk over what seeq_dfa_plan_stream() (parts == 0) or seeq_dfa_build_filter(parts >= 2) builds: a partition
+// FILTER automaton flags candidates -- every line with a hit must get at least one event, lines without may get some.
+// info[0..3] = states, parts, warm-up bytes, accept rate * 1e9.  Returns -1 when nothing fits.
+extern "C" long harness_dfa_filter(const uint8_t *text, size_t n, const char *keys, int m, int tau, int parts, int chunk,
+                                   uint64_t *out, size_t cap, uint32_t *info)
+{
+   seeq_dfa_t *d = parts >= 2 ? seeq_dfa_build_filter(keys, m, tau, parts) : seeq_dfa_plan_stream(keys, m, tau, 0);
+   if (!d) return -1;
+   if (info) { info[0] = d->nstates; info[1] = (uint32_t)d->nparts; info[2] = (uint32_t)d->warm; info[3] = (uint32_t)(d->p_accept * 1e9); }
+   const int warm = d->warm;
+   size_t ne = 0;
+   for (size_t c0 = 0; c0 < n; c0 += (size_t)chunk) {
+      uint32_t state = 0;
+      for (long long p = (long long)c0 - warm; p < (long long)c0 + chunk && p < (long long)n; p++) {
+         const uint8_t b = p < 0 ? (uint8_t)'\n' : text[p];
+         state = d->table[(state ^ (uint32_t)(b & 0xE)) >> 1];
+         if (p >= (long long)c0 && state == d->acc_final) {
+            if (ne < cap) out[ne] = (uint64_t)p;
+            ne++;
+         }
+      }
+   }
+   seeq_dfa_free(d);
+   return (long)ne;
+}

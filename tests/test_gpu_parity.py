@@ -112,13 +112,12 @@ def test_long_pattern_words(gpu, capi, oracle):
 
 def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=None):
     """One batched scan through the device C-ABI.  path: 'generic' (newline index + k_forward<W>),
-    'fused' = k_direct (text in registers), 'fused-lds' = k_fused (text tiles in LDS), 'fused-dfa' = k_dfa and
-    'fused-stream' = k_stream (transition table in LDS; default options only, k_direct otherwise; for k_stream
-    `tile` is the chunk size per lane), or 'auto' (the library's own choice); the env knobs are read by the
-    library when the scan runs."""
+    'fused' = k_direct (one line per lane, text in registers), 'fused-stream' = k_stream (transition table in LDS:
+    the pattern's complete automaton or a partition filter; k_direct when neither fits; `tile` is the chunk size
+    per lane), or 'auto' (the library's own choice); the env knobs are read when the scan context is created."""
     from seeq_amd import device as dev
     if path != "auto":
-        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-lds": "lds", "fused-dfa": "dfa", "fused-stream": "stream"}.get(path, "direct")
+        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream"}.get(path, "direct")
     if tile and path == "fused-stream":
         os.environ["SEEQ_STREAM_CH"] = str(tile)
     elif tile:
@@ -131,6 +130,7 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
         res = sc.scan_host(pat, bytes(buf), opt | (dev.SEEQDEV_FASTA if fasta else 0), want)
         res["path"] = sc.last_path()
         res["kernel"] = sc.last_kernel()
+        res["filter"] = sc.last_filter()
         sc.close()
         pat.close()
     finally:
@@ -141,8 +141,7 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
     return res
 
 
-@pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024), ("fused-lds", None),
-                                       ("fused-lds", 4096), ("fused-dfa", None), ("fused-dfa", 1024),
+@pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024),
                                        ("fused-stream", None), ("fused-stream", 64)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
@@ -158,10 +157,12 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
             exp = oracle.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
             got = _scan(capi, pattern, tau, buf, mo | nd, dev.WANT_RECORDS, fasta, path, tile)
             assert got["path"] == (path.split("-")[0] if fusable else "generic")     # the kernel under test really ran
-            if path == "fused-dfa" and nd == SQ_FAIL and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
-                assert got["kernel"] == "k_dfa"
             if path == "fused-stream" and nd == SQ_FAIL and not fasta and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
-                assert got["kernel"] == "k_stream"
+                assert got["kernel"] == "k_stream" and not got["filter"]
+            if path == "fused-stream" and tile is None and nd == SQ_FAIL and pattern == PAT40:
+                assert got["kernel"] == "k_stream" and got["filter"]      # configs[4]: partition filter automaton
+            if path == "fused":
+                assert got["kernel"] == "k_direct"
             assert got["nlines"] == exp["nlines"]
             assert got["nmatchlines"] == exp["nmatchlines"]
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (name, mo, nd)
@@ -173,7 +174,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
         assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
 
 
-@pytest.mark.parametrize("path", ["generic", "fused", "fused-lds", "fused-dfa", "fused-stream"])
+@pytest.mark.parametrize("path", ["generic", "fused", "fused-stream"])
 def test_edge_buffers(gpu, capi, oracle, path):
     """Empty / ragged / maximum-ish inputs: no trailing newline, empty lines, NUL and CR bytes, a line longer
     than the LDS window (fused: falls back to the HBM per-line scan), 70 k empty lines (fused: many passes
@@ -189,11 +190,11 @@ def test_edge_buffers(gpu, capi, oracle, path):
     for buf in cases:
         for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
             exp = oracle.buffer_scan("ACGT", 1, buf, opt)
-            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, {"fused": 1024, "fused-lds": 4096, "fused-dfa": 1024, "fused-stream": 64}.get(path))
+            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, {"fused": 1024, "fused-stream": 64}.get(path))
             assert got["nlines"] == exp["nlines"], (buf[:20], opt)
             assert got["nmatchlines"] == exp["nmatchlines"], (buf[:20], opt)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (buf[:20], opt)
-            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, {"fused": 1024, "fused-lds": 4096, "fused-dfa": 1024, "fused-stream": 64}.get(path))
+            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, {"fused": 1024, "fused-stream": 64}.get(path))
             assert cnt["nmatchlines"] == exp["nmatchlines"] and cnt["nlines"] == exp["nlines"]
 
 
@@ -241,6 +242,7 @@ def test_device_resident_scan_large_properties(gpu, capi, oracle):
     t = torch.empty(n * (length + 1), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     dev.synth_reads(t.data_ptr(), 0, n, length, PAT20, 3, stream=stream)
+    torch.cuda.synchronize()                         # (the scanner's stream is ordered behind the null stream anyway)
     pat = dev.Pattern(PAT20, 3)
     sc = dev.Scanner(stream)
     whole = sc.scan_tensor(pat, t, SQ_BEST, dev.WANT_RECORDS)
@@ -836,3 +838,85 @@ def test_mixed_reads_and_long_line(gpu, capi, oracle):
         assert got["kernel"] == "k_stream"
         assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], mo
         assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), mo
+
+
+def test_scanner_reused_across_patterns(gpu, capi, oracle):
+    """One Scanner, many patterns created and freed in turn (a freed pattern's address is often handed out again):
+    the per-context EQ table cache is keyed on the pattern's generation id, so every scan uses its own pattern."""
+    from seeq_amd import device as dev
+    buf = open(os.path.join(GOLDEN, "reads_small.txt"), "rb").read()
+    sc = dev.Scanner()
+    rng = random.Random(5)
+    for i in range(12):
+        m = rng.choice([8, 12, 20, 28])
+        pattern = "".join(rng.choice("ACGT") for _ in range(m)) if i % 3 else PAT20[:m]
+        tau = rng.randint(1, 3)
+        pat = dev.Pattern(pattern, tau)
+        exp = oracle.buffer_scan(pattern, tau, buf, SQ_ALL)
+        got = sc.scan_host(pat, buf, SQ_ALL, dev.WANT_RECORDS)
+        assert got["nmatchlines"] == exp["nmatchlines"], (i, pattern, tau)
+        assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (i, pattern, tau)
+        pat.close()
+    # the per-line kernels are the ones that read the EQ table in their scan loop
+    os.environ["SEEQ_FUSED_KERNEL"] = "direct"
+    try:
+        sc2 = dev.Scanner()
+        for i in range(8):
+            pattern = "".join(rng.choice("ACGT") for _ in range(20))
+            pat = dev.Pattern(pattern if i % 2 else PAT20, 3)
+            exp = oracle.buffer_scan(pat.pattern, 3, buf, SQ_BEST)
+            got = sc2.scan_host(pat, buf, SQ_BEST, dev.WANT_RECORDS)
+            assert sc2.last_kernel() == "k_direct"
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (i, pat.pattern)
+            pat.close()
+        sc2.close()
+    finally:
+        os.environ.pop("SEEQ_FUSED_KERNEL", None)
+    sc.close()
+
+
+def test_filter_automaton_patterns(gpu, capi, oracle):
+    """Patterns whose complete automaton does not fit LDS run k_stream over a partition FILTER automaton; every hit line
+    it flags is verified by the exact pass.  configs[4]'s pattern plus random class/N patterns of 24..62 positions at
+    distances 2..6, reads with planted copies at 0..tau+2 edits, N, lower case and (SQ_FAIL) a few non-DNA bytes:
+    FIRST / BEST / ALL records and both counts against the oracle, and the filter really is what ran."""
+    from seeq_amd import device as dev
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(404)
+    cases = [(PAT40, 5), ("GATGTAGCGCGATTAGCCTGAAAA", 3), (PAT20, 4), ("GATGAAGCACGATTAGCCTGAAAATGAGAG", 5)]
+    for _ in range(8):
+        m = rng.choice([24, 31, 40, 50, 62])
+        cases.append(("".join("N" if rng.random() < 0.05 else "[" + "".join(rng.sample("ACGT", 2)) + "]"
+                              if rng.random() < 0.08 else rng.choice("ACGT") for _ in range(m)), rng.randint(2, 6)))
+    nfilter = 0
+    for ci, (pattern, tau) in enumerate(cases):
+        core = plain(pattern)
+        lines = []
+        for i in range(3000):
+            n = rng.choice([0, 20, 150, 250, 400])
+            t = "".join(rng.choice("ACGT") for _ in range(n))
+            if i % 4 == 0 and n >= len(core):
+                cp = mutate(rng, core, rng.randint(0, tau + 2))
+                q = rng.randrange(n - len(cp) + 1) if n >= len(cp) else 0
+                t = (t[:q] + cp + t[q + len(cp):])[:n]
+            if i % 41 == 0 and n:
+                q = rng.randrange(n); t = t[:q] + "N" + t[q + 1:]
+            if ci % 3 == 2 and i % 53 == 0 and n:
+                q = rng.randrange(n); t = t[:q] + rng.choice("!*RJ+.\t") + t[q + 1:]
+            lines.append(t.lower() if i % 29 == 0 else t)
+        buf = ("\n".join(lines) + ("\n" if ci % 2 else "")).encode()
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = oracle.buffer_scan(pattern, tau, buf, mo)
+            got = _scan(capi, pattern, tau, buf, mo, dev.WANT_RECORDS)
+            nfilter += got["filter"]
+            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, tau, mo)
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, mo)
+        expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL)
+        c1 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTLINES)
+        c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH)
+        assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], (pattern, tau)
+        assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau)
+        if ci < 4:
+            assert got["kernel"] == "k_stream" and got["filter"], (pattern, tau, got["kernel"])
+    assert nfilter >= 20, nfilter

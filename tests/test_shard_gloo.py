@@ -1,13 +1,19 @@
-"""CPU: the N>1 path (line sharding + count all-reduce + line-number base) with world_size 2 over gloo.
-On the GPU box the same code runs over RCCL; here each rank counts its shard with the oracle."""
+"""The N>1 path: line sharding + count all-reduce + line-number base, world_size 2 over gloo.
+
+CPU (`-m "not gpu"`): each rank counts its shard with the oracle -- this checks the sharding arithmetic, the
+collectives and the merge.  GPU (`-m gpu`): the SAME worker with the HIP path as the ranks' scanner (two processes on
+the one GPU of the test box, gloo for the 24-byte count reduce; on a multi-GPU node bench.py runs it over RCCL), plus
+single-process tests that scan the shards of one buffer cut mid-file on two scan contexts and compare the merged
+records and line numbers with the oracle on the whole buffer."""
 import os
 import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import GOLDEN, ROOT
 
 PAT, TAU, N, LEN = "GATGTAGCGCGATTAGCCTG", 3, 6001, 150
 
@@ -20,21 +26,36 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _scan_shard(kind, buf, opt, fasta=False):
+    """The ranks' scanner: 'oracle' (CPU checker) or 'hip' (the product: device C-ABI on cuda:0)."""
+    if kind == "oracle":
+        from oracle.pyoracle import Oracle
+        res = Oracle().buffer_scan(PAT, TAU, buf, opt, fasta=fasta)
+        return dict(nlines=res["nlines"], nmatchlines=res["nmatchlines"], nhits=len(res["records"]), records=res["records"])
+    from seeq_amd import device as dev
+    pat = dev.Pattern(PAT, TAU)
+    sc = dev.Scanner()
+    res = sc.scan_host(pat, bytes(buf), opt | (dev.SEEQDEV_FASTA if fasta else 0), dev.WANT_RECORDS)
+    assert sc.last_kernel() in ("k_stream", "k_direct")
+    sc.close()
+    pat.close()
+    return res
+
+
+def _worker(rank, world, port, out, kind):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from oracle.pyoracle import Oracle
     from seeq_amd import shard
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    orc = Oracle()
     first, count = shard.shard_range(N, rank, world)
-    buf = orc.synth_reads(first, count, LEN, PAT, TAU)
-    res = orc.buffer_scan(PAT, TAU, buf, 1)
-    local = dict(nlines=res["nlines"], nmatchlines=res["nmatchlines"], nhits=len(res["records"]))
+    buf = Oracle().synth_reads(first, count, LEN, PAT, TAU)
+    res = _scan_shard(kind, buf, 1)
+    local = dict(nlines=res["nlines"], nmatchlines=res["nmatchlines"], nhits=res["nhits"])
     total = shard.reduce_counts(local)
     base = shard.line_base(local["nlines"])
-    out.put((rank, first, count, local, total, base))
+    out.put((rank, first, count, local, total, base, np.asarray(res["records"], dtype=np.uint64)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,19 +71,115 @@ def test_shard_ranges():
             assert max(c for _, c in r) - min(c for _, c in r) <= 1
 
 
-def test_two_rank_count_reduce(oracle):
+def _two_ranks(oracle, kind):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=120) for _ in range(world))
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda g: g[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     whole = oracle.buffer_scan(PAT, TAU, oracle.synth_reads(0, N, LEN, PAT, TAU), 1)
-    for rank, first, count, local, total, base in got:
+    merged = []
+    for rank, first, count, local, total, base, rec in got:
         assert total == dict(nlines=N, nmatchlines=whole["nmatchlines"], nhits=len(whole["records"]))
         assert base == first                      # one line per read: line base == first read index
+        r = rec.copy()
+        r[:, 0] += base                           # rank-local line numbers -> global (records stay rank-local otherwise)
+        merged.append(r)
     assert sum(g[3]["nmatchlines"] for g in got) == whole["nmatchlines"]
+    assert np.array_equal(np.concatenate(merged), whole["records"])
+
+
+def test_two_rank_count_reduce(oracle):
+    _two_ranks(oracle, "oracle")
+
+
+@pytest.mark.gpu
+def test_two_rank_count_reduce_hip(gpu, oracle):
+    """world_size 2 with the HIP path as every rank's scanner (both ranks on this box's one GPU)."""
+    _two_ranks(oracle, "hip")
+
+
+def _cut_cases():
+    fa = open(os.path.join(GOLDEN, "fasta_small.txt"), "rb").read()
+    fq = open(os.path.join(GOLDEN, "fastq_small.txt"), "rb").read()
+    rd = open(os.path.join(GOLDEN, "reads_small.txt"), "rb").read()
+    return [("reads", rd, False), ("fastq", fq, False), ("fasta", fa, True), ("reads-no-trailing-newline", rd[:-1], False)]
+
+
+def test_cut_at_newlines_and_merge(oracle):
+    """Byte-range sharding of real files: cuts land right after a newline; the merged per-shard oracle results equal
+    the oracle on the whole buffer -- counts, records and line numbers, FASTA headers discounted across the cuts."""
+    from seeq_amd import shard
+    for name, buf, fasta in _cut_cases():
+        whole = oracle.buffer_scan(PAT, TAU, buf, 2, fasta=fasta)
+        for world in (1, 2, 3, 8):
+            ranges = shard.cut_at_newlines(buf, world)
+            assert ranges[0][0] == 0 and ranges[-1][1] == len(buf)
+            assert all(ranges[k][1] == ranges[k + 1][0] for k in range(world - 1))
+            assert all(hi == lo or hi == len(buf) or buf[hi - 1:hi] == b"\n" for lo, hi in ranges)
+            parts = []
+            for lo, hi in ranges:
+                r = oracle.buffer_scan(PAT, TAU, buf[lo:hi], 2, fasta=fasta)
+                parts.append(dict(nlines=r["nlines"], nmatchlines=r["nmatchlines"], nhits=len(r["records"]), records=r["records"]))
+            m = shard.merge_results(parts)
+            assert m["nlines"] == whole["nlines"] and m["nmatchlines"] == whole["nmatchlines"], (name, world)
+            assert np.array_equal(m["records"], whole["records"]), (name, world)
+    # a FASTA buffer cut so that a header is the first line of the second shard, and one where it is the last of the first
+    fa = b">h1\nACGT\n>h2 " + PAT.encode() + b"\n" + PAT.encode() + b"\nACGT\n"
+    for cutpos in (fa.index(b">h2"), fa.index(PAT.encode() + b"\nACGT")):
+        parts = []
+        for piece in (fa[:cutpos], fa[cutpos:]):
+            r = oracle.buffer_scan(PAT, TAU, piece, 2, fasta=True)
+            parts.append(dict(nlines=r["nlines"], nmatchlines=r["nmatchlines"], nhits=len(r["records"]), records=r["records"]))
+        whole = oracle.buffer_scan(PAT, TAU, fa, 2, fasta=True)
+        assert np.array_equal(shard.merge_results(parts)["records"], whole["records"])
+
+
+@pytest.mark.gpu
+def test_two_contexts_cut_mid_file_hip(gpu, capi, oracle):
+    """The HIP path on the shards of one buffer cut mid-file, each shard on its own scan context (what a rank per GPU
+    does), merged on the host: records, line numbers and counts equal the oracle on the whole buffer -- reads, FASTQ,
+    FASTA (a header right at the cut), no trailing newline, FIRST / BEST / ALL."""
+    from seeq_amd import device as dev
+    from seeq_amd import shard
+    pat = dev.Pattern(PAT, TAU)
+    ctx = [dev.Scanner(), dev.Scanner(), dev.Scanner()]
+    fa_cut = b">h1\nACGT\n>h2 " + PAT.encode() + b"\n" + PAT.encode() + b"\nACGT\n" + b">h3\n" + PAT.encode()[:18] + b"\n"
+    for name, buf, fasta in _cut_cases() + [("fasta-header-at-cut", fa_cut, True)]:
+        for opt in (0, 1, 2):
+            whole = oracle.buffer_scan(PAT, TAU, buf, opt, fasta=fasta)
+            for world in (2, 3):
+                ranges = shard.cut_at_newlines(buf, world)
+                if name == "fasta-header-at-cut" and world == 2:
+                    c = buf.index(b">h2")
+                    ranges = [(0, c), (c, len(buf))]
+                parts = [ctx[k].scan_host(pat, buf[lo:hi], opt | (dev.SEEQDEV_FASTA if fasta else 0), dev.WANT_RECORDS)
+                         for k, (lo, hi) in enumerate(ranges)]
+                m = shard.merge_results(parts)
+                assert m["nlines"] == whole["nlines"] and m["nmatchlines"] == whole["nmatchlines"], (name, opt, world)
+                assert np.array_equal(m["records"], whole["records"]), (name, opt, world)
+    for c in ctx:
+        c.close()
+    pat.close()
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(gpu):
+    """`bench.py --gpus 2` without a launcher starts two ranks itself (here both on GPU 0, gloo collectives:
+    SEEQ_BENCH_SHARE_GPU=1) and prints one line with n_gpus 2 and both ranks' lines in the total."""
+    import json
+    import subprocess
+    env = dict(os.environ, SEEQ_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "300000", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-per-call", "--check-lines", "100000"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["results"]["lines"] == 600000
+    assert line["results"]["oracle_lines_checked"] >= 100000
