@@ -131,6 +131,13 @@ void   seeqdevHostFree(void * p);
 int seeqdevScanHost(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * host_text, size_t nbytes,
                     int options, int want, seeqdev_counts_t * counts);
 
+/* One string in ONE kernel launch -- what seeqStringMatch (reference libseeq.c:171-352, called once per string by
+ * seeqmodule.c:858) runs on: data[0..n) is staged (short strings are read by the kernel straight from page-locked
+ * host memory), scanned with `options` (libseeq.h match / non-DNA / input bits; SINGLELINE semantics) and the hits
+ * land in page-locked host memory: *rec (left to right, valid until the next call on this context), *nrec. */
+int seeqdevStringMatch(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * data, size_t n, int options,
+                       const seeqdev_hit_t ** rec, size_t * nrec);
+
 /* Device time (ms) of the last fetched scan, measured with HIP events recorded
  * on the scan's stream around each phase of each segment (no extra
  * synchronisation): [0] newline index, [1] forward scan = the k_forward

@@ -148,8 +148,8 @@ int seeq_store_hits(seeq_t *sq, const seeqdev_hit_t *rec, size_t n)
    return 0;
 }
 
-/* reference libseeq.c:171-352: one string, on the GPU. */
-#define SEEQ_LONG_STRING ((size_t)1 << 18)                  /* 256 KiB */
+/* reference libseeq.c:171-352: one string, on the GPU, in one launch (seeqdevStringMatch). */
+#define SEEQ_LONG_STRING ((size_t)1 << 15)                  /* 32 KiB */
 
 long seeqStringMatch(const char *data, seeq_t *sq, int options)
 {
@@ -161,10 +161,17 @@ long seeqStringMatch(const char *data, seeq_t *sq, int options)
    if (!scan) return -1;
    const size_t n = strlen(data);                              /* reference libseeq.c:245 */
    /* A long string (a chromosome handed to seeqStringMatch / the Python module) goes through the batched line
-      scan instead of the one-lane single-line kernels: in line mode a '\n' ends the string just as it does here
+      scan instead of the one-lane string kernel: in line mode a '\n' ends the string just as it does here
       (libseeq.c:267-270), so the string's hits are exactly the records of line 1. */
-   const int as_lines = n >= SEEQ_LONG_STRING && !(options & MASK_INPUT);
-   const int dev_opt = (options & (MASK_MATCH | MASK_NONDNA | MASK_INPUT)) | (as_lines ? 0 : SEEQDEV_SINGLELINE);
+   const int as_lines = n >= SEEQ_LONG_STRING && !(options & MASK_INPUT) && sq->wlen <= 62;
+   const int dev_opt = options & (MASK_MATCH | MASK_NONDNA | MASK_INPUT);
+   if (!as_lines) {
+      const seeqdev_hit_t *rec = NULL;
+      size_t nrec = 0;
+      if (seeqdevStringMatch(scan, eng->pat, data, n, dev_opt, &rec, &nrec)) return -1;
+      if (seeq_store_hits(sq, rec, nrec)) return -1;
+      return (long)sq->hits;                                   /* reference libseeq.c:351 */
+   }
    seeqdev_counts_t cnt;
    if (seeqdevScanHost(scan, eng->pat, data, n, dev_opt, SEEQDEV_WANT_RECORDS, &cnt)) return -1;
    if (cnt.nrecords > eng->rec_cap) {
@@ -174,12 +181,9 @@ long seeqStringMatch(const char *data, seeq_t *sq, int options)
       eng->rec_cap = cnt.nrecords;
    }
    if (seeqdevScanCopyRecords(scan, eng->rec, 0, cnt.nrecords)) return -1;
-   if (as_lines) {                                             /* records are ordered by line: keep line 1 */
-      uint64_t k = 0;
-      while (k < cnt.nrecords && eng->rec[k].line == 1) k++;
-      cnt.nrecords = k;
-   }
-   if (seeq_store_hits(sq, eng->rec, cnt.nrecords)) return -1;
+   uint64_t k = 0;                                             /* records are ordered by line: keep line 1 */
+   while (k < cnt.nrecords && eng->rec[k].line == 1) k++;
+   if (seeq_store_hits(sq, eng->rec, k)) return -1;
    return (long)sq->hits;                                      /* reference libseeq.c:351 */
 }
 

@@ -131,6 +131,8 @@ struct ScanArgs {
 static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
 static constexpr size_t FUSED_MIN_TILE = 512;    /* smallest text tile / region of the one-pass kernels */
+static constexpr int STREAM_TPW = 8;              /* k_stream, overlapped segments: tiles per wave of a short-lived workgroup */
+static constexpr int STREAM_NW_HOST = 16;         /* = STREAM_NW (seeq_stream.h): waves per k_stream workgroup */
 static constexpr size_t MAX_FUSED_GRID = 16384;   /* upper bound of the waves (= hit slices) of a persistent scan grid */
 static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate the line length */
 
@@ -537,6 +539,7 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_stream.h"
+static_assert(STREAM_NW == STREAM_NW_HOST, "waves per k_stream workgroup");
 extern "C" {
 #include "seeq_dfa.h"
 }
@@ -698,6 +701,7 @@ struct ScanKnobs {
    int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
+   bool no_overlap;      /* SEEQ_OVERLAP=0: segments strictly one after the other on one stream */
 };
 
 struct OccMemo { const void *fn; size_t lds; int per_cu; };
@@ -713,12 +717,21 @@ struct seeqdev_scan {
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
-   uint32_t *hit_start, *hit_line, *nh, *hit_col; uint4 *tmp; size_t cap_hitlines;
-   /* fused path */
-   uint32_t *tile_cl, *tile_hits, *tile_dirty; uint64_t *tile_dmask; size_t cap_ftiles;
-   uint32_t *wg_hits;             /* [MAX_FUSED_GRID] */
-   uint32_t *wg_part;             /* [3 * MAX_FUSED_GRID] */
-   uint32_t *wg_lastnl;           /* [MAX_FUSED_GRID] k_stream: last newline seen by each wave */
+   uint32_t *hit_start, *hit_line, *nh, *hit_col; size_t cap_hitlines;
+   /* one-pass kernels: what the scan kernel of a segment writes and its post-pass reads.  Two sets: with more than one
+      segment k_stream of segment k+1 runs (on its own stream) while the post-pass of segment k is still at work. */
+   struct OnePassWs {
+      uint32_t *tile_cl, *tile_hits, *tile_dirty; uint64_t *tile_dmask;   /* [cap_ftiles] */
+      uint4    *tmp;                 /* [cap_hitlines] hit slices, then the COUNT -> EMIT cache */
+      uint32_t *wg_hits;             /* [cap_slices] */
+      uint32_t *wg_part;             /* [4 * cap_slices] */
+      uint32_t *wg_lastnl;           /* [cap_slices] k_stream: last newline seen by each wave */
+   } ow[2];
+   size_t cap_ftiles, cap_slices;
+   bool   two_sets;                  /* ow[1] is allocated */
+   hipStream_t sp;                   /* overlap: the post-pass stream (high priority); the scan kernels stay on `stream` */
+   hipEvent_t  ev_scan[2], ev_post[2], ev_end;
+   bool        have_streams;
    uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
    unsigned long eq_pat_id; int eq_options;   /* what d_eqtab holds (pattern generation id, option bits) */
    double avg_line;               /* average bytes per line incl. newline (hint or sampled) */
@@ -731,6 +744,9 @@ struct seeqdev_scan {
    uint32_t *scan_ws;           size_t cap_scan_ws;
    Counters *d_cnt;
    Counters *h_cnt;            /* pinned */
+   /* seeqdevStringMatch: one string per call in ONE launch (pinned, device-visible) */
+   uint8_t *h_str; size_t cap_str;            /* the string (strings below STRING_ZC_MAX are read by the kernel over the link) */
+   uint32_t *h_strout; size_t cap_strout;     /* {nhits, pad[3]} + records */
    /* staging for seeqdevScanHost */
    uint8_t *d_text; size_t cap_text;
    /* last run (for the transparent re-run on overflow) */
@@ -786,9 +802,6 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 1024 * sizeof(uint32_t), hipHostMallocDefault);
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 1024 * sizeof(uint32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
-   if (e == hipSuccess) e = hipMalloc((void **)&s->wg_hits, MAX_FUSED_GRID * sizeof(uint32_t));
-   if (e == hipSuccess) e = hipMalloc((void **)&s->wg_part, 3 * MAX_FUSED_GRID * sizeof(uint32_t));
-   if (e == hipSuccess) e = hipMalloc((void **)&s->wg_lastnl, MAX_FUSED_GRID * sizeof(uint32_t));
    {
       const char *pe = getenv("SEEQ_PATH");
       s->force_path = pe ? (!strcmp(pe, "generic") ? 1 : !strcmp(pe, "fused") ? 2 : 0) : 0;
@@ -801,6 +814,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_TILE_BYTES");   kn.tile_bytes = v ? atoi(v) : 0;
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
+      v = getenv("SEEQ_OVERLAP");      kn.no_overlap = v && atoi(v) == 0;
       s->ncu = 256;
       int dev = 0;
       hipDeviceProp_t prop;
@@ -819,13 +833,25 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
 {
    if (!s) return;
    (void)hipStreamSynchronize(s->stream);
-   void *bufs[] = {s->rec_off, s->wg_hits, s->wg_part, s->wg_lastnl, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
-                   s->hit_line, s->tmp, s->tile_cl, s->tile_hits, s->tile_dirty, s->tile_dmask, s->d_eqtab,
+   if (s->have_streams) {
+      for (int i = 0; i < 2; i++) { (void)hipEventDestroy(s->ev_scan[i]); (void)hipEventDestroy(s->ev_post[i]); }
+      (void)hipStreamSynchronize(s->sp); (void)hipStreamDestroy(s->sp);
+      (void)hipEventDestroy(s->ev_end);
+   }
+   for (int i = 0; i < 2; i++) {
+      void *ob[] = {s->ow[i].tile_cl, s->ow[i].tile_hits, s->ow[i].tile_dirty, s->ow[i].tile_dmask, s->ow[i].tmp, s->ow[i].wg_hits,
+                    s->ow[i].wg_part, s->ow[i].wg_lastnl};
+      for (void *b : ob) if (b) (void)hipFree(b);
+   }
+   void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+                   s->hit_line, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
    if (s->h_eqtab) (void)hipHostFree(s->h_eqtab);
    if (s->h_sample) (void)hipHostFree(s->h_sample);
+   if (s->h_str) (void)hipHostFree(s->h_str);
+   if (s->h_strout) (void)hipHostFree(s->h_strout);
    for (size_t i = 0; i < 4 * s->nev_seg; i++) (void)hipEventDestroy(s->ev[i]);
    free(s->ev);
    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -845,12 +871,27 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
          s->cap_tiles = tiles;
       }
       const size_t ftiles = seg / FUSED_MIN_TILE + 2;
+      /* hit slices: one per wave of a persistent grid (<= MAX_FUSED_GRID), or per wave of k_stream's short-lived
+         workgroups (STREAM_TPW tiles of >= 4 KiB each) */
+      size_t slices = (seg / 4096 / (STREAM_NW_HOST * STREAM_TPW) + 2) * STREAM_NW_HOST;
+      if (slices < MAX_FUSED_GRID) slices = MAX_FUSED_GRID;
+      const int nsets = s->two_sets ? 2 : 1;
       if (ftiles > s->cap_ftiles) {
-         if (ws_alloc((void **)&s->tile_cl, ftiles * sizeof(uint32_t))) return -1;
-         if (ws_alloc((void **)&s->tile_dirty, ftiles * sizeof(uint32_t))) return -1;
-         if (ws_alloc((void **)&s->tile_dmask, ftiles * sizeof(uint64_t))) return -1;
-         if (ws_alloc((void **)&s->tile_hits, ftiles * sizeof(uint32_t))) return -1;
+         for (int i = 0; i < nsets; i++) {
+            if (ws_alloc((void **)&s->ow[i].tile_cl, ftiles * sizeof(uint32_t))) return -1;
+            if (ws_alloc((void **)&s->ow[i].tile_dirty, ftiles * sizeof(uint32_t))) return -1;
+            if (ws_alloc((void **)&s->ow[i].tile_dmask, ftiles * sizeof(uint64_t))) return -1;
+            if (ws_alloc((void **)&s->ow[i].tile_hits, ftiles * sizeof(uint32_t))) return -1;
+         }
          s->cap_ftiles = ftiles;
+      }
+      if (slices > s->cap_slices) {
+         for (int i = 0; i < nsets; i++) {
+            if (ws_alloc((void **)&s->ow[i].wg_hits, slices * sizeof(uint32_t))) return -1;
+            if (ws_alloc((void **)&s->ow[i].wg_part, 4 * slices * sizeof(uint32_t))) return -1;
+            if (ws_alloc((void **)&s->ow[i].wg_lastnl, slices * sizeof(uint32_t))) return -1;
+         }
+         s->cap_slices = slices;
       }
    }
    if (max_lines > s->cap_lines) {
@@ -866,7 +907,8 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
    if (max_hitlines > s->cap_hitlines) {
       if (ws_alloc((void **)&s->hit_start, max_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->hit_line, max_hitlines * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&s->tmp, max_hitlines * sizeof(uint4))) return -1;
+      for (int i = 0; i < (s->two_sets ? 2 : 1); i++)
+         if (ws_alloc((void **)&s->ow[i].tmp, max_hitlines * sizeof(uint4))) return -1;
       if (ws_alloc((void **)&s->nh, max_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->hit_col, max_hitlines * sizeof(uint32_t))) return -1;
       s->cap_hitlines = max_hitlines;
@@ -984,26 +1026,26 @@ __global__ __launch_bounds__(WG) void k_scanset_apply(ScanSet ss, const uint32_t
 
 /* ---- launch helpers ------------------------------------------------------- */
 template <int XF>
-static void launch_scan(seeqdev_scan *s, const void *in, uint32_t *out, size_t cap_items, const uint32_t *n_ptr,
+static void launch_scan(seeqdev_scan *s, hipStream_t st, const void *in, uint32_t *out, size_t cap_items, const uint32_t *n_ptr,
                         uint32_t add, uint32_t shift, uint32_t *total_out)
 {
    const unsigned nb = (unsigned)((cap_items + SCAN_BLOCK - 1) / SCAN_BLOCK);
    if (nb == 0) return;
-   hipLaunchKernelGGL(k_scan_reduce<XF>, dim3(nb), dim3(WG), 0, s->stream, in, s->scan_ws, n_ptr, add, shift);
-   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WG), 0, s->stream, s->scan_ws, n_ptr, add, shift, total_out);
-   hipLaunchKernelGGL(k_scan_apply<XF>, dim3(nb), dim3(WG), 0, s->stream, in, out, (const uint32_t *)s->scan_ws,
+   hipLaunchKernelGGL(k_scan_reduce<XF>, dim3(nb), dim3(WG), 0, st, in, s->scan_ws, n_ptr, add, shift);
+   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WG), 0, st, s->scan_ws, n_ptr, add, shift, total_out);
+   hipLaunchKernelGGL(k_scan_apply<XF>, dim3(nb), dim3(WG), 0, st, in, out, (const uint32_t *)s->scan_ws,
                       n_ptr, add, shift);
 }
 
-static void launch_scanset(seeqdev_scan *s, uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t n, uint32_t *t0, uint32_t *t1, uint32_t *t2)
+static void launch_scanset(seeqdev_scan *s, hipStream_t st, uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t n, uint32_t *t0, uint32_t *t1, uint32_t *t2)
 {
    const unsigned nb = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
    if (nb == 0) return;
    ScanSet ss = {{a0, a1, a2}, {t0, t1, t2}};
    const unsigned na = a2 ? 3 : a1 ? 2 : 1;
-   hipLaunchKernelGGL(k_scanset_reduce, dim3(nb, na), dim3(WG), 0, s->stream, ss, s->scan_ws, n, nb);
-   hipLaunchKernelGGL(k_scanset_top, dim3(na), dim3(WG), 0, s->stream, ss, s->scan_ws, nb);
-   hipLaunchKernelGGL(k_scanset_apply, dim3(nb, na), dim3(WG), 0, s->stream, ss, (const uint32_t *)s->scan_ws, n, nb);
+   hipLaunchKernelGGL(k_scanset_reduce, dim3(nb, na), dim3(WG), 0, st, ss, s->scan_ws, n, nb);
+   hipLaunchKernelGGL(k_scanset_top, dim3(na), dim3(WG), 0, st, ss, s->scan_ws, nb);
+   hipLaunchKernelGGL(k_scanset_apply, dim3(nb, na), dim3(WG), 0, st, ss, (const uint32_t *)s->scan_ws, n, nb);
 }
 
 /* The tile_cnt scan has a host-known length (ntiles); a dedicated small kernel
@@ -1032,6 +1074,36 @@ __global__ __launch_bounds__(WG) void k_scan_tiles(uint32_t *tile_cnt, uint32_t 
       running += tot;
    }
    if (threadIdx.x == 0) *total_out = running;
+}
+
+/* Streams, events and the second workspace set of the overlapped multi-segment scan (created on first use). */
+static int ensure_overlap(seeqdev_scan *s)
+{
+   if (!s->have_streams) {
+      int lo = 0, hi = 0;                                    /* numerically lower = higher priority */
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIP_TRY(hipStreamCreateWithPriority(&s->sp, hipStreamNonBlocking, hi), EIO);
+      HIP_TRY(hipEventCreateWithFlags(&s->ev_end, hipEventDisableTiming), EIO);
+      for (int i = 0; i < 2; i++) {
+         HIP_TRY(hipEventCreateWithFlags(&s->ev_scan[i], hipEventDisableTiming), EIO);
+         HIP_TRY(hipEventCreateWithFlags(&s->ev_post[i], hipEventDisableTiming), EIO);
+      }
+      s->have_streams = true;
+   }
+   if (!s->two_sets) {
+      HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+      seeqdev_scan::OnePassWs &o = s->ow[1];
+      if (ws_alloc((void **)&o.tile_cl, s->cap_ftiles * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&o.tile_dirty, s->cap_ftiles * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&o.tile_dmask, s->cap_ftiles * sizeof(uint64_t))) return -1;
+      if (ws_alloc((void **)&o.tile_hits, s->cap_ftiles * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&o.wg_hits, s->cap_slices * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&o.wg_part, 4 * s->cap_slices * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&o.wg_lastnl, s->cap_slices * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&o.tmp, s->cap_hitlines * sizeof(uint4))) return -1;
+      s->two_sets = true;
+   }
+   return 0;
 }
 
 /* Workgroups of `fn` (threads per workgroup, dynamic LDS) that fit one CU; asked once per kernel and LDS size.
@@ -1204,9 +1276,21 @@ static int run_segments(seeqdev_scan *s)
       s->nev_seg = nseg;
    }
    if (s->prof) s->prof_segs = nseg;
+   /* Overlap (k_stream, more than one segment): the scan kernels run back to back on the context's stream and write
+      into alternating workspace sets; every segment's post-pass (ordering, exact pass, records) runs on a second,
+      high-priority stream as soon as its scan is done -- i.e. while the NEXT segment's scan is running, whose
+      workgroups are short-lived (STREAM_TPW tiles per wave) so that the post-pass kernels find room on the CUs. */
+   const bool overlap = use_stream && nseg > 1 && !kn.no_overlap;
+   if (overlap && ensure_overlap(s)) return -1;
+   const uint32_t tpw = overlap ? (uint32_t)STREAM_TPW : 0u;
    for (size_t sg = 0; sg < nseg; sg++) {
       hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
       uint32_t stream_ntiles = 0;
+      const int wsi = overlap ? (int)(sg & 1) : 0;
+      seeqdev_scan::OnePassWs &ow = s->ow[wsi];
+      hipStream_t st_scan = s->stream;                             /* the scan kernel of this segment */
+      hipStream_t st = overlap ? s->sp : s->stream;                /* everything behind it */
+      if (overlap && sg >= 2) HIP_TRY(hipStreamWaitEvent(st_scan, s->ev_post[wsi], 0), EIO);   /* the post-pass of segment sg - 2 is done with this set */
       ScanArgs a;
       memset(&a, 0, sizeof a);
       a.text = (const uint8_t *)s->text;
@@ -1236,10 +1320,11 @@ static int run_segments(seeqdev_scan *s)
          stream_ntiles = f.ntiles;
          f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
          f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
-         f.tile_cl = s->tile_cl; f.tile_hits = s->tile_hits; f.tmp = s->tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
-         f.wg_hits = s->wg_hits; f.wg_part = s->wg_part; f.wg_lastnl = stream_ll ? s->wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
-         f.tile_dirty = f.wg_lastnl ? s->tile_dirty : nullptr;
-         f.tile_dmask = f.wg_lastnl ? s->tile_dmask : nullptr;
+         f.tile_cl = ow.tile_cl; f.tile_hits = ow.tile_hits; f.tmp = ow.tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
+         f.wg_hits = ow.wg_hits; f.wg_part = ow.wg_part; f.wg_lastnl = stream_ll ? ow.wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
+         f.tile_dirty = f.wg_lastnl ? ow.tile_dirty : nullptr;
+         f.tile_dmask = f.wg_lastnl ? ow.tile_dmask : nullptr;
+         f.tiles_per_wave = tpw;
          f.cnt = c;
          uint32_t pos_bias = 0;
          if (use_stream) {
@@ -1250,11 +1335,18 @@ static int run_segments(seeqdev_scan *s)
             pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room) & ~127u;     /* chunk boundaries stay multiples of the chunk */
             f.pos_bias = pos_bias;
          }
-         if (ev) { HIP_TRY(hipEventRecord(ev[0], s->stream), EIO); HIP_TRY(hipEventRecord(ev[1], s->stream), EIO); }
-         const unsigned fgrid = fused_grid;               /* persistent: workgroups without a tile just publish zeros */
-         f.slice_cap = f.cap_tmp / nslices;
+         if (ev) { HIP_TRY(hipEventRecord(ev[0], st_scan), EIO); HIP_TRY(hipEventRecord(ev[1], st_scan), EIO); }
+         unsigned fgrid = fused_grid;                     /* persistent: workgroups without a tile just publish zeros */
+         unsigned nsl = nslices;
+         if (tpw) {                                       /* short-lived workgroups: 16 * tpw tiles each */
+            fgrid = (unsigned)((f.ntiles + STREAM_NW * tpw - 1) / (STREAM_NW * tpw));
+            if (fgrid == 0) fgrid = 1;
+            nsl = fgrid * STREAM_NW;
+            if (nsl > s->cap_slices) { seeqerr = 0; errno = ENOMEM; snprintf(g_last_error, sizeof g_last_error, "slice table too small"); return -1; }
+         }
+         f.slice_cap = f.cap_tmp / nsl;
          if (use_stream) {
-#define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, s->stream, f)
+#define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st_scan, f)
             if (stream_ll && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true, true); }
             else if (stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true); }
             else if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false); }
@@ -1263,14 +1355,19 @@ static int run_segments(seeqdev_scan *s)
             else { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(64, 6, false, false, false); else SEEQ_STREAM_LAUNCH(64, 8, false, false, false); }
 #undef SEEQ_STREAM_LAUNCH
          }
-         else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, s->stream, f);
-         else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, s->stream, f);
-         if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
-         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, s->stream, f, (uint32_t)nslices);
+         else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st_scan, f);
+         else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st_scan, f);
+         if (ev) HIP_TRY(hipEventRecord(ev[2], st_scan), EIO);
+         if (overlap) {
+            HIP_TRY(hipEventRecord(s->ev_scan[wsi], st_scan), EIO);
+            HIP_TRY(hipStreamWaitEvent(st, s->ev_scan[wsi], 0), EIO);
+         }
+         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, st, f, (uint32_t)nsl);
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
-            launch_scanset(s, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
-            if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line, s->nh, s->hit_col);
-            else hipLaunchKernelGGL(k_fused_reorder, dim3(nslices), dim3(256), 0, s->stream, f, s->hit_start, s->hit_line);
+            launch_scanset(s, st, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
+            const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
+            if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
+            else hipLaunchKernelGGL(k_fused_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
          a.pos_bias = pos_bias;
@@ -1280,55 +1377,55 @@ static int run_segments(seeqdev_scan *s)
          a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;
       } else {
       /* ---- K0: newline index ---- */
-      if (ev) HIP_TRY(hipEventRecord(ev[0], s->stream), EIO);
+      if (ev) HIP_TRY(hipEventRecord(ev[0], st), EIO);
       if (single) {
-         hipLaunchKernelGGL(k_single_line, dim3(1), dim3(1), 0, s->stream, a);
+         hipLaunchKernelGGL(k_single_line, dim3(1), dim3(1), 0, st, a);
       } else {
-         hipLaunchKernelGGL(k_nl_count, dim3(a.ntiles), dim3(WG), 0, s->stream, a);
-         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, s->stream, a.tile_cnt, a.ntiles, &c->seg_nlines);
-         hipLaunchKernelGGL(k_index_finalize, dim3(1), dim3(1), 0, s->stream, a);
-         hipLaunchKernelGGL(k_nl_write, dim3(a.ntiles), dim3(WG), 0, s->stream, a);
+         hipLaunchKernelGGL(k_nl_count, dim3(a.ntiles), dim3(WG), 0, st, a);
+         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, st, a.tile_cnt, a.ntiles, &c->seg_nlines);
+         hipLaunchKernelGGL(k_index_finalize, dim3(1), dim3(1), 0, st, a);
+         hipLaunchKernelGGL(k_nl_write, dim3(a.ntiles), dim3(WG), 0, st, a);
       }
       /* ---- K1: forward scan ---- */
-      if (ev) HIP_TRY(hipEventRecord(ev[1], s->stream), EIO);
-      hipLaunchKernelGGL(k_forward<W>, dim3(grid_lines), dim3(WG), 0, s->stream, a);
-      if (ev) HIP_TRY(hipEventRecord(ev[2], s->stream), EIO);
+      if (ev) HIP_TRY(hipEventRecord(ev[1], st), EIO);
+      hipLaunchKernelGGL(k_forward<W>, dim3(grid_lines), dim3(WG), 0, st, a);
+      if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
       /* ---- K2: ranks of hit lines (and FASTA headers) ---- */
-      launch_scan<1>(s, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
-      if (fasta) launch_scan<1>(s, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
+      launch_scan<1>(s, st, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
+      if (fasta) launch_scan<1>(s, st, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
       }
       if (want != SEEQDEV_WANT_COUNTLINES || superset) {
          /* ---- K3: compaction ---- */
-         if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, s->stream, a);
-         if (!use_fused) hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, s->stream, a);   /* the fused paths: done by k_fused_post */
+         if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, st, a);
+         if (!use_fused) hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, st, a);   /* the fused paths: done by k_fused_post */
          const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
          if (grid_hits == 0) grid_hits = 1;
-         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, s->stream, a, s->hit_col,
-                                            (const uint32_t *)s->tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
+         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col,
+                                            (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
-         uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? s->tmp : nullptr;   /* COUNT -> EMIT */
+         uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? ow.tmp : nullptr;   /* COUNT -> EMIT */
          /* ---- K4: hits per hit line ---- */
          if (need_nh) {
             if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
-#define SEEQ_COUNT1(WW, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, WW, -1, WK>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol, ecache)
+#define SEEQ_COUNT1(WW, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, WW, -1, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
                if (fw == 2) { if (a.stream_ch) SEEQ_COUNT1(2, true); else SEEQ_COUNT1(2, false); }
                else { if (a.stream_ch) SEEQ_COUNT1(1, true); else SEEQ_COUNT1(1, false); }
 #undef SEEQ_COUNT1
             }
-            else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
+            else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, st, a);
             /* lines with >= 1 verified hit: with 0/1 verdicts that is the scan total (seg_nrec) -- no extra pass */
-            if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, s->stream, a);
-            launch_scan<0>(s, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
+            if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
+            launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */
          if (want == SEEQDEV_WANT_RECORDS) {
-            hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, s->stream, a);
+            hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);
             if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
                const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
-#define SEEQ_EMIT1(WW, OO, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO, WK>), dim3(grid_hits), dim3(WG), 0, s->stream, a, eqp, hcol, ecache)
+#define SEEQ_EMIT1(WW, OO, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
                if (a.stream_ch) {
                   if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST, true); else SEEQ_EMIT1(2, -1, true); }
                   else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST, true); else SEEQ_EMIT1(1, -1, true); }
@@ -1339,14 +1436,19 @@ static int run_segments(seeqdev_scan *s)
 #undef SEEQ_EMIT1
             }
             else {
-               hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, s->stream, a);
-               hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, s->stream, a);    /* k_exact1 writes them itself */
+               hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, st, a);
+               hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, st, a);    /* k_exact1 writes them itself */
             }
          }
       }
-      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, s->stream, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));
-      if (ev) HIP_TRY(hipEventRecord(ev[3], s->stream), EIO);
+      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));
+      if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
+      if (overlap) HIP_TRY(hipEventRecord(s->ev_post[wsi], st), EIO);
       HIP_TRY(hipGetLastError(), EIO);
+   }
+   if (overlap) {                                         /* the caller's stream continues behind the last post-pass */
+      HIP_TRY(hipEventRecord(s->ev_end, s->sp), EIO);
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_end, 0), EIO);
    }
    HIP_TRY(hipMemcpyAsync(s->h_cnt, c, sizeof(Counters), hipMemcpyDeviceToHost, s->stream), EIO);
    return 0;
@@ -1508,3 +1610,110 @@ extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, 
 }
 
 extern "C" int seeqdevScanLastLaunches(const seeqdev_scan_t *s) { return s ? (int)s->prof_segs : 0; }
+
+/* ========================================================================== */
+/* One string, one launch: seeqStringMatch (reference libseeq.c:171-352)        */
+/* ========================================================================== */
+/* The per-string entry point is what the reference's Python module calls for every string (seeqmodule.c:858).  One
+ * workgroup: all threads stage the string (read over the link from page-locked host memory when it is short, else
+ * from HBM) and the tables into LDS, then one lane runs the line scan -- forward column, acceptance rules, reverse
+ * start recovery -- and writes count + records straight into page-locked host memory.  One launch, one stream
+ * synchronisation, no device allocation.  Long strings in line mode take the batched scan instead (libseeq_api.c). */
+static constexpr uint32_t STRING_LDS_MAX = 48u * 1024;      /* strings up to this are staged in LDS */
+static constexpr uint32_t STRING_ZC_MAX = 4096;             /* ... and up to this read straight from host memory */
+
+template <int W>
+__global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, const uint32_t *peq, int m, int tau, int options,
+                                               uint32_t *out, uint32_t cap)
+{
+   extern __shared__ __align__(16) uint8_t s_text[];       /* n + 16 bytes when staged */
+   __shared__ uint32_t s_peq[10 * W];
+   __shared__ uint8_t s_lut[256];
+   const int Wp = (m + 31) >> 5;
+   for (int i = threadIdx.x; i < 10 * W; i += WG) {
+      const int dir = i / (5 * W), rem = i % (5 * W), cls = rem / W, w = rem % W;
+      s_peq[i] = w < Wp ? peq[(dir * 5 + cls) * Wp + w] : 0u;
+   }
+   for (int b = threadIdx.x; b < 256; b += WG) s_lut[b] = sq_class_of((uint32_t)b, options);
+   const bool staged = n <= STRING_LDS_MAX;
+   if (staged) {
+      /* 16 bytes per thread and round, all loads of a round in flight together (the link's latency is paid once per round) */
+      for (uint32_t o = threadIdx.x * 16; o < n; o += WG * 16) {
+         const sq_chunk16_t c = sq_load16(text, o, n);
+         *reinterpret_cast<uint4 *>(s_text + o) = make_uint4(c.w[0], c.w[1], c.w[2], c.w[3]);
+      }
+   }
+   __syncthreads();
+   if (threadIdx.x != 0) return;
+   const uint8_t *tp = staged ? (const uint8_t *)s_text : text;
+   const uint32_t nh = sq_scan_line<W, SQ_MODE_EMIT>(tp, (uint64_t)n, 0, (const uint32_t *)s_peq, (const uint32_t *)(s_peq + 5 * W),
+                                                     (const uint8_t *)s_lut, m, tau, options & 3, 1,
+                                                     reinterpret_cast<sq_hit_t *>(out + 4), cap);
+   out[0] = nh;
+   __threadfence_system();
+}
+
+template <int W>
+static void launch_string(seeqdev_scan *s, const seeqdev_pattern *pat, const uint8_t *text, uint32_t n, int options, uint32_t cap)
+{
+   const size_t lds = n <= STRING_LDS_MAX ? (((size_t)n + 31) & ~(size_t)15) : 0;
+   hipLaunchKernelGGL(k_string<W>, dim3(1), dim3(WG), lds, s->stream, text, n, (const uint32_t *)pat->d_peq, pat->wlen, pat->tau,
+                      options, s->h_strout, cap);
+}
+
+/* data[0..n): the string (no NUL needed; a NUL inside ends it as in the reference).  On return *rec points at the
+ * hit records (left to right; context-owned page-locked memory, valid until the next call) and *nrec is their number. */
+extern "C" int seeqdevStringMatch(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const char *data, size_t n, int options,
+                                  const seeqdev_hit_t **rec, size_t *nrec)
+{
+   seeqerr = 0;
+   if (!s || !pat || (!data && n) || !rec || !nrec) { errno = EINVAL; return -1; }
+   if (n > 0xFFFF0000ull) { errno = E2BIG; return -1; }
+   if (!s->h_strout) {
+      s->cap_strout = 256;                                  /* records */
+      HIP_TRY(hipHostMalloc((void **)&s->h_strout, 16 + s->cap_strout * sizeof(seeqdev_hit_t), hipHostMallocDefault), ENOMEM);
+   }
+   if (!s->h_str) {
+      s->cap_str = STRING_ZC_MAX + 16;
+      HIP_TRY(hipHostMalloc((void **)&s->h_str, s->cap_str, hipHostMallocDefault), ENOMEM);
+   }
+   const uint8_t *dtext;
+   if (n <= STRING_ZC_MAX) {
+      memcpy(s->h_str, data, n);
+      dtext = s->h_str;                                     /* page-locked host memory is device-visible at the same address */
+   } else {
+      if (n > s->cap_text) {
+         const size_t cap = n + (n >> 2) + 4096;
+         if (ws_alloc((void **)&s->d_text, cap)) return -1;
+         s->cap_text = cap;
+      }
+      HIP_TRY(hipMemcpyAsync(s->d_text, data, n, hipMemcpyHostToDevice, s->stream), EIO);
+      s->avg_text = NULL;
+      dtext = s->d_text;
+   }
+   const int W = pat->words;
+   for (int attempt = 0; attempt < 2; attempt++) {
+      const uint32_t cap = (uint32_t)s->cap_strout;
+      s->h_strout[0] = 0;
+      if (W <= 1) launch_string<1>(s, pat, dtext, (uint32_t)n, options, cap);
+      else if (W <= 2) launch_string<2>(s, pat, dtext, (uint32_t)n, options, cap);
+      else if (W <= 4) launch_string<4>(s, pat, dtext, (uint32_t)n, options, cap);
+      else if (W <= 8) launch_string<8>(s, pat, dtext, (uint32_t)n, options, cap);
+      else launch_string<16>(s, pat, dtext, (uint32_t)n, options, cap);
+      HIP_TRY(hipGetLastError(), EIO);
+      HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+      const uint32_t nh = s->h_strout[0];
+      if (nh <= cap) {
+         *rec = reinterpret_cast<const seeqdev_hit_t *>(s->h_strout + 4);
+         *nrec = nh;
+         return 0;
+      }
+      /* SQ_ALL with more hits than the record buffer holds: grow it and scan again */
+      (void)hipHostFree(s->h_strout);
+      s->h_strout = NULL;
+      s->cap_strout = (size_t)nh + (nh >> 2) + 64;
+      HIP_TRY(hipHostMalloc((void **)&s->h_strout, 16 + s->cap_strout * sizeof(seeqdev_hit_t), hipHostMallocDefault), ENOMEM);
+   }
+   errno = EIO;
+   return -1;
+}

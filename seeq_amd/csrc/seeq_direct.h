@@ -287,9 +287,10 @@ __global__ __launch_bounds__(64 * NW, (W == 1 ? 4 : 3)) void k_direct(FusedArgs 
    }
    if (lane == 0) {
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
-      a.wg_part[3 * gwave + 0] = wv_lines;
-      a.wg_part[3 * gwave + 1] = wv_hdrs;
-      a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
+      a.wg_part[4 * gwave + 0] = wv_lines;
+      a.wg_part[4 * gwave + 1] = wv_hdrs;
+      a.wg_part[4 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
+      a.wg_part[4 * gwave + 3] = 0u;
    }
 }
 

@@ -38,7 +38,11 @@ struct FusedArgs {
    uint32_t       cap_tmp;     /* total entries                                */
    uint32_t       slice_cap;   /* entries per slice = cap_tmp / slices           */
    uint32_t      *wg_hits;     /* per slice (= per wave of k_stream / k_direct): entries stored */
-   uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31}               */
+   uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31, flags (k_stream: 1 = met a byte outside
+                                  its alphabet, 2 = wants the long-line variant)}                     */
+   uint32_t       tiles_per_wave; /* k_stream: 0 = persistent grid, wave w takes tiles w, w + waves, ...; T > 0 = workgroup b
+                                  takes the 16 T tiles from 16 T b on and exits (short-lived workgroups let the post-pass of
+                                  the previous segment, queued on another stream, get onto the CUs)                      */
    uint32_t      *tile_dirty;  /* k_stream, long-line mode: per tile, 1 when it holds a byte outside the alphabet (then its exclusive prefix); else NULL */
    uint64_t      *tile_dmask;  /* k_stream, long-line mode: per tile, one bit per 128-byte chunk (lane) that holds a non-alphabet byte */
    uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */
@@ -155,12 +159,13 @@ template <> struct fused_state_t<2> {
 __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslices)
 {
    __shared__ uint32_t s_red[4][4];
-   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0;
+   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0, flags = 0;
    for (uint32_t i = threadIdx.x; i < nslices; i += 256) {
       if (a.wg_lastnl) { const uint32_t l = a.wg_lastnl[i]; lastnl = l > lastnl ? l : lastnl; }
-      lines += a.wg_part[3 * i + 0];
-      hdrs += a.wg_part[3 * i + 1];
-      const uint32_t h = a.wg_part[3 * i + 2];
+      lines += a.wg_part[4 * i + 0];
+      hdrs += a.wg_part[4 * i + 1];
+      const uint32_t h = a.wg_part[4 * i + 2];
+      flags |= a.wg_part[4 * i + 3];
       hits += h & 0x7FFFFFFFu;
       mx = (h & 0x7FFFFFFFu) > mx ? (h & 0x7FFFFFFFu) : mx;
       ovf |= h >> 31;
@@ -173,12 +178,13 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       const uint32_t o = __shfl_xor(mx, d, 64);
       mx = o > mx ? o : mx;
       ovf |= __shfl_xor(ovf, d, 64);
+      flags |= __shfl_xor(flags, d, 64);
       const uint32_t ol = __shfl_xor(lastnl, d, 64);
       lastnl = ol > lastnl ? ol : lastnl;
    }
-   __shared__ uint32_t s_last[4];
+   __shared__ uint32_t s_last[4], s_flags[4];
    const int w = threadIdx.x >> 6;
-   if ((threadIdx.x & 63) == 0) s_last[w] = lastnl;
+   if ((threadIdx.x & 63) == 0) { s_last[w] = lastnl; s_flags[w] = flags; }
    if ((threadIdx.x & 63) == 0) { s_red[w][0] = lines; s_red[w][1] = hdrs; s_red[w][2] = hits; s_red[w][3] = mx | (ovf << 31); }
    __syncthreads();
    if (threadIdx.x == 0) {
@@ -190,6 +196,14 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
          ovf |= s_red[k][3] >> 31;
       }
       Counters *c = a.cnt;
+      /* what the scan kernel noticed about the text (kept out of its own code path: the scan of the NEXT segment may
+         be running while this segment's post-pass reads these) */
+      flags = s_flags[0] | s_flags[1] | s_flags[2] | s_flags[3];
+      if (flags & 1u) {
+         c->dirty |= 1u;
+         if (a.options & MASK_NONDNA) c->overflow |= 16u;     /* SQ_CONVERT / SQ_IGNORE: k_stream is only exact on clean text -> re-run */
+      }
+      if (flags & 2u) c->overflow |= 32u;                     /* re-run once with the long-line variant (then kept) */
       c->seg_nlines = lines;
       c->seg_nheaders = hdrs;
       /* capacity wanted next time: every slice as large as the fullest one, plus slack */
@@ -207,18 +221,21 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
 }
 
 /* Slices -> ordered (hit_start, hit_line).  tile_hits / tile_cl hold exclusive prefixes by now.
-   One workgroup per slice (k_direct). */
-__global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line)
+   One wave per slice (k_direct). */
+__global__ __launch_bounds__(256) void k_fused_reorder(FusedArgs a, uint32_t nslices, uint32_t *hit_start, uint32_t *hit_line)
 {
    const Counters *c = a.cnt;
    if (c->overflow & 2u) return;
-   const uint32_t n = a.wg_hits[blockIdx.x];
-   const uint4 *slice = a.tmp + (size_t)blockIdx.x * a.slice_cap;
-   for (uint32_t i = threadIdx.x; i < n; i += 256) {
-      const uint4 e = slice[i];
-      const uint32_t dst = a.tile_hits[e.x] + e.y;
-      hit_start[dst] = e.z;
-      hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[e.x] + e.w + 1);      /* 1-based, reference seeq.c:377 */
+   const uint32_t lane = threadIdx.x & 63;
+   for (uint32_t sl = blockIdx.x * 4 + (threadIdx.x >> 6); sl < nslices; sl += gridDim.x * 4) {      /* one wave per slice */
+      const uint32_t n = a.wg_hits[sl];
+      const uint4 *slice = a.tmp + (size_t)sl * a.slice_cap;
+      for (uint32_t i = lane; i < n; i += 64) {
+         const uint4 e = slice[i];
+         const uint32_t dst = a.tile_hits[e.x] + e.y;
+         hit_start[dst] = e.z;
+         hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[e.x] + e.w + 1);      /* 1-based, reference seeq.c:377 */
+      }
    }
 }
 

@@ -165,7 +165,13 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
    const uint64_t last = a.nbytes - 1;
 
-   for (uint32_t tile = gwave; tile < a.ntiles; tile += nwaves) {
+   /* persistent grid: wave w of the grid takes tiles w, w + waves, ...; short-lived workgroups (tiles_per_wave = T):
+      workgroup b takes the 16 T consecutive tiles from 16 T b on, wave w every 16th of them */
+   const uint32_t tpw = a.tiles_per_wave;
+   const uint32_t tstep = tpw ? (uint32_t)NW : nwaves;
+   uint32_t tend = a.ntiles;
+   if (tpw) { const uint64_t e = ((uint64_t)blockIdx.x + 1) * NW * tpw; if (e < tend) tend = (uint32_t)e; }
+   for (uint32_t tile = tpw ? blockIdx.x * (NW * tpw) + wave : gwave; tile < tend; tile += tstep) {
       const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;
       /* opaque per tile: keeps the compiler from hoisting the per-lane 64-bit addresses of the guarded loads
          out of the tile loop (that costs ~20 VGPRs and spills) */
@@ -360,36 +366,35 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;
    }
-   if ((wv_dirty & 1u) && lane == 0) {
-      atomicOr(&a.cnt->dirty, 1u);
-      if (a.options & MASK_NONDNA) atomicOr(&a.cnt->overflow, 16u);   /* SQ_CONVERT / SQ_IGNORE: only exact on clean text -> re-run */
-   }
-   if ((wv_dirty & 2u) && lane == 0) atomicOr(&a.cnt->overflow, 32u);     /* re-run once with the long-line variant (then kept) */
    if (lane == 0) {
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
-      a.wg_part[3 * gwave + 0] = wv_lines;
-      a.wg_part[3 * gwave + 1] = wv_hdrs;
+      a.wg_part[4 * gwave + 0] = wv_lines;
+      a.wg_part[4 * gwave + 1] = wv_hdrs;
       if (LL) a.wg_lastnl[gwave] = wv_lastnl;    /* offset + 1 of the last newline this wave saw */
-      a.wg_part[3 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
+      a.wg_part[4 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
+      a.wg_part[4 * gwave + 3] = wv_dirty;       /* 1: a byte outside the alphabet, 2: wants the long-line variant (k_fused_post acts on them) */
    }
 }
 
 /* Slices -> ordered per-line arrays (tile_hits / tile_cl hold exclusive prefixes by now). */
-__global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t *hit_start, uint32_t *hit_line, uint32_t *unresolved,
-                                                        uint32_t *hit_col)
+__global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t nslices, uint32_t *hit_start, uint32_t *hit_line,
+                                                        uint32_t *unresolved, uint32_t *hit_col)
 {
    const Counters *c = a.cnt;
    if (c->overflow & 2u) return;
-   const uint32_t n = a.wg_hits[blockIdx.x];
-   const uint4 *slice = a.tmp + (size_t)blockIdx.x * a.slice_cap;
-   for (uint32_t i = threadIdx.x; i < n; i += 256) {
-      const uint4 e = slice[i];
-      const uint32_t tile = e.x & 0x7FFFFFFFu;
-      const uint32_t dst = a.tile_hits[tile] + (e.y & 0x1FFFu);
-      hit_start[dst] = e.z;
-      hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[tile] + e.w + 1);     /* 1-based, reference seeq.c:377 */
-      unresolved[dst] = e.x >> 31;                        /* e.z is the hit itself: the line starts before the tile */
-      hit_col[dst] = e.y >> 13;
+   const uint32_t lane = threadIdx.x & 63;
+   for (uint32_t sl = blockIdx.x * 4 + (threadIdx.x >> 6); sl < nslices; sl += gridDim.x * 4) {      /* one wave per slice */
+      const uint32_t n = a.wg_hits[sl];
+      const uint4 *slice = a.tmp + (size_t)sl * a.slice_cap;
+      for (uint32_t i = lane; i < n; i += 64) {
+         const uint4 e = slice[i];
+         const uint32_t tile = e.x & 0x7FFFFFFFu;
+         const uint32_t dst = a.tile_hits[tile] + (e.y & 0x1FFFu);
+         hit_start[dst] = e.z;
+         hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[tile] + e.w + 1);     /* 1-based, reference seeq.c:377 */
+         unresolved[dst] = e.x >> 31;                        /* e.z is the hit itself: the line starts before the tile */
+         hit_col[dst] = e.y >> 13;
+      }
    }
 }
 

@@ -917,6 +917,6 @@ def test_filter_automaton_patterns(gpu, capi, oracle):
         c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH)
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], (pattern, tau)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau)
-        if ci < 4:
+        if ci in (0, 1, 3):        # (the 20-mer at distance 4 only has a filter of 10-mers with 2 errors: not selective -> k_direct)
             assert got["kernel"] == "k_stream" and got["filter"], (pattern, tau, got["kernel"])
-    assert nfilter >= 20, nfilter
+    assert nfilter >= 15, nfilter
