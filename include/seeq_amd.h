@@ -68,7 +68,8 @@ typedef struct seeqdev_scan    seeqdev_scan_t;      /* stream + workspace    */
 
 /* Number of usable HIP devices (0 if none / no runtime).  Never fails. */
 int seeqdevDeviceCount(void);
-/* Select the device used by subsequent calls of this thread (hipSetDevice). */
+/* Select the device used by subsequent seeqdevPatternNew / seeqdevScanNew calls of this thread (hipSetDevice).
+ * Patterns and scan contexts remember the device they were created on; every call on them runs there. */
 int seeqdevSetDevice(int device);
 const char * seeqdevLastError(void);
 
@@ -137,6 +138,14 @@ int seeqdevScanHost(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const 
  * land in page-locked host memory: *rec (left to right, valid until the next call on this context), *nrec. */
 int seeqdevStringMatch(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * data, size_t n, int options,
                        const seeqdev_hit_t ** rec, size_t * nrec);
+
+/* The asynchronous half of seeqdevScanHost: stage (H2D on the context's stream) and enqueue the scan, return at once;
+ * seeqdevScanFetch() then waits for it.  host_text must stay valid and unchanged until the fetch returns.  A reader
+ * that fills the next chunk meanwhile, and one context per GPU, is how seeqFileMatch pipelines its ingest. */
+int seeqdevScanHostBegin(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * host_text, size_t nbytes,
+                         int options, int want);
+/* Time (ms) of that H2D copy for the last fetched scan (profiling on), from HIP events on the context's stream. */
+int seeqdevScanLastCopyMs(const seeqdev_scan_t * scan, float * h2d_ms);
 
 /* Device time (ms) of the last fetched scan, measured with HIP events recorded
  * on the scan's stream around each phase of each segment (no extra

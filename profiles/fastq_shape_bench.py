@@ -24,6 +24,7 @@ PATTERN, TAU, L = "GATGTAGCGCGATTAGCCTG", 3, 150
 nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 mode = sys.argv[2] if len(sys.argv) > 2 else "best"
 shape = sys.argv[3] if len(sys.argv) > 3 else "fastq"       # "fastq" (4-line records) or "fasta" (">id" + read, SEEQDEV_FASTA)
+nondna = {"fail": 0, "convert": dev.SQ_CONVERT, "ignore": dev.SQ_IGNORE}[sys.argv[4] if len(sys.argv) > 4 else "fail"]   # -x 0 / 1 / 2
 d = torch.device("cuda:0")
 reads = torch.empty(nrec * (L + 1), dtype=torch.uint8, device=d)
 dev.synth_reads(reads.data_ptr(), 0, nrec, L, PATTERN, TAU)
@@ -55,7 +56,7 @@ sc = dev.Scanner()
 sc.set_profiling(True)
 opt, want = (0, dev.WANT_COUNTLINES) if mode == "count" else (dev.SQ_BEST, dev.WANT_RECORDS)
 FA = dev.SEEQDEV_FASTA if shape == "fasta" else 0
-opt |= FA
+opt |= FA | nondna
 for _ in range(2):
     cnt = sc.scan_tensor(pat, text, opt, want)
 torch.cuda.synchronize()
@@ -75,7 +76,7 @@ ok = c2["nmatchlines"] == exp["nmatchlines"] and c2["nlines"] == exp["nlines"]
 if want == dev.WANT_RECORDS:
     s2 = dev.Scanner(); c3 = s2.scan_tensor(pat, text[:k * REC], opt, want)
     ok = ok and np.array_equal(s2.records(c3["nrecords"]).astype(np.uint64), exp["records"])
-print(json.dumps({"shape": "Q (4-line FASTQ records)" if shape == "fastq" else "2-line FASTA records", "mode": mode, "records": nrec, "lines": int(cnt["nlines"]),
+print(json.dumps({"shape": "Q (4-line FASTQ records)" if shape == "fastq" else "2-line FASTA records", "mode": mode, "nondna": sys.argv[4] if len(sys.argv) > 4 else "fail", "records": nrec, "lines": int(cnt["nlines"]),
                   "bytes": int(text.numel()), "ms_per_step": dt * 1e3, "lines_per_s": cnt["nlines"] / dt,
                   "gb_per_s": text.numel() / dt / 1e9, "matching_lines": int(cnt["nmatchlines"]),
                   "kernel": sc.last_kernel(), "times_ms": sc.last_times_ms(),

@@ -53,6 +53,16 @@ static int hip_fail(hipError_t e, const char *what, int err_no)
 
 extern "C" const char *seeqdevLastError(void) { return g_last_error; }
 
+/* Every entry point that takes a scan context or a pattern runs on THAT object's device, whatever device the calling
+ * thread used last (a caller that spreads chunks over several GPUs goes from one context to the next). */
+static int use_device(int device)
+{
+   int cur = -1;
+   if (hipGetDevice(&cur) == hipSuccess && cur == device) return 0;
+   HIP_TRY(hipSetDevice(device), ENODEV);
+   return 0;
+}
+
 extern "C" int seeqdevDeviceCount(void)
 {
    int n = 0;
@@ -124,6 +134,7 @@ struct ScanArgs {
    uint32_t       stream_ntiles, stream_tile_bytes;
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
+   uint32_t       lazy_clean;   /* k_stream ran without its alphabet check: k_exact1 checks each candidate line's bytes up to the candidate */
    uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: max(32, m + tau - 1) */
    Counters      *cnt;
 };
@@ -682,6 +693,7 @@ extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int 
 extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
 {
    if (!p) return;
+   (void)use_device(p->device);
    if (p->d_peq) (void)hipFree(p->d_peq);
    if (p->d_sdfa) (void)hipFree(p->d_sdfa);
    free(p->keys);
@@ -702,6 +714,8 @@ struct ScanKnobs {
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    bool no_overlap;      /* SEEQ_OVERLAP=0: segments strictly one after the other on one stream */
+   bool stream_check;    /* SEEQ_STREAM_CHECK=1: keep k_stream's alphabet check in every variant */
+   bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
 struct OccMemo { const void *fn; size_t lds; int per_cu; };
@@ -709,6 +723,10 @@ struct OccMemo { const void *fn; size_t lds; int per_cu; };
 struct seeqdev_scan {
    hipStream_t stream;
    bool        own_stream;
+   int         device;            /* the HIP device this context (its stream, its workspace) lives on */
+   hipEvent_t  ev_h2d[2];         /* profiling: around the H2D copy of seeqdevScanHostBegin */
+   bool        have_h2d_ev;
+   float       h2d_ms;            /* ... of the last fetched scan */
    int         ncu;               /* compute units of the device (cached) */
    ScanKnobs   knobs;
    OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
@@ -785,6 +803,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    }
    seeqdev_scan *s = (seeqdev_scan *)calloc(1, sizeof *s);
    if (!s) return NULL;
+   if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
    s->seg_bytes = (size_t)0xF0000000u;      /* 3.75 GiB segments: u32 offsets with room for k_stream's bias; multiple of every tile size */
    const char *env = getenv("SEEQ_SEGMENT_BYTES");
    if (env && atoll(env) >= 65536) s->seg_bytes = ((size_t)atoll(env) + 15) & ~(size_t)15;
@@ -815,6 +834,8 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_OVERLAP");      kn.no_overlap = v && atoi(v) == 0;
+      v = getenv("SEEQ_STREAM_CHECK"); kn.stream_check = v && atoi(v) == 1;
+      v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       s->ncu = 256;
       int dev = 0;
       hipDeviceProp_t prop;
@@ -832,6 +853,8 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
 extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
 {
    if (!s) return;
+   (void)use_device(s->device);
+   if (s->have_h2d_ev) { (void)hipEventDestroy(s->ev_h2d[0]); (void)hipEventDestroy(s->ev_h2d[1]); }
    (void)hipStreamSynchronize(s->stream);
    if (s->have_streams) {
       for (int i = 0; i < 2; i++) { (void)hipEventDestroy(s->ev_scan[i]); (void)hipEventDestroy(s->ev_post[i]); }
@@ -1150,13 +1173,16 @@ static int run_segments(seeqdev_scan *s)
    /* k_stream: line-agnostic table-driven scan (seeq_stream.h), the default whenever the pattern has an automaton that
       fits LDS (seeq_dfa.h): the complete Levenshtein automaton (its verdicts are exact) or, for longer patterns /
       larger distances, a partition FILTER automaton (its hit lines are candidates: the exact pass verifies them). */
-   bool use_stream = false;
+   bool use_stream = false, can_sub = false;
    int stream_ch = 128;
    {
-      /* SQ_CONVERT / SQ_IGNORE differ from SQ_FAIL only on non-DNA bytes: k_stream runs, and when it meets one
-         (Counters.dirty) it raises overflow flag 16 -> the scan is re-run on the per-line kernels, for good */
+      /* SQ_FAIL: always.  SQ_CONVERT: exact through the SUB variant (non-DNA bytes replaced by 'N' in registers).
+         Otherwise (SQ_IGNORE; SQ_CONVERT without SUB) k_stream is exact on clean text only: it runs until it meets a
+         non-DNA byte (Counters.dirty -> overflow flag 16: the scan is re-run on the per-line kernels, for good), and
+         not on FASTA input (header lines are made of such bytes). */
       const int nd = options & MASK_NONDNA;
-      const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || (!s->no_stream_nd && !fasta));
+      can_sub = nd == SQ_CONVERT && !fasta && kn.stream_ch == 128 && !kn.stream_ilp1 && !kn.no_sub;
+      const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || can_sub || (!s->no_stream_nd && !fasta));
       if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && kn.kernel != 2) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (mp->sdfa_state == 0 && mp->keys) {
@@ -1194,7 +1220,7 @@ static int run_segments(seeqdev_scan *s)
    unsigned nslices = 1;                      /* hit slices: one per wave */
    const int stream_wu = use_stream && pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
-   bool stream_ilp2 = false, stream_ll = false;
+   bool stream_ilp2 = false, stream_ll = false, stream_chk = true, stream_sub = false;
    size_t dfa_lds = 0;
    if (use_fused) {
       if (use_stream) {
@@ -1202,8 +1228,15 @@ static int run_segments(seeqdev_scan *s)
          tile_bytes = 64u * (uint32_t)stream_ch;
          stream_ilp2 = stream_ch == 128 && !kn.stream_ilp1;
          stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
+         /* the alphabet check stays out of the default variants under SQ_FAIL (k_exact1 looks at the candidate lines) */
+         stream_chk = stream_ll || (options & MASK_NONDNA) != 0 || !stream_ilp2 || stream_ch != 128 || kn.stream_check;
+         stream_sub = can_sub;
 #define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
-         stream_fn = stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
+         stream_fn = stream_sub ? (stream_ll ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true, true, true) : SEEQ_STREAM_FN(128, 8, true, false, true, true, true))
+                                             : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, true, true) : SEEQ_STREAM_FN(128, 8, true, false, false, true, true)))
+                   : !stream_chk ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, false, false) : SEEQ_STREAM_FN(128, 8, true, true, false, false))
+                                          : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, false) : SEEQ_STREAM_FN(128, 8, true, false, false, false)))
+                   : stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
                                         : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true) : SEEQ_STREAM_FN(128, 8, true, false, true)))
                    : fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, false) : SEEQ_STREAM_FN(128, 8, true, true, false))
                    : stream_ch == 128 ? (stream_ilp2 ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false) : SEEQ_STREAM_FN(128, 8, true, false, false))
@@ -1307,6 +1340,7 @@ static int run_segments(seeqdev_scan *s)
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
       a.use_nh = need_nh ? (use_stream ? 3u : 1u) : 0u;
       a.filter = filter ? 1u : 0u;
+      a.lazy_clean = use_stream && !stream_chk ? 1u : 0u;
       a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1 > 32 ? pat->wlen + pat->tau - 1 : 32);
       a.cnt = c;
 
@@ -1347,7 +1381,11 @@ static int run_segments(seeqdev_scan *s)
          f.slice_cap = f.cap_tmp / nsl;
          if (use_stream) {
 #define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st_scan, f)
-            if (stream_ll && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true, true); }
+            if (stream_sub && stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true, true, true); }
+            else if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, true, true); }
+            else if (!stream_chk && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false, false); }
+            else if (!stream_chk) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, false); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, false); }
+            else if (stream_ll && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true, true); }
             else if (stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true); }
             else if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false); }
             else if (stream_ch == 128 && stream_ilp2) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false); }
@@ -1469,6 +1507,12 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
 {
    seeqerr = 0;
    if (!s || !pat || (!d_text && nbytes) || want < 0 || want > 2) { errno = EINVAL; return -1; }
+   if (pat->device != s->device) {
+      snprintf(g_last_error, sizeof g_last_error, "pattern lives on device %d, scan context on device %d", pat->device, s->device);
+      errno = EINVAL;
+      return -1;
+   }
+   if (use_device(s->device)) return -1;
    s->pat = pat; s->text = d_text; s->nbytes = nbytes; s->options = options; s->want = want;
    s->ran = false;
    /* Optimistic default workspace: lines average >= 32 bytes, one line in 8 hits, 1 record per hit line.
@@ -1507,6 +1551,7 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
 {
    seeqerr = 0;
    if (!s || !s->ran) { errno = EINVAL; return -1; }
+   if (use_device(s->device)) return -1;
    /* Overflows surface one stage at a time (lines, hit lines, records, then k_stream's fall-backs): up to six
       re-runs, and the result of the last one is checked too. */
    for (int attempt = 0; attempt < 8; attempt++) {
@@ -1530,6 +1575,8 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
             s->acc_ms[0] += t01; s->acc_ms[1] += t12; s->acc_ms[2] += t23; s->acc_ms[3] += t01 + t12 + t23;
          }
          if (s->prof_segs) s->fwd_ms_avg = s->acc_ms[1] / (float)s->prof_segs;
+         s->h2d_ms = 0.f;
+         if (s->prof && s->have_h2d_ev) (void)hipEventElapsedTime(&s->h2d_ms, s->ev_h2d[0], s->ev_h2d[1]);
          return 0;
       }
       /* Grow to what the device reported (plus slack for the parts it could not see) and re-run. */
@@ -1561,6 +1608,7 @@ extern "C" int seeqdevScanCopyRecords(seeqdev_scan_t *s, seeqdev_hit_t *host_out
    if (!s || (!host_out && n)) { errno = EINVAL; return -1; }
    if (first + n > s->counts.nrecords) { errno = EINVAL; return -1; }
    if (n == 0) return 0;
+   if (use_device(s->device)) return -1;
    HIP_TRY(hipMemcpyAsync(host_out, s->records + first, n * sizeof(seeqdev_hit_t), hipMemcpyDeviceToHost, s->stream),
            EIO);
    HIP_TRY(hipStreamSynchronize(s->stream), EIO);
@@ -1572,7 +1620,7 @@ extern "C" void *seeqdevHostAlloc(size_t bytes)
 {
    void *p = NULL;
    seeqerr = 0;
-   hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+   hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);      /* every device may copy from it */
    if (e != hipSuccess) { hip_fail(e, "hipHostMalloc", ENOMEM); return NULL; }
    return p;
 }
@@ -1588,25 +1636,57 @@ extern "C" int seeqdevScanCopyOffsets(seeqdev_scan_t *s, uint64_t *host_out, siz
    if (!s || (!host_out && n)) { errno = EINVAL; return -1; }
    if (first + n > s->counts.nrecords) { errno = EINVAL; return -1; }
    if (n == 0) return 0;
+   if (use_device(s->device)) return -1;
    HIP_TRY(hipMemcpyAsync(host_out, s->rec_off + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream), EIO);
    HIP_TRY(hipStreamSynchronize(s->stream), EIO);
    return 0;
 }
 
-extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const char *host_text, size_t nbytes,
-                               int options, int want, seeqdev_counts_t *counts)
+extern "C" int seeqdevScanHostBegin(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const char *host_text, size_t nbytes,
+                                    int options, int want)
 {
    seeqerr = 0;
    if (!s || !pat || (!host_text && nbytes)) { errno = EINVAL; return -1; }
+   if (use_device(s->device)) return -1;
    if (nbytes > s->cap_text) {
       const size_t cap = nbytes + (nbytes >> 2) + 4096;
       if (ws_alloc((void **)&s->d_text, cap)) return -1;
       s->cap_text = cap;
    }
+   if (s->prof && !s->have_h2d_ev) {
+      HIP_TRY(hipEventCreate(&s->ev_h2d[0]), EIO);
+      HIP_TRY(hipEventCreate(&s->ev_h2d[1]), EIO);
+      s->have_h2d_ev = true;
+   }
+   if (s->prof) HIP_TRY(hipEventRecord(s->ev_h2d[0], s->stream), EIO);
    if (nbytes) HIP_TRY(hipMemcpyAsync(s->d_text, host_text, nbytes, hipMemcpyHostToDevice, s->stream), EIO);
-   s->avg_text = NULL;                       /* same staging address, new content: sample the line length again */
-   if (seeqdevScanRun(s, pat, s->d_text, nbytes, options, want)) return -1;
+   if (s->prof) HIP_TRY(hipEventRecord(s->ev_h2d[1], s->stream), EIO);
+   /* the line-length sample (kernel selection) comes from the host copy: no round trip, nothing stale */
+   if (s->line_hint <= 0 && !(options & SEEQDEV_SINGLELINE) && nbytes) {
+      const size_t n = nbytes < SAMPLE_BYTES ? nbytes : SAMPLE_BYTES;
+      size_t nl = 0;
+      for (size_t i = 0; i < n; i++) nl += host_text[i] == '\n';
+      s->avg_line = nl ? (double)n / (double)nl : 1e9;
+      s->avg_text = s->d_text;
+      s->avg_nbytes = nbytes;
+   } else {
+      s->avg_text = NULL;
+   }
+   return seeqdevScanRun(s, pat, s->d_text, nbytes, options, want);
+}
+
+extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const char *host_text, size_t nbytes,
+                               int options, int want, seeqdev_counts_t *counts)
+{
+   if (seeqdevScanHostBegin(s, pat, host_text, nbytes, options, want)) return -1;
    return seeqdevScanFetch(s, counts);
+}
+
+extern "C" int seeqdevScanLastCopyMs(const seeqdev_scan_t *s, float *h2d_ms)
+{
+   if (!s || !h2d_ms) { errno = EINVAL; return -1; }
+   *h2d_ms = s->h2d_ms;
+   return 0;
 }
 
 extern "C" int seeqdevScanLastLaunches(const seeqdev_scan_t *s) { return s ? (int)s->prof_segs : 0; }
@@ -1669,6 +1749,7 @@ extern "C" int seeqdevStringMatch(seeqdev_scan_t *s, const seeqdev_pattern_t *pa
    seeqerr = 0;
    if (!s || !pat || (!data && n) || !rec || !nrec) { errno = EINVAL; return -1; }
    if (n > 0xFFFF0000ull) { errno = E2BIG; return -1; }
+   if (use_device(s->device)) return -1;
    if (!s->h_strout) {
       s->cap_strout = 256;                                  /* records */
       HIP_TRY(hipHostMalloc((void **)&s->h_strout, 16 + s->cap_strout * sizeof(seeqdev_hit_t), hipHostMallocDefault), ENOMEM);

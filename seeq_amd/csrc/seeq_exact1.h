@@ -146,7 +146,13 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
    const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1;
    const bool count_any = a.want != SEEQDEV_WANT_COUNTMATCH && !(a.want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const bool by_nh = a.use_nh != 0;                       /* record slots come from the scanned per-line counts */
-   const bool trusted = a.use_nh == 3 && !c->dirty && !a.filter;   /* k_stream, complete automaton, clean text: its verdicts are exact */
+   /* lazy: k_stream ran without its alphabet check (SQ_FAIL, read-length lines).  Then a candidate line is looked at
+      here: the first candidate of a line sits at column `col`; if a byte outside the alphabet comes before it the line
+      ended there (libseeq.c:267-270) and holds NO hit at all -- all bytes before that one were walked exactly, so a hit
+      among them would have been the first candidate -- and if none does, the candidate is exactly what the line-long
+      scan finds (complete automaton), resp. a candidate worth verifying (filter). */
+   const bool lazy = a.use_nh == 3 && a.lazy_clean && hit_col != nullptr;
+   const bool trusted = a.use_nh == 3 && !a.filter && (lazy || !c->dirty);   /* k_stream, complete automaton, clean text (lazy: per line, below): exact verdicts */
    const bool caching = MODE == SQ_MODE_COUNT && cache != nullptr && a.want == SEEQDEV_WANT_RECORDS;
    const bool count_best = caching && match_opt == SQ_BEST;
    const bool cache_ok = MODE == SQ_MODE_EMIT && cache != nullptr && by_nh && !(trusted && count_any);
@@ -159,11 +165,12 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       bool done = k >= nhl;
       const uint32_t hs = done ? 0u : a.hit_start[k];
       if (hs == 0xFFFFFFFFu) done = true;                  /* k_stream: repeat of the previous entry's line */
+      const uint64_t off = done ? a.seg_base : a.seg_base + hs;
+      if (lazy && !done && !exact1_bytes_clean(a.text, off, off + hit_col[k] + 1)) done = true;   /* the line ended before its first candidate */
       if (MODE == SQ_MODE_COUNT && trusted && count_any) {
          if (k < nhl) a.nh[k] = done ? 0u : 1u;            /* (wave-uniform branch) */
          continue;
       }
-      const uint64_t off = done ? a.seg_base : a.seg_base + hs;
       if (a.use_nh == 3 && (a.options & SEEQDEV_FASTA) && !done && a.text[off] == '>') done = true;   /* k_stream candidate inside a FASTA header */
       fused_state_t<W> st;
       st.init(m);

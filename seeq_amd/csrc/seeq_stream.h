@@ -114,6 +114,21 @@ __device__ __forceinline__ void stream_own4x2(uint32_t &sa, uint32_t wa, uint32_
    STREAM_X2(0) STREAM_EV2(0) STREAM_X2(1) STREAM_EV2(1) STREAM_X2(2) STREAM_EV2(2) STREAM_X2(3) STREAM_EV2(3)
 }
 
+/* SQ_CONVERT (reference libseeq.c:223-228: a byte that is not A C G T N or a terminator counts as 'N'): four text bytes
+ * with every byte outside the alphabet replaced by 'N' -- and NUL, which ends the line in every mode (seeqcore.h:89-111,
+ * libseeq.c:267-270), by a byte of the DEAD column -- so that the walk over them is exact. */
+__device__ __forceinline__ uint32_t stream_sub4(uint32_t w)
+{
+   const uint32_t bad = fused_bad4(w);
+   if (bad == 0) return w;
+   uint32_t f = (((bad & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | bad) & 0x80808080u;      /* 0x80 per byte outside the alphabet */
+   uint32_t z = ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;         /* 0x80 per NUL byte */
+   f = f | (f - (f >> 7));                                                      /* -> 0xFF */
+   z = z | (z - (z >> 7));
+   w = (w & ~f) | (0x4E4E4E4Eu & f);                                            /* 'N' */
+   return (w & ~z) | (0x4C4C4C4Cu & z);                                         /* column 6: DEAD until the next newline */
+}
+
 /* the value of `x` in the previous lane; lane 0 gets `first` (DPP wave_shr:1) */
 __device__ __forceinline__ uint32_t stream_from_prev_lane(uint32_t x, uint32_t first)
 {
@@ -138,7 +153,15 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
  * unchanged; candidates inside a header are discarded by the exact pass, which looks at the first byte of the line. */
 /* LL: long-line mode -- per-tile "dirty" flags and the segment's last newline for the window walk of the exact pass
  * (kept out of the read-length kernel: its tile loop has no register to spare). */
-template <int CH, int WU, bool ILP2, bool FA, bool LL>
+/* CHK: the alphabet check is compiled in (a flag per wave: "met a byte outside {ACGTN acgtn \n}").  Needed by the
+ * long-line bookkeeping and under SQ_CONVERT / SQ_IGNORE (there such a byte changes what a LATER hit looks like, so the
+ * scan has to be redone on the per-line kernels).  Under SQ_FAIL on read-length lines it is left out -- it costs a
+ * quarter of the kernel's VALU work -- and the exact pass checks, per candidate line, the bytes from the start of the
+ * line to the candidate instead (k_exact1, `lazy_clean`): the line has a hit iff they are all in the alphabet. */
+/* SUB (SQ_CONVERT): tiles that hold such bytes are walked over a corrected copy (stream_sub4) held in registers: the
+ * verdicts are exact on any text and nothing needs re-running.  (SQ_IGNORE skips such bytes, which stretches the text a
+ * match spans beyond what a chunk's warm-up covers: there the scan is still redone on the per-line kernels.) */
+template <int CH, int WU, bool ILP2, bool FA, bool LL, bool CHK = true, bool SUB = false>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
@@ -196,13 +219,29 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
       }
       /* ---- alphabet check, done with before the walk starts (nothing of it stays live) ---- */
-      {
+      if (CHK || LL) {
          uint32_t bad = 0;
 #pragma unroll
          for (int q = 0; q < NQ; q++) bad |= fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);
          /* a byte outside the alphabet anywhere in the tile: the scan's verdicts need verifying */
-         const uint64_t badlanes = __ballot(bad != 0);
+         uint64_t badlanes = __ballot(bad != 0);
          uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(badlanes != 0 ? 1 : 0);
+         if (SUB) {
+            if (flag) {                                   /* wave-uniform */
+#pragma unroll
+               for (int q = 0; q < NQ; q++) {
+                  v[q].x = stream_sub4(v[q].x); v[q].y = stream_sub4(v[q].y); v[q].z = stream_sub4(v[q].z); v[q].w = stream_sub4(v[q].w);
+               }
+            }
+            /* the 32 bytes before the tile belong to another tile: looked at on their own (the same for all lanes) */
+            const uint32_t pbad = fused_bad4(pa.x) | fused_bad4(pa.y) | fused_bad4(pa.z) | fused_bad4(pa.w) |
+                                  fused_bad4(pb.x) | fused_bad4(pb.y) | fused_bad4(pb.z) | fused_bad4(pb.w);
+            if (__builtin_amdgcn_readfirstlane(pbad != 0 ? 1 : 0)) {
+               pa.x = stream_sub4(pa.x); pa.y = stream_sub4(pa.y); pa.z = stream_sub4(pa.z); pa.w = stream_sub4(pa.w);
+               pb.x = stream_sub4(pb.x); pb.y = stream_sub4(pb.y); pb.z = stream_sub4(pb.z); pb.w = stream_sub4(pb.w);
+            }
+            flag = 0; badlanes = 0;                       /* handled: only a newline (or NUL) ends a line now */
+         }
          asm volatile("" : "+s"(flag));                   /* pinned here: the walk below needs the registers */
          wv_dirty |= flag;
          if (LL && lane == 0) { a.tile_dirty[tile] = flag; a.tile_dmask[tile] = badlanes; }

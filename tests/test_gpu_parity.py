@@ -548,14 +548,16 @@ for dirty in (False, True):
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"]
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
         sc.close(); p.close()
-        # SQ_CONVERT / SQ_IGNORE: k_stream on clean text; a non-DNA byte makes the library re-run on a per-line kernel
+        # SQ_CONVERT: k_stream walks a corrected copy of tiles with non-DNA bytes (default variant); SQ_IGNORE (and
+        # SQ_CONVERT on the 64-byte-chunk variant): k_stream on clean text, a non-DNA byte makes the library re-run on a per-line kernel
         for nd in (dev.SQ_CONVERT, dev.SQ_IGNORE):
             p = dev.Pattern(pat, 3)
             sc = dev.Scanner()
             for opt in (SQ_BEST, SQ_ALL):
                 exp = o.buffer_scan(pat, 3, buf, opt | nd)
                 got = sc.scan_host(p, buf, opt | nd, dev.WANT_RECORDS)
-                assert (sc.last_kernel() == "k_stream") == (not dirty), (dirty, nd, sc.last_kernel())
+                exact_on_dirty = nd == dev.SQ_CONVERT and %d == 128
+                assert (sc.last_kernel() == "k_stream") == (not dirty or exact_on_dirty), (dirty, nd, sc.last_kernel())
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (dirty, nd, opt)
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, nd, opt)
             sc.close(); p.close()
@@ -589,7 +591,7 @@ for tail in ("\n", ""):
     assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
     sc.close(); p.close()
 print("OK")
-''' % (ROOT, os.path.join(ROOT, "tests"), ch, ch)
+''' % (ROOT, os.path.join(ROOT, "tests"), ch, ch, ch)
     for seg in ("65536", "0"):
         env = dict(os.environ, SEEQ_STREAM_CH=str(ch))
         if seg != "0":
@@ -745,15 +747,19 @@ def test_every_byte_value_alone(gpu, capi, oracle):
     from seeq_amd import device as dev
     pat = dev.Pattern(PAT20, 3)
     sc = dev.Scanner()
+    # (a copy of the pattern right behind the byte, one with the byte inside it, one in front of it on the same line)
     for b in range(256):
-        buf = (b"TTTTTTTT" + bytes([b]) + PAT20.encode() + b"TT\n" + b"ACGTACGTAC" + bytes([b]) + b"\n") * 40
-        for opt, want in ((0, dev.WANT_COUNTLINES), (SQ_ALL, dev.WANT_RECORDS)):
-            exp = oracle.buffer_scan(PAT20, 3, buf, opt)
-            got = sc.scan_host(pat, buf, opt, want)
-            assert sc.last_kernel() == "k_stream"
-            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], b
-            if want == dev.WANT_RECORDS:
-                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), b
+        buf = (b"TTTTTTTT" + bytes([b]) + PAT20.encode() + b"TT\n" + b"ACGTACGTAC" + bytes([b]) + b"\n" +
+               PAT20[:9].encode() + bytes([b]) + PAT20[10:].encode() + b"\n" + PAT20.encode() + b"AC" + bytes([b]) + b"GT\n") * 40
+        for nd in (SQ_FAIL, SQ_CONVERT, SQ_IGNORE):
+            for opt, want in ((0, dev.WANT_COUNTLINES), (SQ_ALL, dev.WANT_RECORDS), (SQ_BEST, dev.WANT_RECORDS)):
+                exp = oracle.buffer_scan(PAT20, 3, buf, opt | nd)
+                got = sc.scan_host(pat, buf, opt | nd, want)
+                if nd != SQ_IGNORE:
+                    assert sc.last_kernel() == "k_stream", (b, nd)      # SQ_FAIL: per-candidate check; SQ_CONVERT: corrected copy
+                assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (b, nd, opt)
+                if want == dev.WANT_RECORDS:
+                    assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (b, nd, opt)
     sc.close()
     pat.close()
 
