@@ -713,7 +713,8 @@ struct ScanKnobs {
    int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
-   bool no_overlap;      /* SEEQ_OVERLAP=0: segments strictly one after the other on one stream */
+   bool no_overlap;      /* unless SEEQ_OVERLAP=1: segments strictly one after the other on one stream (the default: measured, the
+                            overlapped post-pass takes from k_stream what it gains -- both live on LDS and occupancy) */
    bool stream_check;    /* SEEQ_STREAM_CHECK=1: keep k_stream's alphabet check in every variant */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
@@ -833,7 +834,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_TILE_BYTES");   kn.tile_bytes = v ? atoi(v) : 0;
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
-      v = getenv("SEEQ_OVERLAP");      kn.no_overlap = v && atoi(v) == 0;
+      v = getenv("SEEQ_OVERLAP");      kn.no_overlap = !(v && atoi(v) == 1);
       v = getenv("SEEQ_STREAM_CHECK"); kn.stream_check = v && atoi(v) == 1;
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       s->ncu = 256;

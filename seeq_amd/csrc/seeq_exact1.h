@@ -73,6 +73,33 @@ __device__ __forceinline__ bool exact1_bytes_clean(const uint8_t *text, uint64_t
    return bad == 0;
 }
 
+/* The same question for the first n bytes of a line (the lazy check of a read-length candidate line): the 16-byte
+ * pieces are fetched eight at a time with nothing depending on the previous one, the piece that straddles the end is
+ * masked in registers (bytes at or beyond n count as 'A') -- no byte loop, no early exit inside a group. */
+__device__ __forceinline__ bool exact1_prefix_clean(const uint8_t *text, uint64_t off, uint32_t n, uint64_t nbytes)
+{
+   uint32_t bad = 0;
+   for (uint32_t p = 0; p < n && !bad; p += 128) {
+      fused_v4u v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+         if (p + 16 * q < n) v[q] = direct_load16(text, off + p + 16 * q, nbytes);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+         const uint32_t o = p + 16 * q;
+         if (o >= n) break;
+         uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+         for (int j = 0; j < 4; j++) {
+            const uint32_t lo = o + 4 * j;                /* line offset of the word's first byte */
+            const uint32_t keep = lo + 4 <= n ? 0xFFFFFFFFu : (lo >= n ? 0u : 0xFFFFFFFFu >> (8 * (lo + 4 - n)));
+            bad |= fused_bad4((w[j] & keep) | (0x41414141u & ~keep));
+         }
+      }
+   }
+   return bad == 0;
+}
+
 /* text[x, y) inside ONE tile (base tb): whole 128-byte chunks by the tile's chunk mask, the partial chunks by bytes */
 __device__ __forceinline__ bool exact1_clean_in_tile(const ScanArgs &a, uint64_t tb, uint64_t dmask, uint64_t x, uint64_t y)
 {
@@ -166,10 +193,17 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       const uint32_t hs = done ? 0u : a.hit_start[k];
       if (hs == 0xFFFFFFFFu) done = true;                  /* k_stream: repeat of the previous entry's line */
       const uint64_t off = done ? a.seg_base : a.seg_base + hs;
-      if (lazy && !done && !exact1_bytes_clean(a.text, off, off + hit_col[k] + 1)) done = true;   /* the line ended before its first candidate */
+      /* lazy: a byte outside k_stream's table alphabet before the first candidate.  It may have ended the line there
+         (SQ_FAIL) or be a base the table folds exactly ('U'): this line is scanned whole, from column 0, by the rules
+         below -- EQ[] knows every byte's class -- and nothing k_stream said about it is used. */
+      const bool unclean = lazy && !done && !exact1_prefix_clean(a.text, off, hit_col[k] + 1, a.nbytes);
+      bool preset = false;                                 /* COUNT: the candidate is the verdict (one hit line) */
       if (MODE == SQ_MODE_COUNT && trusted && count_any) {
-         if (k < nhl) a.nh[k] = done ? 0u : 1u;            /* (wave-uniform branch) */
-         continue;
+         if (!__any(unclean)) {                            /* (wave-uniform branch) */
+            if (k < nhl) a.nh[k] = done ? 0u : 1u;
+            continue;
+         }
+         if (!unclean && !done) { preset = true; done = true; }
       }
       if (a.use_nh == 3 && (a.options & SEEQDEV_FASTA) && !done && a.text[off] == '>') done = true;   /* k_stream candidate inside a FASTA header */
       fused_state_t<W> st;
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
          /* nothing ends the line before the first candidate (clean text), so the scan may start just before it: no
             occurrence ends before `col` (a filter: every occurrence contains a part that ends at or after the first
             candidate), and a column started skip_back >= m + tau - 1 bytes earlier has the line's own scores from there */
-         if (col > a.skip_back && (trusted || exact1_clean(a, off, off + col - a.skip_back))) pos = col - a.skip_back;
+         if (col > a.skip_back && !unclean && (trusted || exact1_clean(a, off, off + col - a.skip_back))) pos = col - a.skip_back;
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
@@ -322,6 +356,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       if (k < nhl) {
          if (MODE == SQ_MODE_COUNT) {
             if (count_best) { nhits = best_d < tau1 ? 1u : 0u; c0p = best_end; c0d = best_d; }
+            if (preset) nhits = 1u;
             a.nh[k] = nhits;
             if (caching) cache[k] = make_uint4(c0p, c0d, c1p, c1d);
          } else if (from_cache) {

@@ -592,12 +592,13 @@ for tail in ("\n", ""):
     sc.close(); p.close()
 print("OK")
 ''' % (ROOT, os.path.join(ROOT, "tests"), ch, ch, ch)
-    for seg in ("65536", "0"):
-        env = dict(os.environ, SEEQ_STREAM_CH=str(ch))
+    # (many small segments, one after the other / with the opt-in overlapped post-pass; one segment)
+    for seg, ovl in (("65536", "0"), ("65536", "1"), ("0", "0")):
+        env = dict(os.environ, SEEQ_STREAM_CH=str(ch), SEEQ_OVERLAP=ovl)
         if seg != "0":
             env["SEEQ_SEGMENT_BYTES"] = seg
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
-        assert r.returncode == 0 and "OK" in r.stdout, (seg, r.stdout[-500:], r.stderr[-2000:])
+        assert r.returncode == 0 and "OK" in r.stdout, (seg, ovl, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_stream_fuzz_patterns(gpu, capi, oracle):
