@@ -432,7 +432,7 @@ def main():
         fwd_avg_ms = fwd_ms / max(1, fwd_launches)
         achieved = algo_bytes_launch / (fwd_avg_ms * 1e-3) / 1e9
         traffic = None
-        kern = sc.last_kernel()
+        kern = sc.last_stream_kernel() or sc.last_kernel()
         filt = sc.last_filter()
         pmc = os.path.join(ROOT, "profiles", "pmc_scan_kernels.json")
         traffic_src = None
@@ -448,6 +448,9 @@ def main():
         notes = {
             "k_stream": "line-agnostic table-driven scan: text read once (coalesced 128 B per lane), one LDS gather per "
                         "character; bound by LDS gather issue (32 banks) just above the HBM stream time: see DESIGN.md",
+            "k_stream2": "line-agnostic table-driven scan, every lane walks a 1 KB stretch of the text (128 B per phase, read "
+                         "once), one LDS gather + ~5 VALU per character; bound by VALU issue / the LDS gather unit above the "
+                         "HBM stream time: see DESIGN.md",
             "k_direct": "one-pass per-line scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte) and "
                         "on re-reading lines from L2: see DESIGN.md",
         }
@@ -457,7 +460,7 @@ def main():
             "value": value, "unit": "lines/s", "gb_per_s": gbs,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int (u16 automaton state ids; exact-pass columns u32 bit-vectors)" if kern == "k_stream" else "u32 bit-vectors",
+            "dtype": "int (u16 automaton state ids; exact-pass columns u32 bit-vectors)" if kern.startswith("k_stream") else "u32 bit-vectors",
             "data": "synthetic",
             "config": {"workload": wl[5] % n,
                        "pattern": PATTERN, "distance": TAU, "read_len": READ_LEN, "reads_per_gpu": n,

@@ -102,6 +102,9 @@ int seeqdevScanLastPath(const seeqdev_scan_t * scan);
 /* 1 when the last run's k_stream walked a partition FILTER automaton (candidates verified by the exact pass)
  * instead of the pattern's complete automaton. */
 int seeqdevScanLastFilter(const seeqdev_scan_t * scan);
+/* Which table-driven scan kernel the last run used: 0 none, 1 = k_stream (a lane walks 128-byte chunks, warm-up per
+ * chunk), 2 = k_stream2 (a lane walks a 1 KB stretch: read-length lines without FASTA headers). */
+int seeqdevScanLastStream(const seeqdev_scan_t * scan);
 
 /* Enqueue (asynchronously, on the context's stream) the whole hot path over
  * d_text[0..nbytes): newline index -> per-line forward scan -> hit-line

@@ -61,7 +61,7 @@ EXPORTS = [
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
     "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
-    "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs",
+    "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevScanLastStream",
 ]
 
 
@@ -169,6 +169,8 @@ def lib():
     L.seeqdevScanLastPath.restype = C.c_int
     L.seeqdevScanLastFilter.argtypes = [C.c_void_p]
     L.seeqdevScanLastFilter.restype = C.c_int
+    L.seeqdevScanLastStream.argtypes = [C.c_void_p]
+    L.seeqdevScanLastStream.restype = C.c_int
     L.seeqdevHostAlloc.argtypes = [C.c_size_t]
     L.seeqdevHostAlloc.restype = C.c_void_p
     L.seeqdevHostFree.argtypes = [C.c_void_p]

@@ -550,6 +550,7 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_stream.h"
+#include "seeq_stream2.h"
 static_assert(STREAM_NW == STREAM_NW_HOST, "waves per k_stream workgroup");
 extern "C" {
 #include "seeq_dfa.h"
@@ -715,7 +716,9 @@ struct ScanKnobs {
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    bool no_overlap;      /* unless SEEQ_OVERLAP=1: segments strictly one after the other on one stream (the default: measured, the
                             overlapped post-pass takes from k_stream what it gains -- both live on LDS and occupancy) */
-   bool stream_check;    /* SEEQ_STREAM_CHECK=1: keep k_stream's alphabet check in every variant */
+   bool stream_lazy;     /* SEEQ_STREAM_LAZY=1: k_stream / k_stream2 without their alphabet check under SQ_FAIL (k_exact1 then checks
+                            every candidate line's prefix; measured: costs more there than it saves here) */
+   bool stream_v1;       /* unless SEEQ_STREAM_V2=1: never use k_stream2 (lane stretches of 1 KB), always k_stream (128-byte chunks) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -732,6 +735,7 @@ struct seeqdev_scan {
    ScanKnobs   knobs;
    OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
    bool        last_filter;       /* the last run walked a partition filter automaton */
+   int         last_stream;       /* 0: the last run did not use the table-driven scan; 1: k_stream; 2: k_stream2 */
    /* workspace (device) */
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
@@ -747,6 +751,7 @@ struct seeqdev_scan {
       uint32_t *wg_lastnl;           /* [cap_slices] k_stream: last newline seen by each wave */
    } ow[2];
    size_t cap_ftiles, cap_slices;
+   uint32_t *lane_ws; size_t cap_lane_tiles;   /* k_stream2: three values per lane and tile (192 u32 per 64 KB tile) */
    bool   two_sets;                  /* ow[1] is allocated */
    hipStream_t sp;                   /* overlap: the post-pass stream (high priority); the scan kernels stay on `stream` */
    hipEvent_t  ev_scan[2], ev_post[2], ev_end;
@@ -835,7 +840,8 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_OVERLAP");      kn.no_overlap = !(v && atoi(v) == 1);
-      v = getenv("SEEQ_STREAM_CHECK"); kn.stream_check = v && atoi(v) == 1;
+      v = getenv("SEEQ_STREAM_LAZY");  kn.stream_lazy = v && atoi(v) == 1;
+      v = getenv("SEEQ_STREAM_V2");    kn.stream_v1 = !(v && atoi(v) == 1);
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       s->ncu = 256;
       int dev = 0;
@@ -867,7 +873,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
                     s->ow[i].wg_part, s->ow[i].wg_lastnl};
       for (void *b : ob) if (b) (void)hipFree(b);
    }
-   void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+   void *bufs[] = {s->lane_ws, s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
@@ -973,6 +979,7 @@ extern "C" int seeqdevScanSetLineHint(seeqdev_scan_t *s, double avg_bytes_per_li
 
 extern "C" int seeqdevScanLastPath(const seeqdev_scan_t *s) { return s ? s->last_path : 0; }
 extern "C" int seeqdevScanLastFilter(const seeqdev_scan_t *s) { return s && s->last_filter ? 1 : 0; }
+extern "C" int seeqdevScanLastStream(const seeqdev_scan_t *s) { return s ? s->last_stream : 0; }
 
 extern "C" int seeqdevScanSetProfiling(seeqdev_scan_t *s, int on)
 {
@@ -1221,7 +1228,7 @@ static int run_segments(seeqdev_scan *s)
    unsigned nslices = 1;                      /* hit slices: one per wave */
    const int stream_wu = use_stream && pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
-   bool stream_ilp2 = false, stream_ll = false, stream_chk = true, stream_sub = false;
+   bool stream_ilp2 = false, stream_ll = false, stream_chk = true, stream_sub = false, use_stream2 = false;
    size_t dfa_lds = 0;
    if (use_fused) {
       if (use_stream) {
@@ -1230,8 +1237,12 @@ static int run_segments(seeqdev_scan *s)
          stream_ilp2 = stream_ch == 128 && !kn.stream_ilp1;
          stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
          /* the alphabet check stays out of the default variants under SQ_FAIL (k_exact1 looks at the candidate lines) */
-         stream_chk = stream_ll || (options & MASK_NONDNA) != 0 || !stream_ilp2 || stream_ch != 128 || kn.stream_check;
+         stream_chk = stream_ll || (options & MASK_NONDNA) != 0 || !stream_ilp2 || stream_ch != 128 || !kn.stream_lazy;
          stream_sub = can_sub;
+         /* k_stream2 (seeq_stream2.h): every lane walks a 1 KB stretch -- one warm-up per kilobyte instead of per 64 bytes.
+            Read-length lines, one segment after the other; FASTA, long lines and the overlapped post-pass stay on k_stream. */
+         use_stream2 = stream_ilp2 && !fasta && !stream_ll && !kn.stream_v1 && kn.no_overlap && s->seg_bytes % STREAM2_TB == 0;
+         if (use_stream2) tile_bytes = STREAM2_TB;
 #define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
          stream_fn = stream_sub ? (stream_ll ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true, true, true) : SEEQ_STREAM_FN(128, 8, true, false, true, true, true))
                                              : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, true, true) : SEEQ_STREAM_FN(128, 8, true, false, false, true, true)))
@@ -1244,6 +1255,10 @@ static int run_segments(seeqdev_scan *s)
                                                      : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, false, false, false) : SEEQ_STREAM_FN(128, 8, false, false, false)))
                                       : (stream_wu == 6 ? SEEQ_STREAM_FN(64, 6, false, false, false) : SEEQ_STREAM_FN(64, 8, false, false, false));
 #undef SEEQ_STREAM_FN
+         if (use_stream2)
+            stream_fn = stream_sub ? (stream_wu == 6 ? (const void *)k_stream2<6, true, true> : (const void *)k_stream2<8, true, true>)
+                      : stream_chk ? (stream_wu == 6 ? (const void *)k_stream2<6, true, false> : (const void *)k_stream2<8, true, false>)
+                                   : (stream_wu == 6 ? (const void *)k_stream2<6, false, false> : (const void *)k_stream2<8, false, false>);
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          int per_cu = occupancy_of(s, stream_fn, 64 * STREAM_NW, dfa_lds);
          if (per_cu < 0) return -1;
@@ -1294,6 +1309,7 @@ static int run_segments(seeqdev_scan *s)
    const bool use_direct = use_fused && !use_stream;
    s->last_path = use_fused ? (use_stream ? 5 : 3) : 1;
    s->last_filter = filter;
+   s->last_stream = use_stream ? (use_stream2 ? 2 : 1) : 0;
    const bool superset = use_stream;                     /* the scan kernel's hit lines are candidates: nh[] decides */
    if (superset) need_nh = true;
    const bool generic_exact = !superset && kn.exact_generic;      /* A/B knob */
@@ -1380,7 +1396,20 @@ static int run_segments(seeqdev_scan *s)
             if (nsl > s->cap_slices) { seeqerr = 0; errno = ENOMEM; snprintf(g_last_error, sizeof g_last_error, "slice table too small"); return -1; }
          }
          f.slice_cap = f.cap_tmp / nsl;
-         if (use_stream) {
+         if (use_stream2) {
+            if ((size_t)f.ntiles > s->cap_lane_tiles) {
+               HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+               const size_t tiles = s->seg_bytes / STREAM2_TB + 1 > (size_t)f.ntiles ? s->seg_bytes / STREAM2_TB + 1 : (size_t)f.ntiles;
+               if (ws_alloc((void **)&s->lane_ws, tiles * 192 * sizeof(uint32_t))) return -1;
+               s->cap_lane_tiles = tiles;
+            }
+#define SEEQ_STREAM2_LAUNCH(...) hipLaunchKernelGGL((k_stream2<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st_scan, f, s->lane_ws)
+            if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM2_LAUNCH(6, true, true); else SEEQ_STREAM2_LAUNCH(8, true, true); }
+            else if (stream_chk) { if (stream_wu == 6) SEEQ_STREAM2_LAUNCH(6, true, false); else SEEQ_STREAM2_LAUNCH(8, true, false); }
+            else { if (stream_wu == 6) SEEQ_STREAM2_LAUNCH(6, false, false); else SEEQ_STREAM2_LAUNCH(8, false, false); }
+#undef SEEQ_STREAM2_LAUNCH
+         }
+         else if (use_stream) {
 #define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st_scan, f)
             if (stream_sub && stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true, true, true); }
             else if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, true, true); }
@@ -1405,7 +1434,8 @@ static int run_segments(seeqdev_scan *s)
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
             launch_scanset(s, st, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
             const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
-            if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
+            if (use_stream2) hipLaunchKernelGGL(k_stream2_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, (const uint32_t *)s->lane_ws, s->hit_start, s->hit_line, s->nh, s->hit_col);
+            else if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
             else hipLaunchKernelGGL(k_fused_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */

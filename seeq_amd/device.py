@@ -102,6 +102,10 @@ class Scanner:
     def last_kernel(self):
         return {1: "k_forward", 3: "k_direct", 5: "k_stream"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
+    def last_stream_kernel(self):
+        """Which table-driven scan kernel the last run used: "k_stream" (128-byte chunks), "k_stream2" (1 KB stretches) or None."""
+        return {1: "k_stream", 2: "k_stream2"}.get(self._lib.seeqdevScanLastStream(self._h))
+
     def last_filter(self):
         """True when the last k_stream run walked a partition filter automaton (candidates verified by the exact pass)."""
         return bool(self._lib.seeqdevScanLastFilter(self._h))

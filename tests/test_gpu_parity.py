@@ -117,7 +117,9 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
     per lane), or 'auto' (the library's own choice); the env knobs are read when the scan context is created."""
     from seeq_amd import device as dev
     if path != "auto":
-        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream"}.get(path, "direct")
+        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream", "fused-stream2": "stream"}.get(path, "direct")
+    if path == "fused-stream2":
+        os.environ["SEEQ_STREAM_V2"] = "1"
     if tile and path == "fused-stream":
         os.environ["SEEQ_STREAM_CH"] = str(tile)
     elif tile:
@@ -138,11 +140,12 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
         os.environ.pop("SEEQ_TILE_BYTES", None)
         os.environ.pop("SEEQ_STREAM_CH", None)
         os.environ.pop("SEEQ_FUSED_KERNEL", None)
+        os.environ.pop("SEEQ_STREAM_V2", None)
     return res
 
 
 @pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024),
-                                       ("fused-stream", None), ("fused-stream", 64)])
+                                       ("fused-stream", None), ("fused-stream2", None), ("fused-stream", 64)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
                                               ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3),
@@ -157,9 +160,9 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
             exp = oracle.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
             got = _scan(capi, pattern, tau, buf, mo | nd, dev.WANT_RECORDS, fasta, path, tile)
             assert got["path"] == (path.split("-")[0] if fusable else "generic")     # the kernel under test really ran
-            if path == "fused-stream" and nd == SQ_FAIL and not fasta and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
+            if path in ("fused-stream", "fused-stream2") and nd == SQ_FAIL and not fasta and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
                 assert got["kernel"] == "k_stream" and not got["filter"]
-            if path == "fused-stream" and tile is None and nd == SQ_FAIL and pattern == PAT40:
+            if path in ("fused-stream", "fused-stream2") and tile is None and nd == SQ_FAIL and pattern == PAT40:
                 assert got["kernel"] == "k_stream" and got["filter"]      # configs[4]: partition filter automaton
             if path == "fused":
                 assert got["kernel"] == "k_direct"
@@ -174,7 +177,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
         assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
 
 
-@pytest.mark.parametrize("path", ["generic", "fused", "fused-stream"])
+@pytest.mark.parametrize("path", ["generic", "fused", "fused-stream", "fused-stream2", "auto"])
 def test_edge_buffers(gpu, capi, oracle, path):
     """Empty / ragged / maximum-ish inputs: no trailing newline, empty lines, NUL and CR bytes, a line longer
     than the LDS window (fused: falls back to the HBM per-line scan), 70 k empty lines (fused: many passes
@@ -186,7 +189,9 @@ def test_edge_buffers(gpu, capi, oracle, path):
     cases = [star, b"", b"\n", b"\n\n\n", b"ACGT", b"ACGT\n", b"\nACGT", b"ACGT\n\nACGT\n", b"ACGT\0ACGT\nACGT",
              b"AC\rGT\r\nACGT\r\n", b"A" * 5000 + b"\n" + b"ACGT" * 3, b"\n" * 70000 + b"ACGT\n",
              bytes(range(256)) * 3, ragged, b"T" * 4090 + b"ACGT\nACGT" + b"T" * 4090 + b"AC\nGT\n",
-             (b"ACGT" * 300 + b"\n") * 40]
+             (b"ACGT" * 300 + b"\n") * 40,
+             # k_stream2: 64 KB tiles of four-byte hit lines (16 384 per tile, 256 per lane stretch), then ordinary lines
+             b"ACG\n" * 40000 + b"ACGT\n" * 10, b"ACGT" * 20000 + b"\nACGT\n", (b"T" * 1020 + b"ACGT\n") * 130]
     for buf in cases:
         for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
             exp = oracle.buffer_scan("ACGT", 1, buf, opt)
@@ -491,12 +496,14 @@ def _mutate(rng, pat, nerr):
     return "".join(s)
 
 
-@pytest.mark.parametrize("ch", [128, 64])
-def test_stream_chunk_and_tile_boundaries(gpu, capi, oracle, ch):
-    """k_stream gives lanes fixed chunks of the text, so hits, newlines and whole lines straddle chunk, tile
-    (64 chunks) and segment boundaries in every possible way: pattern copies planted at every offset around
-    the boundaries, lines from 0 to 30 000 bytes with several hits each (one line reported by many lanes),
-    non-DNA bytes before / after hits (dirty text: the filter's verdicts get verified), small segments."""
+@pytest.mark.parametrize("ch,v2", [(128, 0), (128, 1), (64, 0)])
+def test_stream_chunk_and_tile_boundaries(gpu, capi, oracle, ch, v2):
+    """k_stream / k_stream2 give lanes fixed chunks (128 B) / stretches (1 KB) of the text, so hits, newlines and whole
+    lines straddle chunk, tile (64 chunks: 8 KB / 64 KB) and segment boundaries in every possible way: pattern copies
+    planted at every offset around the boundaries, lines from 0 bytes to more than a tile with several hits each (one
+    line reported by many lanes), non-DNA bytes before / after hits (dirty text: the filter's verdicts get verified),
+    small segments.  (128, 0): the library's default, k_stream; (128, 1): k_stream2 on the plain text (SEEQ_STREAM_V2=1),
+    k_stream on the FASTA part; (64, 0): k_stream's 64-byte-chunk variant."""
     code = r'''
 import os, sys, random, numpy as np
 sys.path.insert(0, %r)
@@ -508,7 +515,7 @@ o = Oracle()
 pat = "GATGTAGCGCGATTAGCCTG"
 rng = random.Random(77)
 def dna(n): return "".join(rng.choice("ACGT") for _ in range(n))
-tile = 64 * %d
+tile = %d
 for dirty in (False, True):
     parts = []
     # 1. copies ending at every offset around the first tile boundaries (one line per copy, lengths vary)
@@ -539,6 +546,9 @@ for dirty in (False, True):
             exp = o.buffer_scan(pat, 3, buf, opt)
             got = sc.scan_host(p, buf, opt, dev.WANT_RECORDS)
             assert sc.last_kernel() == "k_stream", sc.last_kernel()
+            want2 = tile == 65536 and os.environ.get("SEEQ_OVERLAP") != "1"
+            # (a line longer than a 64 KB tile with a hit in it sends the scan context to k_stream's long-line variant)
+            assert sc.last_stream_kernel() in (("k_stream2", "k_stream") if want2 else ("k_stream",)), sc.last_stream_kernel()
             assert got["nlines"] == exp["nlines"], (dirty, opt, got["nlines"], exp["nlines"])
             assert got["nmatchlines"] == exp["nmatchlines"], (dirty, opt, got["nmatchlines"], exp["nmatchlines"])
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, opt)
@@ -591,10 +601,10 @@ for tail in ("\n", ""):
     assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
     sc.close(); p.close()
 print("OK")
-''' % (ROOT, os.path.join(ROOT, "tests"), ch, ch, ch)
+''' % (ROOT, os.path.join(ROOT, "tests"), 65536 if (ch == 128 and v2) else 64 * ch, ch, ch)
     # (many small segments, one after the other / with the opt-in overlapped post-pass; one segment)
     for seg, ovl in (("65536", "0"), ("65536", "1"), ("0", "0")):
-        env = dict(os.environ, SEEQ_STREAM_CH=str(ch), SEEQ_OVERLAP=ovl)
+        env = dict(os.environ, SEEQ_STREAM_CH=str(ch), SEEQ_OVERLAP=ovl, SEEQ_STREAM_V2=str(v2))
         if seg != "0":
             env["SEEQ_SEGMENT_BYTES"] = seg
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
