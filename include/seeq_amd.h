@@ -80,6 +80,10 @@ seeqdev_pattern_t * seeqdevPatternNew(const char * keys, int wlen, int tau);
 void                seeqdevPatternFree(seeqdev_pattern_t * pat);
 /* The device pattern behind a seeq_t made by seeqNew() (sq->dfa). */
 seeqdev_pattern_t * seeqdevPatternOf(const seeq_t * sq);
+/* The HIP device a pattern lives on (the device that was current in seeqdevPatternNew); -1 for NULL.  A pattern and
+ * the scan contexts that use it must live on the same device: a caller that spreads chunks over several GPUs
+ * (seeqFileMatch with SEEQ_DEVICES) makes one pattern per device. */
+int seeqdevPatternDevice(const seeqdev_pattern_t * pat);
 
 /* A scan context owns its workspace in HBM and runs on `hip_stream`
  * (a hipStream_t passed as void*; NULL => a private stream). */

@@ -123,6 +123,7 @@ void seeqFree(seeq_t *sq)
    if (!sq) return;
    seeq_engine_t *eng = seeq_engine_of(sq);
    if (eng) {
+      seeq_file_forget_engine(eng->id);      /* read-ahead scans of an open file may still use the pattern */
       if (eng->scan) seeqdevScanFree(eng->scan);
       if (eng->pat) seeqdevPatternFree(eng->pat);
       eng->magic = 0;

@@ -691,6 +691,8 @@ extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int 
    return p;
 }
 
+extern "C" int seeqdevPatternDevice(const seeqdev_pattern_t *p) { return p ? p->device : -1; }
+
 extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
 {
    if (!p) return;
@@ -1255,13 +1257,20 @@ static int run_segments(seeqdev_scan *s)
                                                      : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, false, false, false) : SEEQ_STREAM_FN(128, 8, false, false, false)))
                                       : (stream_wu == 6 ? SEEQ_STREAM_FN(64, 6, false, false, false) : SEEQ_STREAM_FN(64, 8, false, false, false));
 #undef SEEQ_STREAM_FN
-         if (use_stream2)
-            stream_fn = stream_sub ? (stream_wu == 6 ? (const void *)k_stream2<6, true, true> : (const void *)k_stream2<8, true, true>)
-                      : stream_chk ? (stream_wu == 6 ? (const void *)k_stream2<6, true, false> : (const void *)k_stream2<8, true, false>)
-                                   : (stream_wu == 6 ? (const void *)k_stream2<6, false, false> : (const void *)k_stream2<8, false, false>);
+         const void *tail_fn = nullptr;
+         if (use_stream2) {
+#define SEEQ_S2_FN(T) (stream_sub ? (stream_wu == 6 ? (const void *)k_stream2<6, true, true, T> : (const void *)k_stream2<8, true, true, T>) \
+                     : stream_chk ? (stream_wu == 6 ? (const void *)k_stream2<6, true, false, T> : (const void *)k_stream2<8, true, false, T>) \
+                                  : (stream_wu == 6 ? (const void *)k_stream2<6, false, false, T> : (const void *)k_stream2<8, false, false, T>))
+            stream_fn = SEEQ_S2_FN(false);
+            tail_fn = SEEQ_S2_FN(true);
+#undef SEEQ_S2_FN
+            nw = STREAM2_NW;
+         }
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
-         int per_cu = occupancy_of(s, stream_fn, 64 * STREAM_NW, dfa_lds);
+         int per_cu = occupancy_of(s, stream_fn, 64 * nw, dfa_lds);
          if (per_cu < 0) return -1;
+         if (tail_fn && occupancy_of(s, tail_fn, 64 * nw, dfa_lds) < 0) return -1;       /* (raises its dynamic-LDS limit) */
          if (kn.wgs_per_cu >= 1 && kn.wgs_per_cu < per_cu) per_cu = kn.wgs_per_cu;       /* experiments: workgroups per CU */
          fused_grid = (unsigned)(ncu * per_cu);
          if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
@@ -1400,13 +1409,26 @@ static int run_segments(seeqdev_scan *s)
             if ((size_t)f.ntiles > s->cap_lane_tiles) {
                HIP_TRY(hipStreamSynchronize(s->stream), EIO);
                const size_t tiles = s->seg_bytes / STREAM2_TB + 1 > (size_t)f.ntiles ? s->seg_bytes / STREAM2_TB + 1 : (size_t)f.ntiles;
-               if (ws_alloc((void **)&s->lane_ws, tiles * 192 * sizeof(uint32_t))) return -1;
+               if (ws_alloc((void **)&s->lane_ws, tiles * STREAM2_WS * sizeof(uint32_t))) return -1;
                s->cap_lane_tiles = tiles;
             }
-#define SEEQ_STREAM2_LAUNCH(...) hipLaunchKernelGGL((k_stream2<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st_scan, f, s->lane_ws)
-            if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM2_LAUNCH(6, true, true); else SEEQ_STREAM2_LAUNCH(8, true, true); }
-            else if (stream_chk) { if (stream_wu == 6) SEEQ_STREAM2_LAUNCH(6, true, false); else SEEQ_STREAM2_LAUNCH(8, true, false); }
-            else { if (stream_wu == 6) SEEQ_STREAM2_LAUNCH(6, false, false); else SEEQ_STREAM2_LAUNCH(8, false, false); }
+            /* whole tiles: the hot kernel.  The segment's last tile when it is cut short or ends the buffer: one wave of
+               the TAIL variant, with a slice of its own behind the hot kernel's */
+            const bool tail = a.seg_len % STREAM2_TB != 0 || a.seg_base + a.seg_len >= nbytes;
+            const uint32_t nfull = tail ? f.ntiles - 1 : f.ntiles;
+            if (tail) nsl += 1;
+            f.slice_cap = f.cap_tmp / nsl;
+#define SEEQ_STREAM2_LAUNCH(G, F, E, S0, ...) hipLaunchKernelGGL((k_stream2<__VA_ARGS__>), dim3(G), dim3(64 * STREAM2_NW), dfa_lds, st_scan, f, s->lane_ws, (uint32_t)(F), (uint32_t)(E), (uint32_t)(S0))
+#define SEEQ_STREAM2_BOTH(...) do { if (nfull) SEEQ_STREAM2_LAUNCH(fgrid, 0, nfull, 0, __VA_ARGS__, false); \
+                                    if (tail) SEEQ_STREAM2_LAUNCH(1, nfull, f.ntiles, nsl - 1, __VA_ARGS__, true); } while (0)
+            if (!nfull) {                                 /* no hot launch: its slices hold nothing */
+               HIP_TRY(hipMemsetAsync(ow.wg_hits, 0, (size_t)nsl * sizeof(uint32_t), st_scan), EIO);
+               HIP_TRY(hipMemsetAsync(ow.wg_part, 0, (size_t)nsl * 4 * sizeof(uint32_t), st_scan), EIO);
+            }
+            if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM2_BOTH(6, true, true); else SEEQ_STREAM2_BOTH(8, true, true); }
+            else if (stream_chk) { if (stream_wu == 6) SEEQ_STREAM2_BOTH(6, true, false); else SEEQ_STREAM2_BOTH(8, true, false); }
+            else { if (stream_wu == 6) SEEQ_STREAM2_BOTH(6, false, false); else SEEQ_STREAM2_BOTH(8, false, false); }
+#undef SEEQ_STREAM2_BOTH
 #undef SEEQ_STREAM2_LAUNCH
          }
          else if (use_stream) {

@@ -30,30 +30,81 @@
 #include "seeq_internal.h"
 
 /* ------------------------------------------------------------------------ */
-/* Read-ahead state, one per open seeqfile_t (kept beside the public struct  */
-/* so that its layout, reference seeq.h:55-60, is untouched).               */
+/* The ingest pipeline, one per open seeqfile_t (kept beside the public       */
+/* struct so that its layout, reference seeq.h:55-60, is untouched).          */
+/*                                                                            */
+/*   reader thread : file -> page-locked chunks (cut at the last '\n', the    */
+/*                   unfinished tail line carried into the next chunk)        */
+/*   GPU lanes     : chunk k+1 is staged (H2D) and scanned on its own stream  */
+/*                   while chunk k is still being scanned / replayed; two     */
+/*                   lanes per device, SEEQ_DEVICES=0,1,.. spreads successive */
+/*                   chunks over several GPUs (lines are independent: the     */
+/*                   host just adds the counts and runs the line number on)   */
+/*   caller        : replays the records of the oldest chunk call by call     */
 /* ------------------------------------------------------------------------ */
+#define MAX_SLOTS 12
+#define MAX_LANES 16
+enum { SL_FREE = 0, SL_FILLING, SL_FILLED, SL_SCANNING, SL_READY };
+
+typedef struct lane_t {
+   int                device;
+   seeqdev_pattern_t *pat;       /* the engine's own pattern on its device, a private copy on any other device */
+   int                own_pat;
+   seeqdev_scan_t    *scan;
+   int                slot;      /* index of the chunk whose scan is in flight, -1: idle */
+} lane_t;
+
+typedef struct slot_t {
+   char            *buf;         /* page-locked chunk */
+   size_t           cap, len;    /* capacity, bytes read */
+   size_t           avail;       /* bytes that belong to complete lines (all of len at EOF) */
+   int              eof;         /* the input ended with this chunk */
+   int              state;
+   /* the scan of buf[scan_from, avail) */
+   int              lane;
+   unsigned long    eng_id;
+   int              opt_key, want;
+   size_t           scan_from;
+   seeqdev_counts_t cnt;
+   seeqdev_hit_t   *rec;
+   uint64_t        *rec_off;     /* per record: offset of its line, relative to scan_from */
+   size_t           rec_cap;
+   size_t           counted;     /* counted lines replayed since scan_from */
+   size_t           rec_pos;
+} slot_t;
+
 typedef struct fstate_t {
    struct fstate_t *next;
    seeqfile_t      *key;
-   char            *buf;       /* chunk */
-   size_t           cap, len;  /* capacity, bytes read */
-   size_t           avail;     /* bytes that belong to complete lines (all of len at EOF) */
-   size_t           pos;       /* next unread byte */
-   int              eof;
-   /* cached GPU scan of buf[scan_from, avail) */
-   int              have;
-   unsigned long    eng_id;
-   int              opt_key;
-   size_t           counted;   /* counted lines replayed since scan_from */
-   seeqdev_hit_t   *rec;
-   uint64_t        *rec_off;   /* per record: offset of its line, relative to scan_from */
-   size_t           rec_cap, nrec, rec_pos;
-   size_t           scan_from; /* where in buf the cached scan started */
-   size_t           scan_lines;/* counted lines in the cached scan */
+   FILE            *fdi;
+   int              raw_fd;      /* not a regular file: the stream is unbuffered and read with read(2), chunks are handed over as lines arrive */
+   slot_t           slot[MAX_SLOTS];
+   int              nslots;
+   unsigned long    head;        /* sequence number of the chunk being replayed (slot = seq % nslots) */
+   unsigned long    filled;      /* chunks the reader has published */
+   size_t           pos;         /* next unread byte of the head chunk */
+   pthread_t        reader;
+   pthread_mutex_t  mu;
+   pthread_cond_t   cv;
+   int              sync_init, reader_on, reader_stop, reader_done, reader_err, waiting;
+   lane_t           lane[MAX_LANES];
+   int              nlanes, next_lane;
+   unsigned long    lanes_eng;
+   seeqdev_pattern_t *dev_pat[MAX_LANES];   /* private pattern copies, one per foreign device */
+   /* -z / --verbose */
+   double           t_read, t_wait_reader, t_wait_gpu, ms_h2d, ms_kernels;
+   size_t           bytes, chunks;
 } fstate_t;
 
 static fstate_t *g_states = NULL;
+static int g_profile = 0;          /* seeq -z: scan contexts record HIP events (H2D, kernels) */
+
+static double now_s(void)
+{
+   struct timespec t;
+   clock_gettime(CLOCK_MONOTONIC, &t);
+   return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 static size_t chunk_bytes(void)
 {
@@ -73,9 +124,45 @@ static fstate_t *state_of(seeqfile_t *f, int create)
    fstate_t *s = calloc(1, sizeof *s);
    if (!s) return NULL;
    s->key = f;
+   s->fdi = f->fdi;
    s->next = g_states;
    g_states = s;
    return s;
+}
+
+/* Wait for the scans in flight and forget every cached result (the chunks stay). */
+static void quiesce(fstate_t *s)
+{
+   for (int i = 0; i < s->nlanes; i++) {
+      lane_t *ln = &s->lane[i];
+      if (ln->slot >= 0) {
+         seeqdev_counts_t c;
+         (void)seeqdevScanFetch(ln->scan, &c);
+         ln->slot = -1;
+      }
+   }
+   if (s->sync_init) pthread_mutex_lock(&s->mu);
+   for (int i = 0; i < s->nslots; i++)
+      if (s->slot[i].state == SL_SCANNING || s->slot[i].state == SL_READY) s->slot[i].state = SL_FILLED;
+   if (s->sync_init) pthread_mutex_unlock(&s->mu);
+}
+
+static void drop_lanes(fstate_t *s)
+{
+   quiesce(s);
+   for (int i = 0; i < s->nlanes; i++)
+      if (s->lane[i].scan) seeqdevScanFree(s->lane[i].scan);
+   for (int i = 0; i < MAX_LANES; i++)
+      if (s->dev_pat[i]) { seeqdevPatternFree(s->dev_pat[i]); s->dev_pat[i] = NULL; }
+   s->nlanes = 0;
+   s->lanes_eng = 0;
+}
+
+/* seeqFree() of an engine whose pattern the lanes of an open file still use (the CLI frees the seeq_t first). */
+void seeq_file_forget_engine(unsigned long eng_id)
+{
+   for (fstate_t *s = g_states; s; s = s->next)
+      if (s->nlanes && s->lanes_eng == eng_id) drop_lanes(s);
 }
 
 static void state_drop(seeqfile_t *f)
@@ -84,9 +171,21 @@ static void state_drop(seeqfile_t *f)
       if ((*pp)->key == f) {
          fstate_t *s = *pp;
          *pp = s->next;
-         seeqdevHostFree(s->buf);
-         free(s->rec);
-         free(s->rec_off);
+         if (s->reader_on) {                              /* it may sit in read(2) on a pipe: cancel, then join */
+            pthread_mutex_lock(&s->mu);
+            s->reader_stop = 1;
+            pthread_cond_broadcast(&s->cv);
+            pthread_mutex_unlock(&s->mu);
+            pthread_cancel(s->reader);
+            pthread_join(s->reader, NULL);
+         }
+         drop_lanes(s);
+         for (int i = 0; i < MAX_SLOTS; i++) {
+            seeqdevHostFree(s->slot[i].buf);
+            free(s->slot[i].rec);
+            free(s->slot[i].rec_off);
+         }
+         if (s->sync_init) { pthread_mutex_destroy(&s->mu); pthread_cond_destroy(&s->cv); }
          free(s);
          return;
       }
@@ -95,7 +194,7 @@ static void state_drop(seeqfile_t *f)
 
 /* fread() for big reads of a regular file: the range is split over a few threads that pread() it straight into the
  * (page-locked) chunk buffer -- one thread copies out of the page cache at ~5-10 GB/s, four come close to the link
- * speed the GPU side can take.  Pipes, small reads and anything unusual go through fread(). */
+ * speed the GPU side can take. */
 typedef struct { int fd; char *dst; size_t n; off_t off; size_t got; } rd_job_t;
 
 static void *rd_worker(void *p)
@@ -148,46 +247,306 @@ static size_t chunk_read(FILE *fdi, char *dst, size_t want)
    return fread(dst, 1, want, fdi);
 }
 
-/* Bring the next chunk in: keep the unfinished tail line, read on, and cut
- * at the last newline (everything, at EOF).  Returns -1 on allocation failure. */
-static int refill(fstate_t *s, FILE *fdi)
+/* A chunk buffer of at least `want` bytes, contents kept. */
+static int slot_reserve(slot_t *sl, size_t want)
 {
-   const size_t tail = s->len - s->avail;
-   if (tail && s->avail) memmove(s->buf, s->buf + s->avail, tail);
-   s->len = tail;
-   s->avail = 0;
-   s->pos = 0;
-   s->have = 0;
-   if (!s->buf) {
-      s->cap = chunk_bytes();
-      s->buf = seeqdevHostAlloc(s->cap);            /* page-locked: H2D at link speed */
-      if (!s->buf) return -1;
+   if (sl->cap >= want && sl->buf) return 0;
+   size_t cap = sl->cap ? sl->cap : chunk_bytes();
+   while (cap < want) cap *= 2;
+   char *g = seeqdevHostAlloc(cap);                      /* page-locked: H2D at link speed */
+   if (!g) return -1;
+   if (sl->buf) {
+      memcpy(g, sl->buf, sl->len);
+      seeqdevHostFree(sl->buf);
    }
+   sl->buf = g;
+   sl->cap = cap;
+   return 0;
+}
+
+/* The reader thread: chunk after chunk, each cut at its last newline (everything, at EOF); the unfinished tail
+ * line opens the next chunk.  (reference seeq.c:361: getline, one line at a time.) */
+static void *reader_main(void *arg)
+{
+   fstate_t *s = arg;
+   int unused;
+   pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &unused);
+   const char *carry = NULL;
+   size_t ncarry = 0;
+   int first_raw = s->raw_fd;
+   for (unsigned long seq = 0;; seq++) {
+      slot_t *sl = &s->slot[seq % (unsigned long)s->nslots];
+      pthread_mutex_lock(&s->mu);
+      while (sl->state != SL_FREE && !s->reader_stop) pthread_cond_wait(&s->cv, &s->mu);
+      if (s->reader_stop) { pthread_mutex_unlock(&s->mu); break; }
+      sl->state = SL_FILLING;
+      pthread_mutex_unlock(&s->mu);
+      int err = 0, eof = 0;
+      sl->len = 0;
+      if (slot_reserve(sl, ncarry + 4096)) err = errno ? errno : ENOMEM;
+      if (!err && ncarry) { memmove(sl->buf, carry, ncarry); sl->len = ncarry; }
+      size_t nl_end = 0;                                  /* offset just behind the last newline seen in this chunk */
+      while (!err) {
+         if (sl->len == sl->cap && slot_reserve(sl, 2 * sl->cap)) { err = errno ? errno : ENOMEM; break; }   /* one line longer than the chunk */
+         const double t0 = now_s();
+         size_t got = 0;
+         if (s->raw_fd) {
+            if (first_raw) {                              /* the byte seeqOpen sniffed and pushed back */
+               first_raw = 0;
+               const int c = getc(s->fdi);
+               if (c != EOF) { sl->buf[sl->len] = (char)c; got = 1; }
+            }
+            if (!got) {
+               pthread_setcancelstate(PTHREAD_CANCEL_ENABLE, &unused);
+               ssize_t r;
+               do r = read(fileno(s->fdi), sl->buf + sl->len, sl->cap - sl->len); while (r < 0 && errno == EINTR);
+               pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &unused);
+               if (r < 0) { err = errno; break; }
+               got = (size_t)r;
+            }
+         } else {
+            pthread_setcancelstate(PTHREAD_CANCEL_ENABLE, &unused);
+            got = chunk_read(s->fdi, sl->buf + sl->len, sl->cap - sl->len);
+            pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &unused);
+         }
+         s->t_read += now_s() - t0;
+         if (got == 0) { eof = 1; break; }
+         const char *nl = memrchr(sl->buf + sl->len, '\n', got);
+         if (nl) nl_end = (size_t)(nl - sl->buf) + 1;
+         sl->len += got;
+         if (!nl_end) continue;                           /* no complete line yet */
+         if (sl->len == sl->cap) break;
+         if (s->raw_fd) {                                 /* a pipe: hand the lines over as soon as somebody waits for them */
+            pthread_mutex_lock(&s->mu);
+            const int waiting = s->waiting;
+            pthread_mutex_unlock(&s->mu);
+            if (waiting) break;
+         }
+      }
+      sl->avail = eof ? sl->len : nl_end;
+      sl->eof = eof;
+      carry = sl->buf + sl->avail;
+      ncarry = sl->len - sl->avail;
+      pthread_mutex_lock(&s->mu);
+      if (err) s->reader_err = err;
+      else { sl->state = SL_FILLED; s->filled = seq + 1; s->bytes += sl->avail; }
+      if (err || eof) s->reader_done = 1;
+      pthread_cond_broadcast(&s->cv);
+      pthread_mutex_unlock(&s->mu);
+      if (err || eof) break;
+   }
+   return NULL;
+}
+
+/* SEEQ_DEVICES="0,2,5" / "0-7" / "all": the devices successive chunks go to.  Default: the engine's own device. */
+static int parse_devices(int *dev, int maxn, int own)
+{
+   const char *env = getenv("SEEQ_DEVICES");
+   const int have = seeqdevDeviceCount();
+   int n = 0;
+   if (env && *env) {
+      if (!strcmp(env, "all")) {
+         for (int d = 0; d < have && n < maxn; d++) dev[n++] = d;
+      } else {
+         const char *p = env;
+         while (*p && n < maxn) {
+            char *e;
+            long a = strtol(p, &e, 10), b = a;
+            if (e == p) break;
+            if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); if (e == p) break; }
+            for (long d = a; d <= b && n < maxn; d++)
+               if (d >= 0 && d < have) dev[n++] = (int)d;
+            p = *e == ',' ? e + 1 : e;
+            if (*e && *e != ',') break;
+         }
+      }
+   }
+   if (n == 0) dev[n++] = own;
+   return n;
+}
+
+static int ensure_lanes(fstate_t *s, seeq_engine_t *eng, const seeq_t *sq)
+{
+   if (s->nlanes && s->lanes_eng == eng->id) return 0;
+   if (s->nlanes) drop_lanes(s);
+   const int own = seeqdevPatternDevice(eng->pat);
+   int dev[MAX_LANES / 2];
+   const int ndev = parse_devices(dev, MAX_LANES / 2, own);
+   int per = 2;                                           /* lanes per device: the H2D of one overlaps the kernels of the other */
+   const char *env = getenv("SEEQ_LANES");
+   if (env && atoi(env) >= 1 && atoi(env) <= 4) per = atoi(env);
+   while (ndev * per > MAX_LANES) per--;
+   int n = 0, rc = 0;
+   for (int k = 0; k < ndev * per && !rc; k++) {
+      const int d = dev[k % ndev];                        /* consecutive lanes sit on different devices */
+      lane_t *ln = &s->lane[n];
+      memset(ln, 0, sizeof *ln);
+      ln->device = d;
+      ln->slot = -1;
+      if (seeqdevSetDevice(d)) { rc = -1; break; }
+      if (d == own) ln->pat = eng->pat;
+      else {
+         if (!s->dev_pat[k % ndev]) s->dev_pat[k % ndev] = seeqdevPatternNew(sq->keys, sq->wlen, sq->tau);
+         ln->pat = s->dev_pat[k % ndev];
+      }
+      if (ln->pat) ln->scan = seeqdevScanNew(NULL);
+      if (!ln->pat || !ln->scan) { rc = -1; break; }
+      if (g_profile) (void)seeqdevScanSetProfiling(ln->scan, 1);
+      n++;
+   }
+   s->nlanes = n;
+   (void)seeqdevSetDevice(own);
+   if (rc) { drop_lanes(s); return -1; }
+   s->lanes_eng = eng->id;
+   s->next_lane = 0;
+   return 0;
+}
+
+static int ensure_reader(fstate_t *s)
+{
+   if (s->reader_on) return 0;
+   if (!s->sync_init) {
+      pthread_mutex_init(&s->mu, NULL);
+      pthread_cond_init(&s->cv, NULL);
+      s->sync_init = 1;
+   }
+   s->nslots = s->nlanes + 2;                             /* one being filled, one being replayed, the rest on the GPUs */
+   if (s->nslots > MAX_SLOTS) s->nslots = MAX_SLOTS;
+   if (s->nslots < 3) s->nslots = 3;
+   if (pthread_create(&s->reader, NULL, reader_main, s)) return -1;
+   s->reader_on = 1;
+   return 0;
+}
+
+/* Chunk states change under the mutex: the reader polls the state of the chunk it wants next. */
+static void set_state(fstate_t *s, slot_t *sl, int st)
+{
+   pthread_mutex_lock(&s->mu);
+   sl->state = st;
+   pthread_mutex_unlock(&s->mu);
+}
+
+/* Enqueue the scan of chunk `sl` on an idle lane (asynchronous); 0 when none is idle. */
+static int begin_scan(fstate_t *s, slot_t *sl, int idx, size_t from, seeq_engine_t *eng, int dev_opt, int want)
+{
+   lane_t *ln = NULL;
+   int li = -1;
+   for (int k = 0; k < s->nlanes; k++) {
+      const int c = (s->next_lane + k) % s->nlanes;
+      if (s->lane[c].slot < 0) { ln = &s->lane[c]; li = c; break; }
+   }
+   if (!ln) return 0;
+   s->next_lane = (li + 1) % s->nlanes;
+   sl->scan_from = from;
+   sl->eng_id = eng->id;
+   sl->opt_key = dev_opt;
+   sl->want = want;
+   sl->lane = li;
+   sl->counted = 0;
+   sl->rec_pos = 0;
+   if (seeqdevScanHostBegin(ln->scan, ln->pat, sl->buf + from, sl->avail - from, dev_opt, want)) return -1;
+   ln->slot = idx;
+   set_state(s, sl, SL_SCANNING);
+   s->chunks++;
+   return 1;
+}
+
+static int finish_scan(fstate_t *s, slot_t *sl)
+{
+   lane_t *ln = &s->lane[sl->lane];
+   const double t0 = now_s();
+   const int rc = seeqdevScanFetch(ln->scan, &sl->cnt);
+   s->t_wait_gpu += now_s() - t0;
+   ln->slot = -1;
+   if (rc) return -1;
+   if (g_profile) {
+      float ms[4] = {0, 0, 0, 0}, h2d = 0;
+      (void)seeqdevScanLastTimes(ln->scan, ms);
+      (void)seeqdevScanLastCopyMs(ln->scan, &h2d);
+      s->ms_kernels += ms[3];
+      s->ms_h2d += h2d;
+   }
+   if (sl->want != SEEQDEV_WANT_RECORDS) return 0;
+   const size_t n = sl->cnt.nrecords;
+   if (n > sl->rec_cap) {
+      seeqdev_hit_t *g = realloc(sl->rec, n * sizeof *g);
+      if (!g) { seeqerr = 0; return -1; }
+      sl->rec = g;
+      uint64_t *o = realloc(sl->rec_off, n * sizeof *o);
+      if (!o) { seeqerr = 0; return -1; }
+      sl->rec_off = o;
+      sl->rec_cap = n;
+   }
+   if (seeqdevScanCopyRecords(ln->scan, sl->rec, 0, n)) return -1;
+   if (seeqdevScanCopyOffsets(ln->scan, sl->rec_off, 0, n)) return -1;
+   return 0;
+}
+
+/* The oldest chunk, scanned for (engine, options, want) from s->pos on; *out = NULL at the end of the input.
+ * Side effect: every published chunk behind it that finds an idle lane gets its scan enqueued (read-ahead). */
+static int pump(fstate_t *s, seeq_engine_t *eng, const seeq_t *sq, int dev_opt, int want, slot_t **out)
+{
+   *out = NULL;
+   if (ensure_lanes(s, eng, sq)) return -1;
+   if (ensure_reader(s)) { seeqerr = 0; return -1; }
    for (;;) {
-      if (s->len == s->cap) {           /* one line longer than the chunk: grow */
-         char *g = seeqdevHostAlloc(2 * s->cap);
-         if (!g) return -1;
-         memcpy(g, s->buf, s->len);
-         seeqdevHostFree(s->buf);
-         s->buf = g;
-         s->cap *= 2;
+      pthread_mutex_lock(&s->mu);
+      const unsigned long filled = s->filled;
+      pthread_mutex_unlock(&s->mu);
+      /* (only this thread moves chunks out of FILLED and back; the reader only touches FREE chunks) */
+      slot_t *head = &s->slot[s->head % (unsigned long)s->nslots];
+      if (s->head < filled && head->state == SL_READY &&
+          (head->eng_id != eng->id || head->opt_key != dev_opt || head->want != want)) set_state(s, head, SL_FILLED);   /* scanned for another pattern / option set */
+      for (unsigned long seq = s->head; seq < filled; seq++) {
+         const int idx = (int)(seq % (unsigned long)s->nslots);
+         slot_t *sl = &s->slot[idx];
+         if (sl->state != SL_FILLED) continue;
+         const size_t from = seq == s->head ? s->pos : 0;
+         if (from >= sl->avail) {                         /* nothing (left) to scan */
+            memset(&sl->cnt, 0, sizeof sl->cnt);
+            sl->scan_from = from; sl->eng_id = eng->id; sl->opt_key = dev_opt; sl->want = want;
+            sl->counted = 0; sl->rec_pos = 0;
+            set_state(s, sl, SL_READY);
+            continue;
+         }
+         const int r = begin_scan(s, sl, idx, from, eng, dev_opt, want);
+         if (r < 0) return -1;
+         if (r == 0) break;                               /* every lane is busy */
       }
-      const size_t got = chunk_read(fdi, s->buf + s->len, s->cap - s->len);
-      const size_t scan_from = s->len;
-      s->len += got;
-      if (got == 0) {
-         s->eof = 1;
-         s->avail = s->len;
-         return 0;
+      if (s->head < filled) {
+         if (head->state == SL_SCANNING) {
+            if (finish_scan(s, head)) return -1;
+            set_state(s, head, SL_READY);
+            continue;                                     /* its lane is idle again: feed it before replaying */
+         }
+         if (head->state == SL_READY) { *out = head; return 0; }
       }
-      /* last newline: search only what is new when nothing older had one */
-      (void)scan_from;
-      const char *nl = memrchr(s->buf, '\n', s->len);
-      if (nl) {
-         s->avail = (size_t)(nl - s->buf) + 1;
-         return 0;
+      pthread_mutex_lock(&s->mu);
+      if (s->reader_err) { errno = s->reader_err; seeqerr = 0; pthread_mutex_unlock(&s->mu); return -1; }
+      if (s->filled == filled) {
+         if (s->reader_done && s->head >= s->filled) { pthread_mutex_unlock(&s->mu); return 0; }   /* end of the input */
+         const double t0 = now_s();
+         s->waiting = 1;
+         /* about to sleep until a pipe delivers more: what the caller has printed so far should be visible by then
+            (`producer | seeq ... | consumer` behaves line by line with the reference's getline loop) */
+         if (s->raw_fd) { pthread_mutex_unlock(&s->mu); fflush(stdout); pthread_mutex_lock(&s->mu); if (s->filled != filled) { s->waiting = 0; pthread_mutex_unlock(&s->mu); continue; } }
+         pthread_cond_wait(&s->cv, &s->mu);
+         s->waiting = 0;
+         s->t_wait_reader += now_s() - t0;
       }
+      pthread_mutex_unlock(&s->mu);
    }
+}
+
+/* The head chunk is replayed: give it back to the reader. */
+static void advance(fstate_t *s)
+{
+   pthread_mutex_lock(&s->mu);
+   s->slot[s->head % (unsigned long)s->nslots].state = SL_FREE;
+   s->head++;
+   s->pos = 0;
+   pthread_cond_broadcast(&s->cv);
+   pthread_mutex_unlock(&s->mu);
 }
 
 /* getline-like: sq->string holds the line, NUL-terminated (seeq.c:361-364). */
@@ -220,6 +579,12 @@ seeqfile_t *seeqOpen(const char *file)
    }
    f->fdi = fdi;
    f->line = 0;
+   /* Not a regular file (a pipe, a terminal): read with read(2) from the reader thread so that lines can be handed on as
+      they arrive instead of when 64 MiB are full; the stream is made unbuffered first, so that nothing but the byte
+      sniffed below is ever held back in the FILE. */
+   struct stat st;
+   int raw = 0;
+   if (fstat(fileno(fdi), &st) != 0 || !S_ISREG(st.st_mode)) raw = setvbuf(fdi, NULL, _IONBF, 0) == 0;
    const int c = getc(fdi);               /* FASTA sniff, reference seeq.c:243-253 */
    if (c == '>') {
       f->flags = 1;
@@ -232,6 +597,10 @@ seeqfile_t *seeqOpen(const char *file)
       }
    }
    if (c != EOF) ungetc(c, fdi);
+   if (raw) {
+      fstate_t *s = state_of(f, 1);
+      if (s) s->raw_fd = 1;
+   }
    return f;
 }
 
@@ -248,32 +617,6 @@ int seeqClose(seeqfile_t *f)
       seeqerr = errno;
       return -1;
    }
-   return 0;
-}
-
-/* Scan buf[pos, avail) once for the given options and cache the records. */
-static int scan_chunk(fstate_t *s, seeq_engine_t *eng, int dev_opt, int want, seeqdev_counts_t *cnt)
-{
-   seeqdev_scan_t *scan = seeq_engine_scan(eng);
-   if (!scan) return -1;
-   if (seeqdevScanHost(scan, eng->pat, s->buf + s->pos, s->avail - s->pos, dev_opt, want, cnt)) return -1;
-   if (want != SEEQDEV_WANT_RECORDS) return 0;
-   if (cnt->nrecords > s->rec_cap) {
-      seeqdev_hit_t *g = realloc(s->rec, cnt->nrecords * sizeof *g);
-      if (!g) { seeqerr = 0; return -1; }
-      s->rec = g;
-      uint64_t *o = realloc(s->rec_off, cnt->nrecords * sizeof *o);
-      if (!o) { seeqerr = 0; return -1; }
-      s->rec_off = o;
-      s->rec_cap = cnt->nrecords;
-   }
-   if (seeqdevScanCopyRecords(scan, s->rec, 0, cnt->nrecords)) return -1;
-   if (seeqdevScanCopyOffsets(scan, s->rec_off, 0, cnt->nrecords)) return -1;
-   s->scan_from = s->pos;
-   s->scan_lines = cnt->nlines;
-   s->nrec = cnt->nrecords;
-   s->rec_pos = 0;
-   s->counted = 0;
    return 0;
 }
 
@@ -313,42 +656,47 @@ long seeqFileMatch(seeqfile_t *sqfile, seeq_t *sq, int match_opt, int file_opt)
    if (!eng) { errno = EINVAL; return -1; }
    fstate_t *s = state_of(sqfile, 1);
    if (!s) return -1;
+   if (!s->reader_on) s->fdi = sqfile->fdi;          /* (the reader thread owns the stream from its start on) */
 
    /* SQ_STREAM has no meaning per file line (getline has already split at '\n'). */
    const int dev_opt = (match_opt & (MASK_MATCH | MASK_NONDNA)) | (fasta ? SEEQDEV_FASTA : 0);
    const int counting = file_opt == SQ_COUNTLINES || file_opt == SQ_COUNTMATCH;
+   const int want = file_opt == SQ_COUNTLINES ? SEEQDEV_WANT_COUNTLINES
+                  : file_opt == SQ_COUNTMATCH ? SEEQDEV_WANT_COUNTMATCH : SEEQDEV_WANT_RECORDS;
    long count = 0;
    const size_t startline = sqfile->line;
 
    for (;;) {
-      if (s->pos >= s->avail) {
-         if (s->eof) break;
-         if (refill(s, sqfile->fdi)) { seeqerr = 0; return -1; }
-         if (s->avail == 0) continue;          /* eof with nothing left -> break above */
+      slot_t *c;
+      if (pump(s, eng, sq, dev_opt, want, &c)) return -1;
+      if (!c) break;                           /* end of the input, everything replayed */
+      if (s->pos >= c->avail) {                /* this chunk is done: the reader may have it back */
+         advance(s);
+         continue;
       }
       if (counting) {
          /* Whole chunk in one go: only the counts travel back (seeq.c:104-107). */
-         seeqdev_counts_t cnt;
-         const int want = file_opt == SQ_COUNTLINES ? SEEQDEV_WANT_COUNTLINES : SEEQDEV_WANT_COUNTMATCH;
-         if (scan_chunk(s, eng, dev_opt, want, &cnt)) return -1;
+         const seeqdev_counts_t cnt = c->cnt;
          count += (long)(file_opt == SQ_COUNTLINES ? cnt.nmatchlines : cnt.nhits);
          sqfile->line += cnt.nlines;
          /* side effects the reference leaves behind: last line in sq->string, last header in info */
-         size_t e = s->avail;
-         if (e > s->pos && s->buf[e - 1] == '\n') e--;
-         const char *b = e > s->pos ? memrchr(s->buf + s->pos, '\n', e - s->pos) : NULL;
-         const size_t ls = b ? (size_t)(b - s->buf) + 1 : s->pos;
-         if (set_string(sq, s->buf + ls, e - ls)) { seeqerr = 0; return -1; }
+         {
+            size_t e = c->avail;
+            if (e > s->pos && c->buf[e - 1] == '\n') e--;
+            const char *b = e > s->pos ? memrchr(c->buf + s->pos, '\n', e - s->pos) : NULL;
+            const size_t ls = b ? (size_t)(b - c->buf) + 1 : s->pos;
+            if (set_string(sq, c->buf + ls, e - ls)) { seeqerr = 0; return -1; }
+         }
          sq->hits = 0;
          if (fasta && cnt.nheaders) {
-            size_t q = s->avail;
+            size_t q = c->avail;
             while (q > s->pos) {               /* last line of the chunk that starts with '>' */
                size_t le = q;
-               if (s->buf[le - 1] == '\n') le--;
-               const char *p = le > s->pos ? memrchr(s->buf + s->pos, '\n', le - s->pos) : NULL;
-               const size_t lb = p ? (size_t)(p - s->buf) + 1 : s->pos;
-               if (s->buf[lb] == '>' && le > lb) {
-                  char *dup = strndup(s->buf + lb, le - lb);
+               if (c->buf[le - 1] == '\n') le--;
+               const char *p = le > s->pos ? memrchr(c->buf + s->pos, '\n', le - s->pos) : NULL;
+               const size_t lb = p ? (size_t)(p - c->buf) + 1 : s->pos;
+               if (c->buf[lb] == '>' && le > lb) {
+                  char *dup = strndup(c->buf + lb, le - lb);
                   if (!dup) { seeqerr = 666; return -1; }
                   sqfile->info = dup;          /* the reference does not free the old one either (seeq.c:368) */
                   break;
@@ -356,57 +704,50 @@ long seeqFileMatch(seeqfile_t *sqfile, seeq_t *sq, int match_opt, int file_opt)
                q = lb;
             }
          }
-         s->pos = s->avail;
+         s->pos = c->avail;
          continue;
       }
 
-      const int key = dev_opt;
-      if (!s->have || s->eng_id != eng->id || s->opt_key != key) {
-         seeqdev_counts_t cnt;
-         if (scan_chunk(s, eng, dev_opt, SEEQDEV_WANT_RECORDS, &cnt)) return -1;
-         s->have = 1;
-         s->eng_id = eng->id;
-         s->opt_key = key;
-      }
+      const size_t nrec = c->cnt.nrecords;
       if (file_opt == SQ_MATCH) {
          /* Jump from hit to hit: every line in between has 0 hits, so the reference's loop (seeq.c:361-386)
             would just count it (and remember FASTA headers).  The device gave us each record's line offset. */
-         if (s->rec_pos < s->nrec) {
-            const seeqdev_hit_t *r = s->rec + s->rec_pos;
-            const size_t lo = s->scan_from + (size_t)s->rec_off[s->rec_pos];
+         if (c->rec_pos < nrec) {
+            const seeqdev_hit_t *r = c->rec + c->rec_pos;
+            const size_t lo = c->scan_from + (size_t)c->rec_off[c->rec_pos];
             size_t k = 1;
-            while (s->rec_pos + k < s->nrec && r[k].line == r->line) k++;
-            const char *line = s->buf + lo;
-            const char *nl = memchr(line, '\n', s->avail - lo);
-            const size_t n = nl ? (size_t)(nl - line) : s->avail - lo;
-            if (fasta && last_header(sqfile, s->buf, s->pos, lo)) return -1;
-            sqfile->line += r->line - s->counted;                  /* seeq.c:377, for all the lines skipped */
-            s->counted = r->line;
+            while (c->rec_pos + k < nrec && r[k].line == r->line) k++;
+            const char *line = c->buf + lo;
+            const char *nl = memchr(line, '\n', c->avail - lo);
+            const size_t n = nl ? (size_t)(nl - line) : c->avail - lo;
+            if (fasta && last_header(sqfile, c->buf, s->pos, lo)) return -1;
+            sqfile->line += r->line - c->counted;                  /* seeq.c:377, for all the lines skipped */
+            c->counted = r->line;
             s->pos = lo + n + (nl ? 1 : 0);
             if (set_string(sq, line, n)) { seeqerr = 0; return -1; }
             if (seeq_store_hits(sq, r, k)) return -1;
-            s->rec_pos += k;
+            c->rec_pos += k;
             return 1;                                               /* count = k > 0: seeq.c:385-386 */
          }
          /* no hit left in this chunk: consume the rest */
-         if (fasta && last_header(sqfile, s->buf, s->pos, s->avail)) return -1;
-         sqfile->line += s->scan_lines - s->counted;
-         s->counted = s->scan_lines;
-         if (s->avail > s->pos) {                                   /* the last line read stays in sq->string */
-            size_t e = s->avail;
-            if (s->buf[e - 1] == '\n') e--;
-            const char *b = e > s->pos ? memrchr(s->buf + s->pos, '\n', e - s->pos) : NULL;
-            const size_t ls = b ? (size_t)(b - s->buf) + 1 : s->pos;
-            if (set_string(sq, s->buf + ls, e - ls)) { seeqerr = 0; return -1; }   /* headers too: getline put them there */
+         if (fasta && last_header(sqfile, c->buf, s->pos, c->avail)) return -1;
+         sqfile->line += c->cnt.nlines - c->counted;
+         c->counted = c->cnt.nlines;
+         if (c->avail > s->pos) {                                   /* the last line read stays in sq->string */
+            size_t e = c->avail;
+            if (c->buf[e - 1] == '\n') e--;
+            const char *b = e > s->pos ? memrchr(c->buf + s->pos, '\n', e - s->pos) : NULL;
+            const size_t ls = b ? (size_t)(b - c->buf) + 1 : s->pos;
+            if (set_string(sq, c->buf + ls, e - ls)) { seeqerr = 0; return -1; }   /* headers too: getline put them there */
             sq->hits = 0;
          }
-         s->pos = s->avail;
+         s->pos = c->avail;
          continue;
       }
       /* SQ_ANY / SQ_NOMATCH: replay line by line (seeq.c:361-386). */
-      const char *line = s->buf + s->pos;
-      const char *nl = memchr(line, '\n', s->avail - s->pos);
-      const size_t n = nl ? (size_t)(nl - line) : s->avail - s->pos;
+      const char *line = c->buf + s->pos;
+      const char *nl = memchr(line, '\n', c->avail - s->pos);
+      const size_t n = nl ? (size_t)(nl - line) : c->avail - s->pos;
       s->pos += n + (nl ? 1 : 0);
       if (fasta && n > 0 && line[0] == '>') {                     /* seeq.c:367-374 */
          if (set_string(sq, line, n)) { seeqerr = 0; return -1; }
@@ -415,17 +756,17 @@ long seeqFileMatch(seeqfile_t *sqfile, seeq_t *sq, int match_opt, int file_opt)
          continue;
       }
       sqfile->line++;                                             /* seeq.c:377 */
-      s->counted++;
+      c->counted++;
       size_t k = 0;
-      while (s->rec_pos + k < s->nrec && s->rec[s->rec_pos + k].line == s->counted) k++;
+      while (c->rec_pos + k < nrec && c->rec[c->rec_pos + k].line == c->counted) k++;
       const long rval = (long)k;
       const int stop = file_opt == SQ_ANY || (rval == 0 && file_opt == SQ_NOMATCH);
       /* sq->string / sq->match only matter for the line a call returns on, or the last line of the file */
-      if (stop || s->pos >= s->avail) {
+      if (stop || s->pos >= c->avail) {
          if (set_string(sq, line, n)) { seeqerr = 0; return -1; }
-         if (seeq_store_hits(sq, s->rec + s->rec_pos, k)) return -1;
+         if (seeq_store_hits(sq, c->rec + c->rec_pos, k)) return -1;
       }
-      s->rec_pos += k;
+      c->rec_pos += k;
       count += rval;
       if (stop) return 1;                                         /* seeq.c:385-386 */
    }
@@ -507,6 +848,7 @@ int seeq(char *expression, char *input, struct seeqarg_t args)
    if (args.verbose) {
       fprintf(stderr, "\nmatching...\n");
       clock_gettime(CLOCK_MONOTONIC, &t0);
+      g_profile = 1;                          /* HIP events around the H2D copies and the kernels of every chunk */
    }
    int opt = 0;
    if (args.non_dna == 1) opt |= SQ_CONVERT;
@@ -538,8 +880,18 @@ int seeq(char *expression, char *input, struct seeqarg_t args)
    }
    if (args.verbose) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
+      const double wall = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
       fprintf(stderr, "engine: %s (HIP, no DFA cache)\n", SEEQ_AMD_VERSION);
-      fprintf(stderr, "done in %.3fs\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+      const fstate_t *s = state_of(f, 0);
+      if (s && s->chunks) {
+         const double gb = (double)s->bytes / 1e9;
+         fprintf(stderr, "ingest: %zu chunk(s), %.3f GB, %d lane(s); reader %.3fs (%.2f GB/s, own thread); H2D %.1f ms (%.1f GB/s); kernels %.1f ms (%.1f GB/s);\n"
+                         "        caller waited %.3fs for the reader, %.3fs for the GPU; replay + output %.3fs\n",
+                 s->chunks, gb, s->nlanes, s->t_read, s->t_read > 0 ? gb / s->t_read : 0.0, s->ms_h2d, s->ms_h2d > 0 ? gb / (s->ms_h2d * 1e-3) : 0.0,
+                 s->ms_kernels, s->ms_kernels > 0 ? gb / (s->ms_kernels * 1e-3) : 0.0, s->t_wait_reader, s->t_wait_gpu,
+                 wall - s->t_wait_reader - s->t_wait_gpu);
+      }
+      fprintf(stderr, "done in %.3fs\n", wall);
    }
    seeqFree(sq);
    seeqClose(f);

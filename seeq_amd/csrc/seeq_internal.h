@@ -31,5 +31,7 @@ typedef struct seeq_engine_t {
 seeq_engine_t  *seeq_engine_of(const seeq_t *sq);
 seeqdev_scan_t *seeq_engine_scan(seeq_engine_t *eng);
 int             seeq_store_hits(seeq_t *sq, const seeqdev_hit_t *rec, size_t n);
+/* seeq_file.c: an engine is about to be freed -- open files whose read-ahead scans use its pattern let go of it */
+void            seeq_file_forget_engine(unsigned long eng_id);
 
 #endif

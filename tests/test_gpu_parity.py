@@ -367,6 +367,99 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
+def test_cli_pipelined_ingest_lanes_and_devices(gpu, capi):
+    """The ingest pipeline of seeqFileMatch: a reader thread cuts the file into chunks, successive chunks go to the
+    lanes (two per device; SEEQ_DEVICES lists the devices -- here device 0 several times, which gives the scheduling of a
+    multi-GPU run on the one GPU of the test box).  Whatever the chunk size, lane count and device list, stdout must be
+    the bytes of the single-chunk run: records in file order, line numbers running on across chunks, FASTA headers of the
+    right record."""
+    cases = [("reads_small.txt", ["-d", "3", "-b", "-f", PAT20]), ("reads_small.txt", ["-d", "3", "-c", PAT20]),
+             ("reads_small.txt", ["-d", "3", "-i", "-l", PAT20]), ("reads_small.txt", ["-d", "3", "-a", "-l", "-p", "-k", PAT20]),
+             ("fasta_small.txt", ["-d", "3", "-b", PAT20]), ("fasta_small.txt", ["-d", "3", "-c", PAT20]),
+             ("fasta_small.txt", ["-d", "3", "-l", "-p", PAT20]), ("fastq_small.txt", ["-d", "3", "-x", "1", "-a", "-f", PAT20])]
+    for name, args in cases:
+        path = os.path.join(GOLDEN, name)
+        ref = subprocess.run([capi.CLI_PATH] + args + [path], capture_output=True)
+        assert ref.returncode == 0
+        for chunk, lanes, devs in (("700", "1", None), ("4096", "2", None), ("1500", "2", "0,0"), ("3000", "4", "0,0,0"), ("65536", "3", "all")):
+            env = dict(os.environ, SEEQ_CHUNK_BYTES=chunk, SEEQ_LANES=lanes)
+            if devs:
+                env["SEEQ_DEVICES"] = devs
+            r = subprocess.run([capi.CLI_PATH] + args + [path], capture_output=True, env=env)
+            assert r.returncode == 0 and r.stdout == ref.stdout, (name, args, chunk, lanes, devs, r.stderr[-500:])
+
+
+def test_cli_pipe_streams_lines_as_they_arrive(gpu, capi):
+    """`producer | seeq PATTERN`: the reference works line by line (getline, seeq.c:361), so a match shows up as soon as its
+    line has been written.  The chunked reader must not sit on a pipe until 64 MiB have arrived."""
+    import select
+    import time
+    p = subprocess.Popen([capi.CLI_PATH, "-d", "1", "-l", "CACAGAT"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=0)
+    try:
+        def expect(text, within=60.0):
+            got = b""
+            end = time.time() + within
+            while len(got) < len(text) and time.time() < end:
+                if select.select([p.stdout], [], [], 0.5)[0]:
+                    piece = os.read(p.stdout.fileno(), 4096)
+                    if not piece:
+                        break
+                    got += piece
+            assert got == text, (got, text)
+        p.stdin.write(b"TTTTCACAGATTTT\n"); p.stdin.flush()
+        expect(b"1 TTTTCACAGATTTT\n")                     # (first chunk: includes HIP start-up)
+        p.stdin.write(b"GGGG\nAAAA\n"); p.stdin.flush()
+        time.sleep(0.3)
+        p.stdin.write(b"CACAGTT"); p.stdin.flush()          # an unfinished line ...
+        time.sleep(0.3)
+        p.stdin.write(b"\nxCACAGATx\n"); p.stdin.flush()  # ... finished here; the next one has a non-DNA byte in front
+        expect(b"4 CACAGTT\n")
+        p.stdin.close()
+        assert p.stdout.read() == b"" and p.wait(timeout=60) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+def test_filematch_pattern_switch_mid_file(gpu, capi, oracle):
+    """seeqFileMatch is resumable and takes the pattern per call (seeq.c:293): a caller that switches to another seeq_t (or
+    other options) in the middle of a file gets that pattern's answers from the next line on -- the chunks scanned ahead
+    for the old one are scanned again."""
+    code = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, %r)
+from oracle.pyoracle import Oracle, SQ_ALL, SQ_BEST
+from seeq_amd import _capi
+o = Oracle(); L = _capi.lib()
+path = os.path.join(%r, "reads_small.txt")
+lines = open(path).read().split("\n")
+if lines[-1] == "": lines.pop()
+pats = [(b"GATGTAGCGCGATTAGCCTG", 3, SQ_ALL), (b"GATTAGC", 1, SQ_BEST)]
+sqs = [L.seeqNew(p, t, 0) for p, t, _ in pats]
+f = L.seeqOpen(path.encode())
+n = 0
+while True:
+    which = (n // 7) %% 2                                   # change pattern and options every 7 lines
+    if L.seeqFileMatch(f, sqs[which], pats[which][2], 0) <= 0: break
+    n += 1
+    assert f.contents.line == n
+    got = []
+    while True:
+        m = L.seeqMatchIter(sqs[which])
+        if not m: break
+        got.append((m.contents.start, m.contents.end, m.contents.dist))
+    assert got == o.string_match(pats[which][0].decode(), pats[which][1], lines[n - 1], pats[which][2])[::-1], (n, which, got)
+assert n == len(lines), (n, len(lines))
+L.seeqFree(sqs[0])                                          # (the engine goes before the file, as in the reference's seeq())
+L.seeqClose(f); L.seeqFree(sqs[1])
+print("OK")
+''' % (ROOT, GOLDEN)
+    for chunk in ("2000", "100000"):
+        env = dict(os.environ, SEEQ_CHUNK_BYTES=chunk)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "OK" in r.stdout, (chunk, r.stdout[-300:], r.stderr[-2000:])
+
+
 def test_cli_known_answers(gpu, capi):
     path = os.path.join(GOLDEN, "testdata.txt")
     for args, exp in KA.CLI:
