@@ -432,7 +432,7 @@ def main():
         fwd_avg_ms = fwd_ms / max(1, fwd_launches)
         achieved = algo_bytes_launch / (fwd_avg_ms * 1e-3) / 1e9
         traffic = None
-        kern = sc.last_stream_kernel() or sc.last_kernel()
+        kern = sc.last_kernel()
         filt = sc.last_filter()
         pmc = os.path.join(ROOT, "profiles", "pmc_scan_kernels.json")
         traffic_src = None
@@ -446,11 +446,9 @@ def main():
             except Exception:
                 traffic = None
         notes = {
-            "k_stream": "line-agnostic table-driven scan: text read once (coalesced 128 B per lane), one LDS gather per "
-                        "character; bound by LDS gather issue (32 banks) just above the HBM stream time: see DESIGN.md",
-            "k_stream2": "line-agnostic table-driven scan, every lane walks a 1 KB stretch of the text (128 B per phase, read "
-                         "once), one LDS gather + ~5 VALU per character; bound by VALU issue / the LDS gather unit above the "
-                         "HBM stream time: see DESIGN.md",
+            "k_stream": "line-agnostic table-driven scan: text read once (coalesced 128 B per lane), one LDS gather and five VALU "
+                        "instructions per walk step, 1.375 steps per text byte; bound by the LDS gather unit (32 banks, ~80 % busy) "
+                        "with VALU issue right behind it, both above the HBM stream time: see DESIGN.md",
             "k_direct": "one-pass per-line scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte) and "
                         "on re-reading lines from L2: see DESIGN.md",
         }

@@ -106,9 +106,6 @@ int seeqdevScanLastPath(const seeqdev_scan_t * scan);
 /* 1 when the last run's k_stream walked a partition FILTER automaton (candidates verified by the exact pass)
  * instead of the pattern's complete automaton. */
 int seeqdevScanLastFilter(const seeqdev_scan_t * scan);
-/* Which table-driven scan kernel the last run used: 0 none, 1 = k_stream (a lane walks 128-byte chunks, warm-up per
- * chunk), 2 = k_stream2 (a lane walks a 1 KB stretch: read-length lines without FASTA headers). */
-int seeqdevScanLastStream(const seeqdev_scan_t * scan);
 
 /* Enqueue (asynchronously, on the context's stream) the whole hot path over
  * d_text[0..nbytes): newline index -> per-line forward scan -> hit-line
@@ -151,6 +148,17 @@ int seeqdevStringMatch(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, con
  * that fills the next chunk meanwhile, and one context per GPU, is how seeqFileMatch pipelines its ingest. */
 int seeqdevScanHostBegin(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * host_text, size_t nbytes,
                          int options, int want);
+/* Several patterns over ONE text (barcode demultiplexing, reference doc/response.tex:358-360): the text is staged once
+ * (seeqdevScanHostMulti) or is already resident (seeqdevScanRunMulti), then every pattern gets its own scan over it, back
+ * to back on the context's stream.  counts[k] (may be NULL) = pattern k's counts; with SEEQDEV_WANT_RECORDS pattern k's
+ * ordered records are kept on the host (seeqdevScanMultiRecords: context-owned, valid until the next multi scan).
+ * All patterns must live on the context's device.  Results per pattern are those of a seeqdevScanRun of its own. */
+int seeqdevScanRunMulti(seeqdev_scan_t * scan, const seeqdev_pattern_t * const * pats, int npat, const void * d_text, size_t nbytes,
+                        int options, int want, seeqdev_counts_t * counts);
+int seeqdevScanHostMulti(seeqdev_scan_t * scan, const seeqdev_pattern_t * const * pats, int npat, const char * host_text, size_t nbytes,
+                         int options, int want, seeqdev_counts_t * counts);
+int seeqdevScanMultiRecords(const seeqdev_scan_t * scan, int k, const seeqdev_hit_t ** rec, size_t * nrec);
+
 /* Time (ms) of that H2D copy for the last fetched scan (profiling on), from HIP events on the context's stream. */
 int seeqdevScanLastCopyMs(const seeqdev_scan_t * scan, float * h2d_ms);
 

@@ -61,7 +61,8 @@ EXPORTS = [
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
     "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
-    "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevScanLastStream", "seeqdevPatternDevice",
+    "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
+    "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords",
 ]
 
 
@@ -169,8 +170,12 @@ def lib():
     L.seeqdevScanLastPath.restype = C.c_int
     L.seeqdevScanLastFilter.argtypes = [C.c_void_p]
     L.seeqdevScanLastFilter.restype = C.c_int
-    L.seeqdevScanLastStream.argtypes = [C.c_void_p]
-    L.seeqdevScanLastStream.restype = C.c_int
+    L.seeqdevScanRunMulti.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    L.seeqdevScanRunMulti.restype = C.c_int
+    L.seeqdevScanHostMulti.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    L.seeqdevScanHostMulti.restype = C.c_int
+    L.seeqdevScanMultiRecords.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.seeqdevScanMultiRecords.restype = C.c_int
     L.seeqdevHostAlloc.argtypes = [C.c_size_t]
     L.seeqdevHostAlloc.restype = C.c_void_p
     L.seeqdevHostFree.argtypes = [C.c_void_p]

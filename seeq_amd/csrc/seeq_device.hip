@@ -134,7 +134,6 @@ struct ScanArgs {
    uint32_t       stream_ntiles, stream_tile_bytes;
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
-   uint32_t       lazy_clean;   /* k_stream ran without its alphabet check: k_exact1 checks each candidate line's bytes up to the candidate */
    uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: max(32, m + tau - 1) */
    Counters      *cnt;
 };
@@ -142,7 +141,6 @@ struct ScanArgs {
 static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
 static constexpr size_t FUSED_MIN_TILE = 512;    /* smallest text tile / region of the one-pass kernels */
-static constexpr int STREAM_TPW = 8;              /* k_stream, overlapped segments: tiles per wave of a short-lived workgroup */
 static constexpr int STREAM_NW_HOST = 16;         /* = STREAM_NW (seeq_stream.h): waves per k_stream workgroup */
 static constexpr size_t MAX_FUSED_GRID = 16384;   /* upper bound of the waves (= hit slices) of a persistent scan grid */
 static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate the line length */
@@ -550,7 +548,6 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_stream.h"
-#include "seeq_stream2.h"
 static_assert(STREAM_NW == STREAM_NW_HOST, "waves per k_stream workgroup");
 extern "C" {
 #include "seeq_dfa.h"
@@ -716,11 +713,6 @@ struct ScanKnobs {
    int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
-   bool no_overlap;      /* unless SEEQ_OVERLAP=1: segments strictly one after the other on one stream (the default: measured, the
-                            overlapped post-pass takes from k_stream what it gains -- both live on LDS and occupancy) */
-   bool stream_lazy;     /* SEEQ_STREAM_LAZY=1: k_stream / k_stream2 without their alphabet check under SQ_FAIL (k_exact1 then checks
-                            every candidate line's prefix; measured: costs more there than it saves here) */
-   bool stream_v1;       /* unless SEEQ_STREAM_V2=1: never use k_stream2 (lane stretches of 1 KB), always k_stream (128-byte chunks) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -737,27 +729,20 @@ struct seeqdev_scan {
    ScanKnobs   knobs;
    OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
    bool        last_filter;       /* the last run walked a partition filter automaton */
-   int         last_stream;       /* 0: the last run did not use the table-driven scan; 1: k_stream; 2: k_stream2 */
    /* workspace (device) */
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
    uint32_t *hit_start, *hit_line, *nh, *hit_col; size_t cap_hitlines;
-   /* one-pass kernels: what the scan kernel of a segment writes and its post-pass reads.  Two sets: with more than one
-      segment k_stream of segment k+1 runs (on its own stream) while the post-pass of segment k is still at work. */
+   /* one-pass kernels: what the scan kernel of a segment writes and its post-pass reads */
    struct OnePassWs {
       uint32_t *tile_cl, *tile_hits, *tile_dirty; uint64_t *tile_dmask;   /* [cap_ftiles] */
       uint4    *tmp;                 /* [cap_hitlines] hit slices, then the COUNT -> EMIT cache */
       uint32_t *wg_hits;             /* [cap_slices] */
       uint32_t *wg_part;             /* [4 * cap_slices] */
       uint32_t *wg_lastnl;           /* [cap_slices] k_stream: last newline seen by each wave */
-   } ow[2];
+   } ow;
    size_t cap_ftiles, cap_slices;
-   uint32_t *lane_ws; size_t cap_lane_tiles;   /* k_stream2: three values per lane and tile (192 u32 per 64 KB tile) */
-   bool   two_sets;                  /* ow[1] is allocated */
-   hipStream_t sp;                   /* overlap: the post-pass stream (high priority); the scan kernels stay on `stream` */
-   hipEvent_t  ev_scan[2], ev_post[2], ev_end;
-   bool        have_streams;
    uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
    unsigned long eq_pat_id; int eq_options;   /* what d_eqtab holds (pattern generation id, option bits) */
    double avg_line;               /* average bytes per line incl. newline (hint or sampled) */
@@ -775,6 +760,9 @@ struct seeqdev_scan {
    uint32_t *h_strout; size_t cap_strout;     /* {nhits, pad[3]} + records */
    /* staging for seeqdevScanHost */
    uint8_t *d_text; size_t cap_text;
+   /* seeqdevScanRunMulti: per pattern of the last multi scan its counts and (host copy) its records */
+   seeqdev_counts_t *multi_cnt; size_t *multi_first; int multi_n, cap_multi_n;
+   seeqdev_hit_t *multi_rec; size_t cap_multi_rec, multi_nrec;
    /* last run (for the transparent re-run on overflow) */
    const seeqdev_pattern *pat; const void *text; size_t nbytes; int options, want;
    bool ran;
@@ -841,9 +829,6 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_TILE_BYTES");   kn.tile_bytes = v ? atoi(v) : 0;
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
-      v = getenv("SEEQ_OVERLAP");      kn.no_overlap = !(v && atoi(v) == 1);
-      v = getenv("SEEQ_STREAM_LAZY");  kn.stream_lazy = v && atoi(v) == 1;
-      v = getenv("SEEQ_STREAM_V2");    kn.stream_v1 = !(v && atoi(v) == 1);
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       s->ncu = 256;
       int dev = 0;
@@ -865,17 +850,11 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    (void)use_device(s->device);
    if (s->have_h2d_ev) { (void)hipEventDestroy(s->ev_h2d[0]); (void)hipEventDestroy(s->ev_h2d[1]); }
    (void)hipStreamSynchronize(s->stream);
-   if (s->have_streams) {
-      for (int i = 0; i < 2; i++) { (void)hipEventDestroy(s->ev_scan[i]); (void)hipEventDestroy(s->ev_post[i]); }
-      (void)hipStreamSynchronize(s->sp); (void)hipStreamDestroy(s->sp);
-      (void)hipEventDestroy(s->ev_end);
-   }
-   for (int i = 0; i < 2; i++) {
-      void *ob[] = {s->ow[i].tile_cl, s->ow[i].tile_hits, s->ow[i].tile_dirty, s->ow[i].tile_dmask, s->ow[i].tmp, s->ow[i].wg_hits,
-                    s->ow[i].wg_part, s->ow[i].wg_lastnl};
+   {
+      void *ob[] = {s->ow.tile_cl, s->ow.tile_hits, s->ow.tile_dirty, s->ow.tile_dmask, s->ow.tmp, s->ow.wg_hits, s->ow.wg_part, s->ow.wg_lastnl};
       for (void *b : ob) if (b) (void)hipFree(b);
    }
-   void *bufs[] = {s->lane_ws, s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
+   void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
@@ -886,6 +865,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    if (s->h_strout) (void)hipHostFree(s->h_strout);
    for (size_t i = 0; i < 4 * s->nev_seg; i++) (void)hipEventDestroy(s->ev[i]);
    free(s->ev);
+   free(s->multi_cnt); free(s->multi_first); free(s->multi_rec);
    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
    free(s);
 }
@@ -903,26 +883,18 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
          s->cap_tiles = tiles;
       }
       const size_t ftiles = seg / FUSED_MIN_TILE + 2;
-      /* hit slices: one per wave of a persistent grid (<= MAX_FUSED_GRID), or per wave of k_stream's short-lived
-         workgroups (STREAM_TPW tiles of >= 4 KiB each) */
-      size_t slices = (seg / 4096 / (STREAM_NW_HOST * STREAM_TPW) + 2) * STREAM_NW_HOST;
-      if (slices < MAX_FUSED_GRID) slices = MAX_FUSED_GRID;
-      const int nsets = s->two_sets ? 2 : 1;
+      const size_t slices = MAX_FUSED_GRID;               /* hit slices: one per wave of a persistent grid */
       if (ftiles > s->cap_ftiles) {
-         for (int i = 0; i < nsets; i++) {
-            if (ws_alloc((void **)&s->ow[i].tile_cl, ftiles * sizeof(uint32_t))) return -1;
-            if (ws_alloc((void **)&s->ow[i].tile_dirty, ftiles * sizeof(uint32_t))) return -1;
-            if (ws_alloc((void **)&s->ow[i].tile_dmask, ftiles * sizeof(uint64_t))) return -1;
-            if (ws_alloc((void **)&s->ow[i].tile_hits, ftiles * sizeof(uint32_t))) return -1;
-         }
+         if (ws_alloc((void **)&s->ow.tile_cl, ftiles * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->ow.tile_dirty, ftiles * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->ow.tile_dmask, ftiles * sizeof(uint64_t))) return -1;
+         if (ws_alloc((void **)&s->ow.tile_hits, ftiles * sizeof(uint32_t))) return -1;
          s->cap_ftiles = ftiles;
       }
       if (slices > s->cap_slices) {
-         for (int i = 0; i < nsets; i++) {
-            if (ws_alloc((void **)&s->ow[i].wg_hits, slices * sizeof(uint32_t))) return -1;
-            if (ws_alloc((void **)&s->ow[i].wg_part, 4 * slices * sizeof(uint32_t))) return -1;
-            if (ws_alloc((void **)&s->ow[i].wg_lastnl, slices * sizeof(uint32_t))) return -1;
-         }
+         if (ws_alloc((void **)&s->ow.wg_hits, slices * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->ow.wg_part, 4 * slices * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->ow.wg_lastnl, slices * sizeof(uint32_t))) return -1;
          s->cap_slices = slices;
       }
    }
@@ -939,8 +911,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
    if (max_hitlines > s->cap_hitlines) {
       if (ws_alloc((void **)&s->hit_start, max_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->hit_line, max_hitlines * sizeof(uint32_t))) return -1;
-      for (int i = 0; i < (s->two_sets ? 2 : 1); i++)
-         if (ws_alloc((void **)&s->ow[i].tmp, max_hitlines * sizeof(uint4))) return -1;
+      if (ws_alloc((void **)&s->ow.tmp, max_hitlines * sizeof(uint4))) return -1;
       if (ws_alloc((void **)&s->nh, max_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->hit_col, max_hitlines * sizeof(uint32_t))) return -1;
       s->cap_hitlines = max_hitlines;
@@ -981,7 +952,6 @@ extern "C" int seeqdevScanSetLineHint(seeqdev_scan_t *s, double avg_bytes_per_li
 
 extern "C" int seeqdevScanLastPath(const seeqdev_scan_t *s) { return s ? s->last_path : 0; }
 extern "C" int seeqdevScanLastFilter(const seeqdev_scan_t *s) { return s && s->last_filter ? 1 : 0; }
-extern "C" int seeqdevScanLastStream(const seeqdev_scan_t *s) { return s ? s->last_stream : 0; }
 
 extern "C" int seeqdevScanSetProfiling(seeqdev_scan_t *s, int on)
 {
@@ -1109,36 +1079,6 @@ __global__ __launch_bounds__(WG) void k_scan_tiles(uint32_t *tile_cnt, uint32_t 
    if (threadIdx.x == 0) *total_out = running;
 }
 
-/* Streams, events and the second workspace set of the overlapped multi-segment scan (created on first use). */
-static int ensure_overlap(seeqdev_scan *s)
-{
-   if (!s->have_streams) {
-      int lo = 0, hi = 0;                                    /* numerically lower = higher priority */
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      HIP_TRY(hipStreamCreateWithPriority(&s->sp, hipStreamNonBlocking, hi), EIO);
-      HIP_TRY(hipEventCreateWithFlags(&s->ev_end, hipEventDisableTiming), EIO);
-      for (int i = 0; i < 2; i++) {
-         HIP_TRY(hipEventCreateWithFlags(&s->ev_scan[i], hipEventDisableTiming), EIO);
-         HIP_TRY(hipEventCreateWithFlags(&s->ev_post[i], hipEventDisableTiming), EIO);
-      }
-      s->have_streams = true;
-   }
-   if (!s->two_sets) {
-      HIP_TRY(hipStreamSynchronize(s->stream), EIO);
-      seeqdev_scan::OnePassWs &o = s->ow[1];
-      if (ws_alloc((void **)&o.tile_cl, s->cap_ftiles * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&o.tile_dirty, s->cap_ftiles * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&o.tile_dmask, s->cap_ftiles * sizeof(uint64_t))) return -1;
-      if (ws_alloc((void **)&o.tile_hits, s->cap_ftiles * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&o.wg_hits, s->cap_slices * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&o.wg_part, 4 * s->cap_slices * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&o.wg_lastnl, s->cap_slices * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&o.tmp, s->cap_hitlines * sizeof(uint4))) return -1;
-      s->two_sets = true;
-   }
-   return 0;
-}
-
 /* Workgroups of `fn` (threads per workgroup, dynamic LDS) that fit one CU; asked once per kernel and LDS size.
  * Also raises the kernel's dynamic-LDS limit.  -1 (errno set) when HIP refuses. */
 static int occupancy_of(seeqdev_scan *s, const void *fn, int threads, size_t lds)
@@ -1230,7 +1170,7 @@ static int run_segments(seeqdev_scan *s)
    unsigned nslices = 1;                      /* hit slices: one per wave */
    const int stream_wu = use_stream && pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
-   bool stream_ilp2 = false, stream_ll = false, stream_chk = true, stream_sub = false, use_stream2 = false;
+   bool stream_ilp2 = false, stream_ll = false, stream_sub = false;
    size_t dfa_lds = 0;
    if (use_fused) {
       if (use_stream) {
@@ -1238,18 +1178,10 @@ static int run_segments(seeqdev_scan *s)
          tile_bytes = 64u * (uint32_t)stream_ch;
          stream_ilp2 = stream_ch == 128 && !kn.stream_ilp1;
          stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
-         /* the alphabet check stays out of the default variants under SQ_FAIL (k_exact1 looks at the candidate lines) */
-         stream_chk = stream_ll || (options & MASK_NONDNA) != 0 || !stream_ilp2 || stream_ch != 128 || !kn.stream_lazy;
          stream_sub = can_sub;
-         /* k_stream2 (seeq_stream2.h): every lane walks a 1 KB stretch -- one warm-up per kilobyte instead of per 64 bytes.
-            Read-length lines, one segment after the other; FASTA, long lines and the overlapped post-pass stay on k_stream. */
-         use_stream2 = stream_ilp2 && !fasta && !stream_ll && !kn.stream_v1 && kn.no_overlap && s->seg_bytes % STREAM2_TB == 0;
-         if (use_stream2) tile_bytes = STREAM2_TB;
 #define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
-         stream_fn = stream_sub ? (stream_ll ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true, true, true) : SEEQ_STREAM_FN(128, 8, true, false, true, true, true))
-                                             : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, true, true) : SEEQ_STREAM_FN(128, 8, true, false, false, true, true)))
-                   : !stream_chk ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, false, false) : SEEQ_STREAM_FN(128, 8, true, true, false, false))
-                                          : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, false) : SEEQ_STREAM_FN(128, 8, true, false, false, false)))
+         stream_fn = stream_sub ? (stream_ll ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true, true) : SEEQ_STREAM_FN(128, 8, true, false, true, true))
+                                             : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, true) : SEEQ_STREAM_FN(128, 8, true, false, false, true)))
                    : stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
                                         : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true) : SEEQ_STREAM_FN(128, 8, true, false, true)))
                    : fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, false) : SEEQ_STREAM_FN(128, 8, true, true, false))
@@ -1257,20 +1189,9 @@ static int run_segments(seeqdev_scan *s)
                                                      : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, false, false, false) : SEEQ_STREAM_FN(128, 8, false, false, false)))
                                       : (stream_wu == 6 ? SEEQ_STREAM_FN(64, 6, false, false, false) : SEEQ_STREAM_FN(64, 8, false, false, false));
 #undef SEEQ_STREAM_FN
-         const void *tail_fn = nullptr;
-         if (use_stream2) {
-#define SEEQ_S2_FN(T) (stream_sub ? (stream_wu == 6 ? (const void *)k_stream2<6, true, true, T> : (const void *)k_stream2<8, true, true, T>) \
-                     : stream_chk ? (stream_wu == 6 ? (const void *)k_stream2<6, true, false, T> : (const void *)k_stream2<8, true, false, T>) \
-                                  : (stream_wu == 6 ? (const void *)k_stream2<6, false, false, T> : (const void *)k_stream2<8, false, false, T>))
-            stream_fn = SEEQ_S2_FN(false);
-            tail_fn = SEEQ_S2_FN(true);
-#undef SEEQ_S2_FN
-            nw = STREAM2_NW;
-         }
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          int per_cu = occupancy_of(s, stream_fn, 64 * nw, dfa_lds);
          if (per_cu < 0) return -1;
-         if (tail_fn && occupancy_of(s, tail_fn, 64 * nw, dfa_lds) < 0) return -1;       /* (raises its dynamic-LDS limit) */
          if (kn.wgs_per_cu >= 1 && kn.wgs_per_cu < per_cu) per_cu = kn.wgs_per_cu;       /* experiments: workgroups per CU */
          fused_grid = (unsigned)(ncu * per_cu);
          if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
@@ -1318,7 +1239,6 @@ static int run_segments(seeqdev_scan *s)
    const bool use_direct = use_fused && !use_stream;
    s->last_path = use_fused ? (use_stream ? 5 : 3) : 1;
    s->last_filter = filter;
-   s->last_stream = use_stream ? (use_stream2 ? 2 : 1) : 0;
    const bool superset = use_stream;                     /* the scan kernel's hit lines are candidates: nh[] decides */
    if (superset) need_nh = true;
    const bool generic_exact = !superset && kn.exact_generic;      /* A/B knob */
@@ -1335,21 +1255,11 @@ static int run_segments(seeqdev_scan *s)
       s->nev_seg = nseg;
    }
    if (s->prof) s->prof_segs = nseg;
-   /* Overlap (k_stream, more than one segment): the scan kernels run back to back on the context's stream and write
-      into alternating workspace sets; every segment's post-pass (ordering, exact pass, records) runs on a second,
-      high-priority stream as soon as its scan is done -- i.e. while the NEXT segment's scan is running, whose
-      workgroups are short-lived (STREAM_TPW tiles per wave) so that the post-pass kernels find room on the CUs. */
-   const bool overlap = use_stream && nseg > 1 && !kn.no_overlap;
-   if (overlap && ensure_overlap(s)) return -1;
-   const uint32_t tpw = overlap ? (uint32_t)STREAM_TPW : 0u;
    for (size_t sg = 0; sg < nseg; sg++) {
       hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
       uint32_t stream_ntiles = 0;
-      const int wsi = overlap ? (int)(sg & 1) : 0;
-      seeqdev_scan::OnePassWs &ow = s->ow[wsi];
-      hipStream_t st_scan = s->stream;                             /* the scan kernel of this segment */
-      hipStream_t st = overlap ? s->sp : s->stream;                /* everything behind it */
-      if (overlap && sg >= 2) HIP_TRY(hipStreamWaitEvent(st_scan, s->ev_post[wsi], 0), EIO);   /* the post-pass of segment sg - 2 is done with this set */
+      seeqdev_scan::OnePassWs &ow = s->ow;
+      hipStream_t st = s->stream;
       ScanArgs a;
       memset(&a, 0, sizeof a);
       a.text = (const uint8_t *)s->text;
@@ -1366,7 +1276,6 @@ static int run_segments(seeqdev_scan *s)
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
       a.use_nh = need_nh ? (use_stream ? 3u : 1u) : 0u;
       a.filter = filter ? 1u : 0u;
-      a.lazy_clean = use_stream && !stream_chk ? 1u : 0u;
       a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1 > 32 ? pat->wlen + pat->tau - 1 : 32);
       a.cnt = c;
 
@@ -1384,7 +1293,6 @@ static int run_segments(seeqdev_scan *s)
          f.wg_hits = ow.wg_hits; f.wg_part = ow.wg_part; f.wg_lastnl = stream_ll ? ow.wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
          f.tile_dirty = f.wg_lastnl ? ow.tile_dirty : nullptr;
          f.tile_dmask = f.wg_lastnl ? ow.tile_dmask : nullptr;
-         f.tiles_per_wave = tpw;
          f.cnt = c;
          uint32_t pos_bias = 0;
          if (use_stream) {
@@ -1395,48 +1303,14 @@ static int run_segments(seeqdev_scan *s)
             pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room) & ~127u;     /* chunk boundaries stay multiples of the chunk */
             f.pos_bias = pos_bias;
          }
-         if (ev) { HIP_TRY(hipEventRecord(ev[0], st_scan), EIO); HIP_TRY(hipEventRecord(ev[1], st_scan), EIO); }
+         if (ev) { HIP_TRY(hipEventRecord(ev[0], st), EIO); HIP_TRY(hipEventRecord(ev[1], st), EIO); }
          unsigned fgrid = fused_grid;                     /* persistent: workgroups without a tile just publish zeros */
-         unsigned nsl = nslices;
-         if (tpw) {                                       /* short-lived workgroups: 16 * tpw tiles each */
-            fgrid = (unsigned)((f.ntiles + STREAM_NW * tpw - 1) / (STREAM_NW * tpw));
-            if (fgrid == 0) fgrid = 1;
-            nsl = fgrid * STREAM_NW;
-            if (nsl > s->cap_slices) { seeqerr = 0; errno = ENOMEM; snprintf(g_last_error, sizeof g_last_error, "slice table too small"); return -1; }
-         }
+         const unsigned nsl = nslices;
          f.slice_cap = f.cap_tmp / nsl;
-         if (use_stream2) {
-            if ((size_t)f.ntiles > s->cap_lane_tiles) {
-               HIP_TRY(hipStreamSynchronize(s->stream), EIO);
-               const size_t tiles = s->seg_bytes / STREAM2_TB + 1 > (size_t)f.ntiles ? s->seg_bytes / STREAM2_TB + 1 : (size_t)f.ntiles;
-               if (ws_alloc((void **)&s->lane_ws, tiles * STREAM2_WS * sizeof(uint32_t))) return -1;
-               s->cap_lane_tiles = tiles;
-            }
-            /* whole tiles: the hot kernel.  The segment's last tile when it is cut short or ends the buffer: one wave of
-               the TAIL variant, with a slice of its own behind the hot kernel's */
-            const bool tail = a.seg_len % STREAM2_TB != 0 || a.seg_base + a.seg_len >= nbytes;
-            const uint32_t nfull = tail ? f.ntiles - 1 : f.ntiles;
-            if (tail) nsl += 1;
-            f.slice_cap = f.cap_tmp / nsl;
-#define SEEQ_STREAM2_LAUNCH(G, F, E, S0, ...) hipLaunchKernelGGL((k_stream2<__VA_ARGS__>), dim3(G), dim3(64 * STREAM2_NW), dfa_lds, st_scan, f, s->lane_ws, (uint32_t)(F), (uint32_t)(E), (uint32_t)(S0))
-#define SEEQ_STREAM2_BOTH(...) do { if (nfull) SEEQ_STREAM2_LAUNCH(fgrid, 0, nfull, 0, __VA_ARGS__, false); \
-                                    if (tail) SEEQ_STREAM2_LAUNCH(1, nfull, f.ntiles, nsl - 1, __VA_ARGS__, true); } while (0)
-            if (!nfull) {                                 /* no hot launch: its slices hold nothing */
-               HIP_TRY(hipMemsetAsync(ow.wg_hits, 0, (size_t)nsl * sizeof(uint32_t), st_scan), EIO);
-               HIP_TRY(hipMemsetAsync(ow.wg_part, 0, (size_t)nsl * 4 * sizeof(uint32_t), st_scan), EIO);
-            }
-            if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM2_BOTH(6, true, true); else SEEQ_STREAM2_BOTH(8, true, true); }
-            else if (stream_chk) { if (stream_wu == 6) SEEQ_STREAM2_BOTH(6, true, false); else SEEQ_STREAM2_BOTH(8, true, false); }
-            else { if (stream_wu == 6) SEEQ_STREAM2_BOTH(6, false, false); else SEEQ_STREAM2_BOTH(8, false, false); }
-#undef SEEQ_STREAM2_BOTH
-#undef SEEQ_STREAM2_LAUNCH
-         }
-         else if (use_stream) {
-#define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st_scan, f)
-            if (stream_sub && stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true, true, true); }
-            else if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, true, true); }
-            else if (!stream_chk && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false, false); }
-            else if (!stream_chk) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, false); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, false); }
+         if (use_stream) {
+#define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st, f)
+            if (stream_sub && stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true, true); }
+            else if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, true); }
             else if (stream_ll && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true, true); }
             else if (stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true); }
             else if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false); }
@@ -1445,19 +1319,14 @@ static int run_segments(seeqdev_scan *s)
             else { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(64, 6, false, false, false); else SEEQ_STREAM_LAUNCH(64, 8, false, false, false); }
 #undef SEEQ_STREAM_LAUNCH
          }
-         else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st_scan, f);
-         else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st_scan, f);
-         if (ev) HIP_TRY(hipEventRecord(ev[2], st_scan), EIO);
-         if (overlap) {
-            HIP_TRY(hipEventRecord(s->ev_scan[wsi], st_scan), EIO);
-            HIP_TRY(hipStreamWaitEvent(st, s->ev_scan[wsi], 0), EIO);
-         }
+         else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st, f);
+         else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st, f);
+         if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
          hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, st, f, (uint32_t)nsl);
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
             launch_scanset(s, st, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
             const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
-            if (use_stream2) hipLaunchKernelGGL(k_stream2_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, (const uint32_t *)s->lane_ws, s->hit_start, s->hit_line, s->nh, s->hit_col);
-            else if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
+            if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
             else hipLaunchKernelGGL(k_fused_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line);
          }
          a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
@@ -1534,12 +1403,7 @@ static int run_segments(seeqdev_scan *s)
       }
       hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));
       if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
-      if (overlap) HIP_TRY(hipEventRecord(s->ev_post[wsi], st), EIO);
       HIP_TRY(hipGetLastError(), EIO);
-   }
-   if (overlap) {                                         /* the caller's stream continues behind the last post-pass */
-      HIP_TRY(hipEventRecord(s->ev_end, s->sp), EIO);
-      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_end, 0), EIO);
    }
    HIP_TRY(hipMemcpyAsync(s->h_cnt, c, sizeof(Counters), hipMemcpyDeviceToHost, s->stream), EIO);
    return 0;
@@ -1733,6 +1597,76 @@ extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, 
 {
    if (seeqdevScanHostBegin(s, pat, host_text, nbytes, options, want)) return -1;
    return seeqdevScanFetch(s, counts);
+}
+
+/* ========================================================================== */
+/* Several patterns, one text (barcode demultiplexing: reference doc/response.tex:358-360)  */
+/* ========================================================================== */
+/* The text is staged / resident ONCE; every pattern then gets its own scan over it, back to back on the context's
+ * stream (the scan kernels are bound by their own per-character work, not by reading the text -- DESIGN.md -- so a
+ * shared pass over the bytes would not be faster than this; what is shared is what costs: the ingest, the H2D copy
+ * over the link, the workspace, the line-length sample).  Per pattern: counts, and for SEEQDEV_WANT_RECORDS its
+ * ordered records, kept on the host until the next multi scan. */
+extern "C" int seeqdevScanRunMulti(seeqdev_scan_t *s, const seeqdev_pattern_t *const *pats, int npat, const void *d_text, size_t nbytes,
+                                   int options, int want, seeqdev_counts_t *counts)
+{
+   seeqerr = 0;
+   if (!s || !pats || npat < 1 || (!d_text && nbytes)) { errno = EINVAL; return -1; }
+   if (npat > s->cap_multi_n) {
+      seeqdev_counts_t *c = (seeqdev_counts_t *)realloc(s->multi_cnt, (size_t)npat * sizeof *c);
+      if (c) s->multi_cnt = c;
+      size_t *f = (size_t *)realloc(s->multi_first, ((size_t)npat + 1) * sizeof *f);
+      if (f) s->multi_first = f;
+      if (!c || !f) { errno = ENOMEM; return -1; }
+      s->cap_multi_n = npat;
+   }
+   s->multi_n = 0;
+   s->multi_nrec = 0;
+   for (int k = 0; k < npat; k++) {
+      if (seeqdevScanRun(s, pats[k], d_text, nbytes, options, want)) return -1;
+      if (seeqdevScanFetch(s, &s->multi_cnt[k])) return -1;
+      s->multi_first[k] = s->multi_nrec;
+      const size_t n = want == SEEQDEV_WANT_RECORDS ? (size_t)s->multi_cnt[k].nrecords : 0;
+      if (n) {
+         if (s->multi_nrec + n > s->cap_multi_rec) {
+            const size_t cap = (s->multi_nrec + n) + ((s->multi_nrec + n) >> 1) + 1024;
+            seeqdev_hit_t *g = (seeqdev_hit_t *)realloc(s->multi_rec, cap * sizeof *g);
+            if (!g) { errno = ENOMEM; return -1; }
+            s->multi_rec = g;
+            s->cap_multi_rec = cap;
+         }
+         if (seeqdevScanCopyRecords(s, s->multi_rec + s->multi_nrec, 0, n)) return -1;
+         s->multi_nrec += n;
+      }
+      if (counts) counts[k] = s->multi_cnt[k];
+   }
+   s->multi_first[npat] = s->multi_nrec;
+   s->multi_n = npat;
+   return 0;
+}
+
+extern "C" int seeqdevScanHostMulti(seeqdev_scan_t *s, const seeqdev_pattern_t *const *pats, int npat, const char *host_text, size_t nbytes,
+                                    int options, int want, seeqdev_counts_t *counts)
+{
+   seeqerr = 0;
+   if (!s || !pats || npat < 1 || (!host_text && nbytes)) { errno = EINVAL; return -1; }
+   if (use_device(s->device)) return -1;
+   if (nbytes > s->cap_text) {
+      const size_t cap = nbytes + (nbytes >> 2) + 4096;
+      if (ws_alloc((void **)&s->d_text, cap)) return -1;
+      s->cap_text = cap;
+   }
+   if (nbytes) HIP_TRY(hipMemcpyAsync(s->d_text, host_text, nbytes, hipMemcpyHostToDevice, s->stream), EIO);   /* once, for all patterns */
+   s->avg_text = NULL;                                     /* new contents behind the same pointer: sample again */
+   return seeqdevScanRunMulti(s, pats, npat, s->d_text, nbytes, options, want, counts);
+}
+
+extern "C" int seeqdevScanMultiRecords(const seeqdev_scan_t *s, int k, const seeqdev_hit_t **rec, size_t *nrec)
+{
+   if (!s || !rec || !nrec || k < 0 || k >= s->multi_n) { errno = EINVAL; return -1; }
+   *rec = s->multi_rec + s->multi_first[k];
+   *nrec = s->multi_first[k + 1] - s->multi_first[k];
+   return 0;
 }
 
 extern "C" int seeqdevScanLastCopyMs(const seeqdev_scan_t *s, float *h2d_ms)

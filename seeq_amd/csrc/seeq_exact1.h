@@ -73,33 +73,6 @@ __device__ __forceinline__ bool exact1_bytes_clean(const uint8_t *text, uint64_t
    return bad == 0;
 }
 
-/* The same question for the first n bytes of a line (the lazy check of a read-length candidate line): the 16-byte
- * pieces are fetched eight at a time with nothing depending on the previous one, the piece that straddles the end is
- * masked in registers (bytes at or beyond n count as 'A') -- no byte loop, no early exit inside a group. */
-__device__ __forceinline__ bool exact1_prefix_clean(const uint8_t *text, uint64_t off, uint32_t n, uint64_t nbytes)
-{
-   uint32_t bad = 0;
-   for (uint32_t p = 0; p < n && !bad; p += 128) {
-      fused_v4u v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++)
-         if (p + 16 * q < n) v[q] = direct_load16(text, off + p + 16 * q, nbytes);
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-         const uint32_t o = p + 16 * q;
-         if (o >= n) break;
-         uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-         for (int j = 0; j < 4; j++) {
-            const uint32_t lo = o + 4 * j;                /* line offset of the word's first byte */
-            const uint32_t keep = lo + 4 <= n ? 0xFFFFFFFFu : (lo >= n ? 0u : 0xFFFFFFFFu >> (8 * (lo + 4 - n)));
-            bad |= fused_bad4((w[j] & keep) | (0x41414141u & ~keep));
-         }
-      }
-   }
-   return bad == 0;
-}
-
 /* text[x, y) inside ONE tile (base tb): whole 128-byte chunks by the tile's chunk mask, the partial chunks by bytes */
 __device__ __forceinline__ bool exact1_clean_in_tile(const ScanArgs &a, uint64_t tb, uint64_t dmask, uint64_t x, uint64_t y)
 {
@@ -173,13 +146,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
    const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1;
    const bool count_any = a.want != SEEQDEV_WANT_COUNTMATCH && !(a.want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const bool by_nh = a.use_nh != 0;                       /* record slots come from the scanned per-line counts */
-   /* lazy: k_stream ran without its alphabet check (SQ_FAIL, read-length lines).  Then a candidate line is looked at
-      here: the first candidate of a line sits at column `col`; if a byte outside the alphabet comes before it the line
-      ended there (libseeq.c:267-270) and holds NO hit at all -- all bytes before that one were walked exactly, so a hit
-      among them would have been the first candidate -- and if none does, the candidate is exactly what the line-long
-      scan finds (complete automaton), resp. a candidate worth verifying (filter). */
-   const bool lazy = a.use_nh == 3 && a.lazy_clean && hit_col != nullptr;
-   const bool trusted = a.use_nh == 3 && !a.filter && (lazy || !c->dirty);   /* k_stream, complete automaton, clean text (lazy: per line, below): exact verdicts */
+   const bool trusted = a.use_nh == 3 && !a.filter && !c->dirty;   /* k_stream, complete automaton, clean text: exact verdicts */
    const bool caching = MODE == SQ_MODE_COUNT && cache != nullptr && a.want == SEEQDEV_WANT_RECORDS;
    const bool count_best = caching && match_opt == SQ_BEST;
    const bool cache_ok = MODE == SQ_MODE_EMIT && cache != nullptr && by_nh && !(trusted && count_any);
@@ -193,17 +160,9 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       const uint32_t hs = done ? 0u : a.hit_start[k];
       if (hs == 0xFFFFFFFFu) done = true;                  /* k_stream: repeat of the previous entry's line */
       const uint64_t off = done ? a.seg_base : a.seg_base + hs;
-      /* lazy: a byte outside k_stream's table alphabet before the first candidate.  It may have ended the line there
-         (SQ_FAIL) or be a base the table folds exactly ('U'): this line is scanned whole, from column 0, by the rules
-         below -- EQ[] knows every byte's class -- and nothing k_stream said about it is used. */
-      const bool unclean = lazy && !done && !exact1_prefix_clean(a.text, off, hit_col[k] + 1, a.nbytes);
-      bool preset = false;                                 /* COUNT: the candidate is the verdict (one hit line) */
       if (MODE == SQ_MODE_COUNT && trusted && count_any) {
-         if (!__any(unclean)) {                            /* (wave-uniform branch) */
-            if (k < nhl) a.nh[k] = done ? 0u : 1u;
-            continue;
-         }
-         if (!unclean && !done) { preset = true; done = true; }
+         if (k < nhl) a.nh[k] = done ? 0u : 1u;            /* (wave-uniform branch) */
+         continue;
       }
       if (a.use_nh == 3 && (a.options & SEEQDEV_FASTA) && !done && a.text[off] == '>') done = true;   /* k_stream candidate inside a FASTA header */
       fused_state_t<W> st;
@@ -222,7 +181,7 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
          /* nothing ends the line before the first candidate (clean text), so the scan may start just before it: no
             occurrence ends before `col` (a filter: every occurrence contains a part that ends at or after the first
             candidate), and a column started skip_back >= m + tau - 1 bytes earlier has the line's own scores from there */
-         if (col > a.skip_back && !unclean && (trusted || exact1_clean(a, off, off + col - a.skip_back))) pos = col - a.skip_back;
+         if (col > a.skip_back && (trusted || exact1_clean(a, off, off + col - a.skip_back))) pos = col - a.skip_back;
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
@@ -356,7 +315,6 @@ __global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2,
       if (k < nhl) {
          if (MODE == SQ_MODE_COUNT) {
             if (count_best) { nhits = best_d < tau1 ? 1u : 0u; c0p = best_end; c0d = best_d; }
-            if (preset) nhits = 1u;
             a.nh[k] = nhits;
             if (caching) cache[k] = make_uint4(c0p, c0d, c1p, c1d);
          } else if (from_cache) {

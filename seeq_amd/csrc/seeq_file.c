@@ -113,7 +113,7 @@ static size_t chunk_bytes(void)
       long long v = atoll(env);
       if (v >= 64) return (size_t)v;
    }
-   return (size_t)64 << 20;
+   return (size_t)32 << 20;        /* page-locking a chunk costs ~0.18 ms per MiB, a chunk's scan ~0.2 ms of fixed work */
 }
 
 static fstate_t *state_of(seeqfile_t *f, int create)
@@ -193,8 +193,8 @@ static void state_drop(seeqfile_t *f)
 }
 
 /* fread() for big reads of a regular file: the range is split over a few threads that pread() it straight into the
- * (page-locked) chunk buffer -- one thread copies out of the page cache at ~5-10 GB/s, four come close to the link
- * speed the GPU side can take. */
+ * (page-locked) chunk buffer -- one thread copies out of the page cache at ~5-10 GB/s, four reach ~25 GB/s (measured,
+ * profiles/r02_cli_wallclock.txt), eight come close to the link speed the GPU side can take. */
 typedef struct { int fd; char *dst; size_t n; off_t off; size_t got; } rd_job_t;
 
 static void *rd_worker(void *p)
@@ -213,7 +213,13 @@ static void *rd_worker(void *p)
 
 static size_t chunk_read(FILE *fdi, char *dst, size_t want)
 {
-   enum { NT = 4 };
+   enum { NTMAX = 16 };
+   static int nt_env = 0;                                  /* SEEQ_READ_THREADS (1..16), default 8 */
+   if (!nt_env) {
+      const char *e = getenv("SEEQ_READ_THREADS");
+      nt_env = e && atoi(e) >= 1 && atoi(e) <= NTMAX ? atoi(e) : 8;
+   }
+   const int NT = nt_env;
    const size_t big = (size_t)8 << 20;
    struct stat st;
    const int fd = fileno(fdi);
@@ -222,9 +228,9 @@ static size_t chunk_read(FILE *fdi, char *dst, size_t want)
        st.st_size > off && (size_t)(st.st_size - off) >= big) {
       const size_t n = (size_t)(st.st_size - off) < want ? (size_t)(st.st_size - off) : want;
       const size_t per = ((n + NT - 1) / NT + 4095) & ~(size_t)4095;
-      rd_job_t job[NT];
-      pthread_t th[NT];
-      int started[NT] = {0};
+      rd_job_t job[NTMAX];
+      pthread_t th[NTMAX];
+      int started[NTMAX] = {0};
       for (int i = 0; i < NT; i++) {
          const size_t lo = (size_t)i * per < n ? (size_t)i * per : n;
          const size_t hi = lo + per < n ? lo + per : n;
@@ -831,7 +837,9 @@ static void print_hit(const struct seeqarg_t *a, const seeqfile_t *f, const seeq
 
 int seeq(char *expression, char *input, struct seeqarg_t args)
 {
+   const double t_new0 = now_s();
    seeq_t *sq = seeqNew(expression, args.dist, args.memory);
+   const double t_new = now_s() - t_new0;     /* first HIP call of the process: runtime + device initialisation */
    if (!sq) {
       fprintf(stderr, "error in 'seeqNew()'; %s\n:", seeqPrintError());   /* sic, seeq.c:79 */
       return EXIT_FAILURE;
@@ -881,7 +889,7 @@ int seeq(char *expression, char *input, struct seeqarg_t args)
    if (args.verbose) {
       clock_gettime(CLOCK_MONOTONIC, &t1);
       const double wall = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-      fprintf(stderr, "engine: %s (HIP, no DFA cache)\n", SEEQ_AMD_VERSION);
+      fprintf(stderr, "engine: %s (HIP, no DFA cache); seeqNew incl. HIP start-up %.3fs\n", SEEQ_AMD_VERSION, t_new);
       const fstate_t *s = state_of(f, 0);
       if (s && s->chunks) {
          const double gb = (double)s->bytes / 1e9;

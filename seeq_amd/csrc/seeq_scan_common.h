@@ -40,9 +40,6 @@ struct FusedArgs {
    uint32_t      *wg_hits;     /* per slice (= per wave of k_stream / k_direct): entries stored */
    uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31, flags (k_stream: 1 = met a byte outside
                                   its alphabet, 2 = wants the long-line variant)}                     */
-   uint32_t       tiles_per_wave; /* k_stream: 0 = persistent grid, wave w takes tiles w, w + waves, ...; T > 0 = workgroup b
-                                  takes the 16 T tiles from 16 T b on and exits (short-lived workgroups let the post-pass of
-                                  the previous segment, queued on another stream, get onto the CUs)                      */
    uint32_t      *tile_dirty;  /* k_stream, long-line mode: per tile, 1 when it holds a byte outside the alphabet (then its exclusive prefix); else NULL */
    uint64_t      *tile_dmask;  /* k_stream, long-line mode: per tile, one bit per 128-byte chunk (lane) that holds a non-alphabet byte */
    uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */

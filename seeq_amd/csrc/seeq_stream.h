@@ -153,15 +153,10 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
  * unchanged; candidates inside a header are discarded by the exact pass, which looks at the first byte of the line. */
 /* LL: long-line mode -- per-tile "dirty" flags and the segment's last newline for the window walk of the exact pass
  * (kept out of the read-length kernel: its tile loop has no register to spare). */
-/* CHK: the alphabet check is compiled in (a flag per wave: "met a byte outside {ACGTN acgtn \n}").  Needed by the
- * long-line bookkeeping and under SQ_CONVERT / SQ_IGNORE (there such a byte changes what a LATER hit looks like, so the
- * scan has to be redone on the per-line kernels).  Under SQ_FAIL on read-length lines it is left out -- it costs a
- * quarter of the kernel's VALU work -- and the exact pass checks, per candidate line, the bytes from the start of the
- * line to the candidate instead (k_exact1, `lazy_clean`): the line has a hit iff they are all in the alphabet. */
 /* SUB (SQ_CONVERT): tiles that hold such bytes are walked over a corrected copy (stream_sub4) held in registers: the
  * verdicts are exact on any text and nothing needs re-running.  (SQ_IGNORE skips such bytes, which stretches the text a
  * match spans beyond what a chunk's warm-up covers: there the scan is still redone on the per-line kernels.) */
-template <int CH, int WU, bool ILP2, bool FA, bool LL, bool CHK = true, bool SUB = false>
+template <int CH, int WU, bool ILP2, bool FA, bool LL, bool SUB = false>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
@@ -188,13 +183,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
    const uint64_t last = a.nbytes - 1;
 
-   /* persistent grid: wave w of the grid takes tiles w, w + waves, ...; short-lived workgroups (tiles_per_wave = T):
-      workgroup b takes the 16 T consecutive tiles from 16 T b on, wave w every 16th of them */
-   const uint32_t tpw = a.tiles_per_wave;
-   const uint32_t tstep = tpw ? (uint32_t)NW : nwaves;
-   uint32_t tend = a.ntiles;
-   if (tpw) { const uint64_t e = ((uint64_t)blockIdx.x + 1) * NW * tpw; if (e < tend) tend = (uint32_t)e; }
-   for (uint32_t tile = tpw ? blockIdx.x * (NW * tpw) + wave : gwave; tile < tend; tile += tstep) {
+   /* persistent grid: wave w of the grid takes tiles w, w + waves, ... */
+   for (uint32_t tile = gwave; tile < a.ntiles; tile += nwaves) {
       const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;
       /* opaque per tile: keeps the compiler from hoisting the per-lane 64-bit addresses of the guarded loads
          out of the tile loop (that costs ~20 VGPRs and spills) */
@@ -219,7 +209,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
       }
       /* ---- alphabet check, done with before the walk starts (nothing of it stays live) ---- */
-      if (CHK || LL) {
+      {
          uint32_t bad = 0;
 #pragma unroll
          for (int q = 0; q < NQ; q++) bad |= fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);

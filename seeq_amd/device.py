@@ -102,10 +102,6 @@ class Scanner:
     def last_kernel(self):
         return {1: "k_forward", 3: "k_direct", 5: "k_stream"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
-    def last_stream_kernel(self):
-        """Which table-driven scan kernel the last run used: "k_stream" (128-byte chunks), "k_stream2" (1 KB stretches) or None."""
-        return {1: "k_stream", 2: "k_stream2"}.get(self._lib.seeqdevScanLastStream(self._h))
-
     def last_filter(self):
         """True when the last k_stream run walked a partition filter automaton (candidates verified by the exact pass)."""
         return bool(self._lib.seeqdevScanLastFilter(self._h))
@@ -159,6 +155,59 @@ class Scanner:
         if want == WANT_RECORDS:
             res["records"] = self.records(cnt.nrecords)
         return res
+
+
+    # ---- several patterns, one text (include/seeq_amd.h: seeqdevScanRunMulti / seeqdevScanHostMulti) ----
+    def _multi(self, patterns, call, want):
+        n = len(patterns)
+        arr = (C.c_void_p * n)(*[C.cast(p.handle, C.c_void_p) for p in patterns])
+        cnts = (_capi.seeqdev_counts_t * n)()
+        _check(call(arr, n, C.cast(cnts, C.c_void_p)))
+        out = []
+        for k in range(n):
+            c = cnts[k]
+            res = dict(nlines=c.nlines, nmatchlines=c.nmatchlines, nhits=c.nhits, nrecords=c.nrecords, nheaders=c.nheaders)
+            if want == WANT_RECORDS:
+                ptr, m = C.c_void_p(), C.c_size_t()
+                _check(self._lib.seeqdevScanMultiRecords(self._h, k, C.byref(ptr), C.byref(m)))
+                rec = np.zeros((m.value, 4), dtype=np.uint32)
+                if m.value:
+                    C.memmove(rec.ctypes.data, ptr.value, m.value * 16)
+                res["records"] = rec
+            out.append(res)
+        return out
+
+    def scan_host_multi(self, patterns, data, options=0, want=WANT_COUNTLINES):
+        """data: bytes, staged ONCE; every pattern gets its own scan over it.  -> one result dict per pattern."""
+        return self._multi(patterns, lambda arr, n, cnts: self._lib.seeqdevScanHostMulti(self._h, arr, n, data, len(data), options, want, cnts), want)
+
+    def scan_tensor_multi(self, patterns, t, options=0, want=WANT_COUNTLINES):
+        """t: torch uint8 CUDA tensor (contiguous), resident.  -> one result dict per pattern."""
+        return self._multi(patterns, lambda arr, n, cnts: self._lib.seeqdevScanRunMulti(self._h, arr, n, C.c_void_p(t.data_ptr()), t.numel(),
+                                                                                     options, want, cnts), want)
+
+
+def assign_best(results, nlines):
+    """Demultiplexing rule on top of a multi-pattern SQ_BEST scan: per line the pattern with the smallest distance
+    (ties: the first pattern in the list).  results: what scan_*_multi(..., SQ_BEST, WANT_RECORDS) returned.
+    -> (which [nlines] int32, -1 = no pattern matched; dist [nlines] int32; start, end [nlines] int64)."""
+    which = np.full(nlines, -1, dtype=np.int32)
+    dist = np.full(nlines, np.iinfo(np.int32).max, dtype=np.int32)
+    start = np.zeros(nlines, dtype=np.int64)
+    end = np.zeros(nlines, dtype=np.int64)
+    for k, r in enumerate(results):
+        rec = r["records"]
+        if not len(rec):
+            continue
+        ln = rec[:, 0].astype(np.int64) - 1
+        better = rec[:, 3].astype(np.int32) < dist[ln]           # strict: an earlier pattern keeps a tie
+        ln = ln[better]
+        which[ln] = k
+        dist[ln] = rec[better, 3]
+        start[ln] = rec[better, 1]
+        end[ln] = rec[better, 2]
+    dist[which < 0] = -1
+    return which, dist, start, end
 
 
 def synth_reads(d_ptr, first, n, length, pattern_plain, tau, seed=0x5EE92025, stream=None):

@@ -117,9 +117,7 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
     per lane), or 'auto' (the library's own choice); the env knobs are read when the scan context is created."""
     from seeq_amd import device as dev
     if path != "auto":
-        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream", "fused-stream2": "stream"}.get(path, "direct")
-    if path == "fused-stream2":
-        os.environ["SEEQ_STREAM_V2"] = "1"
+        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream"}.get(path, "direct")
     if tile and path == "fused-stream":
         os.environ["SEEQ_STREAM_CH"] = str(tile)
     elif tile:
@@ -140,12 +138,11 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
         os.environ.pop("SEEQ_TILE_BYTES", None)
         os.environ.pop("SEEQ_STREAM_CH", None)
         os.environ.pop("SEEQ_FUSED_KERNEL", None)
-        os.environ.pop("SEEQ_STREAM_V2", None)
     return res
 
 
 @pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024),
-                                       ("fused-stream", None), ("fused-stream2", None), ("fused-stream", 64)])
+                                       ("fused-stream", None), ("fused-stream", 64)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
                                               ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3),
@@ -160,9 +157,9 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
             exp = oracle.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
             got = _scan(capi, pattern, tau, buf, mo | nd, dev.WANT_RECORDS, fasta, path, tile)
             assert got["path"] == (path.split("-")[0] if fusable else "generic")     # the kernel under test really ran
-            if path in ("fused-stream", "fused-stream2") and nd == SQ_FAIL and not fasta and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
+            if path == "fused-stream" and nd == SQ_FAIL and not fasta and (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), ("CACAGAT", 3)):
                 assert got["kernel"] == "k_stream" and not got["filter"]
-            if path in ("fused-stream", "fused-stream2") and tile is None and nd == SQ_FAIL and pattern == PAT40:
+            if path == "fused-stream" and tile is None and nd == SQ_FAIL and pattern == PAT40:
                 assert got["kernel"] == "k_stream" and got["filter"]      # configs[4]: partition filter automaton
             if path == "fused":
                 assert got["kernel"] == "k_direct"
@@ -177,7 +174,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
         assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
 
 
-@pytest.mark.parametrize("path", ["generic", "fused", "fused-stream", "fused-stream2", "auto"])
+@pytest.mark.parametrize("path", ["generic", "fused", "fused-stream", "auto"])
 def test_edge_buffers(gpu, capi, oracle, path):
     """Empty / ragged / maximum-ish inputs: no trailing newline, empty lines, NUL and CR bytes, a line longer
     than the LDS window (fused: falls back to the HBM per-line scan), 70 k empty lines (fused: many passes
@@ -190,7 +187,7 @@ def test_edge_buffers(gpu, capi, oracle, path):
              b"AC\rGT\r\nACGT\r\n", b"A" * 5000 + b"\n" + b"ACGT" * 3, b"\n" * 70000 + b"ACGT\n",
              bytes(range(256)) * 3, ragged, b"T" * 4090 + b"ACGT\nACGT" + b"T" * 4090 + b"AC\nGT\n",
              (b"ACGT" * 300 + b"\n") * 40,
-             # k_stream2: 64 KB tiles of four-byte hit lines (16 384 per tile, 256 per lane stretch), then ordinary lines
+             # whole tiles of four-byte hit lines, then ordinary lines; one 80 KB line; lines that end right behind a kilobyte
              b"ACG\n" * 40000 + b"ACGT\n" * 10, b"ACGT" * 20000 + b"\nACGT\n", (b"T" * 1020 + b"ACGT\n") * 130]
     for buf in cases:
         for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
@@ -365,6 +362,61 @@ print("OK")
     env = dict(os.environ, SEEQ_CHUNK_BYTES="1000")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_multi_pattern_scan_vs_independent_oracle_scans(gpu, capi, oracle):
+    """Several patterns over one text (barcode demultiplexing, reference doc/response.tex:358-360): the text is staged once,
+    every pattern's counts and records must be those of its own, independent oracle scan; the best-barcode assignment
+    built on top is checked against the same rule applied to the oracle's records."""
+    from seeq_amd import device as dev
+    rng = random.Random(11)
+    barcodes = ["ACGTTGCA", "TTGACCGA", "GGCATTAC", "CAGTGTCA", "ATATCGCG", "GATTACAG", PAT20, "TG[AC]CANNGT"]
+    taus = [1, 1, 1, 2, 0, 1, 3, 1]
+    lines = []
+    for i in range(4000):
+        n = rng.choice([40, 75, 150, 151])
+        t = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            k = rng.randrange(len(barcodes))
+            core = dev.plain_pattern(barcodes[k]).replace("N", "A")
+            c = _mutate(rng, core, rng.randint(0, taus[k] + 1))
+            p = rng.randrange(0, max(1, n - len(c)))
+            t[p:p + len(c)] = list(c)
+        if rng.random() < 0.02:
+            t[rng.randrange(n)] = "N"
+        lines.append("".join(t)[:n])
+    buf = ("\n".join(lines) + "\n").encode()
+    pats = [dev.Pattern(b, t) for b, t in zip(barcodes, taus)]
+    sc = dev.Scanner()
+    for opt in (SQ_BEST, SQ_ALL):
+        got = sc.scan_host_multi(pats, buf, opt, dev.WANT_RECORDS)
+        exp = [oracle.buffer_scan(b, t, buf, opt) for b, t in zip(barcodes, taus)]
+        for k in range(len(pats)):
+            assert got[k]["nlines"] == exp[k]["nlines"] == len(lines)
+            assert got[k]["nmatchlines"] == exp[k]["nmatchlines"], (k, opt)
+            assert np.array_equal(got[k]["records"].astype(np.uint64), exp[k]["records"]), (k, opt)
+        if opt == SQ_BEST:
+            which, dist, start, end = dev.assign_best(got, len(lines))
+            ew = [-1] * len(lines); ed = [None] * len(lines)
+            for k in range(len(pats)):
+                for ln, s, e, d in exp[k]["records"]:
+                    if ed[int(ln) - 1] is None or int(d) < ed[int(ln) - 1]:
+                        ew[int(ln) - 1], ed[int(ln) - 1] = k, int(d)
+            assert which.tolist() == ew
+            assert [None if x < 0 else int(x) for x in dist.tolist()] == ed
+            assert (which >= 0).sum() > len(lines) // 4          # the test really assigns reads
+    cnt = sc.scan_host_multi(pats, buf, 0, dev.WANT_COUNTLINES)
+    for k in range(len(pats)):
+        assert cnt[k]["nmatchlines"] == oracle.buffer_scan(barcodes[k], taus[k], buf, 0)["nmatchlines"]
+    # the same over a device-resident tensor
+    import torch
+    t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    got = sc.scan_tensor_multi(pats, t, SQ_BEST, dev.WANT_RECORDS)
+    for k in range(len(pats)):
+        assert np.array_equal(got[k]["records"].astype(np.uint64), oracle.buffer_scan(barcodes[k], taus[k], buf, SQ_BEST)["records"]), k
+    sc.close()
+    for p in pats:
+        p.close()
 
 
 def test_cli_pipelined_ingest_lanes_and_devices(gpu, capi):
@@ -589,14 +641,12 @@ def _mutate(rng, pat, nerr):
     return "".join(s)
 
 
-@pytest.mark.parametrize("ch,v2", [(128, 0), (128, 1), (64, 0)])
-def test_stream_chunk_and_tile_boundaries(gpu, capi, oracle, ch, v2):
-    """k_stream / k_stream2 give lanes fixed chunks (128 B) / stretches (1 KB) of the text, so hits, newlines and whole
-    lines straddle chunk, tile (64 chunks: 8 KB / 64 KB) and segment boundaries in every possible way: pattern copies
-    planted at every offset around the boundaries, lines from 0 bytes to more than a tile with several hits each (one
-    line reported by many lanes), non-DNA bytes before / after hits (dirty text: the filter's verdicts get verified),
-    small segments.  (128, 0): the library's default, k_stream; (128, 1): k_stream2 on the plain text (SEEQ_STREAM_V2=1),
-    k_stream on the FASTA part; (64, 0): k_stream's 64-byte-chunk variant."""
+@pytest.mark.parametrize("ch", [128, 64])
+def test_stream_chunk_and_tile_boundaries(gpu, capi, oracle, ch):
+    """k_stream gives lanes fixed chunks of the text, so hits, newlines and whole lines straddle chunk, tile
+    (64 chunks) and segment boundaries in every possible way: pattern copies planted at every offset around
+    the boundaries, lines from 0 to 30 000 bytes with several hits each (one line reported by many lanes),
+    non-DNA bytes before / after hits (dirty text: the filter's verdicts get verified), small segments."""
     code = r'''
 import os, sys, random, numpy as np
 sys.path.insert(0, %r)
@@ -608,7 +658,7 @@ o = Oracle()
 pat = "GATGTAGCGCGATTAGCCTG"
 rng = random.Random(77)
 def dna(n): return "".join(rng.choice("ACGT") for _ in range(n))
-tile = %d
+tile = 64 * %d
 for dirty in (False, True):
     parts = []
     # 1. copies ending at every offset around the first tile boundaries (one line per copy, lengths vary)
@@ -639,9 +689,6 @@ for dirty in (False, True):
             exp = o.buffer_scan(pat, 3, buf, opt)
             got = sc.scan_host(p, buf, opt, dev.WANT_RECORDS)
             assert sc.last_kernel() == "k_stream", sc.last_kernel()
-            want2 = tile == 65536 and os.environ.get("SEEQ_OVERLAP") != "1"
-            # (a line longer than a 64 KB tile with a hit in it sends the scan context to k_stream's long-line variant)
-            assert sc.last_stream_kernel() in (("k_stream2", "k_stream") if want2 else ("k_stream",)), sc.last_stream_kernel()
             assert got["nlines"] == exp["nlines"], (dirty, opt, got["nlines"], exp["nlines"])
             assert got["nmatchlines"] == exp["nmatchlines"], (dirty, opt, got["nmatchlines"], exp["nmatchlines"])
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, opt)
@@ -694,14 +741,13 @@ for tail in ("\n", ""):
     assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
     sc.close(); p.close()
 print("OK")
-''' % (ROOT, os.path.join(ROOT, "tests"), 65536 if (ch == 128 and v2) else 64 * ch, ch, ch)
-    # (many small segments, one after the other / with the opt-in overlapped post-pass; one segment)
-    for seg, ovl in (("65536", "0"), ("65536", "1"), ("0", "0")):
-        env = dict(os.environ, SEEQ_STREAM_CH=str(ch), SEEQ_OVERLAP=ovl, SEEQ_STREAM_V2=str(v2))
+''' % (ROOT, os.path.join(ROOT, "tests"), ch, ch, ch)
+    for seg in ("65536", "0"):                     # many small segments; one segment
+        env = dict(os.environ, SEEQ_STREAM_CH=str(ch))
         if seg != "0":
             env["SEEQ_SEGMENT_BYTES"] = seg
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
-        assert r.returncode == 0 and "OK" in r.stdout, (seg, ovl, r.stdout[-500:], r.stderr[-2000:])
+        assert r.returncode == 0 and "OK" in r.stdout, (seg, r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_stream_fuzz_patterns(gpu, capi, oracle):
