@@ -298,8 +298,8 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="best")
     ap.add_argument("--pattern", default=None, help="non-default patterns are for experiments (config names them)")

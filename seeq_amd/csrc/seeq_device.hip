@@ -639,6 +639,7 @@ struct seeqdev_pattern {
    uint32_t *h_peq;          /* host copy of d_peq */
    int       sdfa_state;     /* the streaming automaton of k_stream (seeq_dfa.h): 0 not tried, 1 built, -1 none fits */
    uint16_t *d_sdfa;         /* transition table in HBM, staged into LDS by k_stream */
+   uint16_t *d_sdfa_skip;    /* its skip variant (SQ_IGNORE: column 4 maps every state onto itself) */
    uint32_t  sdfa_rows, sdfa_final_base;
    int       sdfa_parts;     /* 1: the complete automaton (exact verdicts); > 1: partition filter (candidates) */
    int       sdfa_warm;      /* bytes of warm-up a chunk walk needs */
@@ -696,6 +697,7 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
    (void)use_device(p->device);
    if (p->d_peq) (void)hipFree(p->d_peq);
    if (p->d_sdfa) (void)hipFree(p->d_sdfa);
+   if (p->d_sdfa_skip) (void)hipFree(p->d_sdfa_skip);
    free(p->keys);
    free(p->h_peq);
    free(p);
@@ -1127,11 +1129,13 @@ static int run_segments(seeqdev_scan *s)
    int stream_ch = 128;
    {
       /* SQ_FAIL: always.  SQ_CONVERT: exact through the SUB variant (non-DNA bytes replaced by 'N' in registers).
-         Otherwise (SQ_IGNORE; SQ_CONVERT without SUB) k_stream is exact on clean text only: it runs until it meets a
-         non-DNA byte (Counters.dirty -> overflow flag 16: the scan is re-run on the per-line kernels, for good), and
-         not on FASTA input (header lines are made of such bytes). */
+         SQ_IGNORE on read-length lines: the SUB variant with skip bytes (its hit lines become candidates where a skipped
+         byte sits in a warm-up window).  Otherwise (SQ_IGNORE on long lines; without SUB) k_stream is exact on clean text
+         only: it runs until it meets a non-DNA byte (Counters.dirty -> overflow flag 16: the scan is re-run on the per-line
+         kernels, for good), and not on FASTA input (header lines are made of such bytes). */
       const int nd = options & MASK_NONDNA;
-      can_sub = nd == SQ_CONVERT && !fasta && kn.stream_ch == 128 && !kn.stream_ilp1 && !kn.no_sub;
+      const bool long_lines = s->avg_line > 600.0 || s->force_ll;
+      can_sub = (nd == SQ_CONVERT || (nd == SQ_IGNORE && !long_lines && !s->no_stream_nd)) && !fasta && kn.stream_ch == 128 && !kn.stream_ilp1 && !kn.no_sub;
       const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || can_sub || (!s->no_stream_nd && !fasta));
       if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && kn.kernel != 2) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
@@ -1140,8 +1144,11 @@ static int run_segments(seeqdev_scan *s)
             mp->sdfa_state = -1;
             if (d) {
                const size_t bytes = (size_t)d->nrows * 16;
-               if (hipMalloc((void **)&mp->d_sdfa, bytes) == hipSuccess &&
-                   hipMemcpy(mp->d_sdfa, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess) {
+               uint16_t *skip = seeq_dfa_skip_variant(d);
+               if (skip && hipMalloc((void **)&mp->d_sdfa, bytes) == hipSuccess &&
+                   hipMemcpy(mp->d_sdfa, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess &&
+                   hipMalloc((void **)&mp->d_sdfa_skip, bytes) == hipSuccess &&
+                   hipMemcpy(mp->d_sdfa_skip, skip, bytes, hipMemcpyHostToDevice) == hipSuccess) {
                   mp->sdfa_rows = d->nrows;
                   mp->sdfa_final_base = d->acc_final;            /* state value of ACC_NEW */
                   mp->sdfa_parts = d->nparts;
@@ -1149,6 +1156,7 @@ static int run_segments(seeqdev_scan *s)
                   mp->sdfa_pacc = d->p_accept;
                   mp->sdfa_state = 1;
                }
+               free(skip);
                seeq_dfa_free(d);
             }
          }
@@ -1170,7 +1178,8 @@ static int run_segments(seeqdev_scan *s)
    unsigned nslices = 1;                      /* hit slices: one per wave */
    const int stream_wu = use_stream && pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
-   bool stream_ilp2 = false, stream_ll = false, stream_sub = false;
+   bool stream_ilp2 = false, stream_ll = false;
+   int stream_sub = 0;                        /* 0, 1: SQ_CONVERT ('N' for non-DNA bytes), 2: SQ_IGNORE (skip bytes) */
    size_t dfa_lds = 0;
    if (use_fused) {
       if (use_stream) {
@@ -1178,10 +1187,11 @@ static int run_segments(seeqdev_scan *s)
          tile_bytes = 64u * (uint32_t)stream_ch;
          stream_ilp2 = stream_ch == 128 && !kn.stream_ilp1;
          stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
-         stream_sub = can_sub;
+         stream_sub = can_sub ? ((options & MASK_NONDNA) == SQ_IGNORE ? 2 : 1) : 0;
 #define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
-         stream_fn = stream_sub ? (stream_ll ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true, true) : SEEQ_STREAM_FN(128, 8, true, false, true, true))
-                                             : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, true) : SEEQ_STREAM_FN(128, 8, true, false, false, true)))
+         stream_fn = stream_sub == 2 ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, 2) : SEEQ_STREAM_FN(128, 8, true, false, false, 2))
+                   : stream_sub ? (stream_ll ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true, 1) : SEEQ_STREAM_FN(128, 8, true, false, true, 1))
+                                             : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, 1) : SEEQ_STREAM_FN(128, 8, true, false, false, 1)))
                    : stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
                                         : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true) : SEEQ_STREAM_FN(128, 8, true, false, true)))
                    : fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, false) : SEEQ_STREAM_FN(128, 8, true, true, false))
@@ -1296,7 +1306,7 @@ static int run_segments(seeqdev_scan *s)
          f.cnt = c;
          uint32_t pos_bias = 0;
          if (use_stream) {
-            f.dfa = pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
+            f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
             /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
             uint64_t room = 0xFFFFFFF0ull - a.seg_len;
             if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;
@@ -1309,8 +1319,9 @@ static int run_segments(seeqdev_scan *s)
          f.slice_cap = f.cap_tmp / nsl;
          if (use_stream) {
 #define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st, f)
-            if (stream_sub && stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true, true); }
-            else if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, true); }
+            if (stream_sub == 2) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, 2); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, 2); }
+            else if (stream_sub && stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true, 1); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true, 1); }
+            else if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, 1); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, 1); }
             else if (stream_ll && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true, true); }
             else if (stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true); }
             else if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false); }

@@ -233,6 +233,23 @@ static inline seeq_dfa_t *seeq_dfa_layout_stream(uint32_t *next, uint32_t n)
    return d;
 }
 
+/* The SKIP variant of a laid-out table (k_stream under SQ_IGNORE, reference libseeq.c:265-266: a byte that is neither a
+ * base nor a terminator is skipped): column 4 -- no DNA byte maps to it; k_stream replaces every byte to skip by 'H' --
+ * leads every state onto itself (ACC_NEW onto ACC_OLD: the line's first hit is reported once).  Same rows, same state
+ * values as the table it is made from.  Returns a malloc'ed copy of the table, or NULL. */
+static inline uint16_t *seeq_dfa_skip_variant(const seeq_dfa_t *d)
+{
+   uint16_t *t = (uint16_t *)malloc((size_t)d->nrows * 8 * sizeof(uint16_t));
+   if (!t) return NULL;
+   memcpy(t, d->table, (size_t)d->nrows * 8 * sizeof(uint16_t));
+   for (uint32_t s = 0; s < d->nrows; s++) {
+      const int rot = (int)((s >> 3) & 1);
+      const uint32_t self = s == d->nstates ? 1u : s;                  /* row nstates is ACC_NEW: on to ACC_OLD (row 1) */
+      t[(size_t)s * 8 + (size_t)(4 ^ (rot ? 4 : 0))] = (uint16_t)(self * 16 + (((self >> 3) & 1) ? 8 : 0));
+   }
+   return t;
+}
+
 /* The complete automaton of the pattern, or NULL when it has more than SEEQ_DFA_MAX_STATES states. */
 static inline seeq_dfa_t *seeq_dfa_build_stream(const char *keys, int m, int tau)
 {

@@ -39,7 +39,7 @@ struct FusedArgs {
    uint32_t       slice_cap;   /* entries per slice = cap_tmp / slices           */
    uint32_t      *wg_hits;     /* per slice (= per wave of k_stream / k_direct): entries stored */
    uint32_t      *wg_part;     /* per slice: {lines, headers, hit lines | overflow<<31, flags (k_stream: 1 = met a byte outside
-                                  its alphabet, 2 = wants the long-line variant)}                     */
+                                  its alphabet, 2 = wants the long-line variant, 4 = its hit lines are a superset)} */
    uint32_t      *tile_dirty;  /* k_stream, long-line mode: per tile, 1 when it holds a byte outside the alphabet (then its exclusive prefix); else NULL */
    uint64_t      *tile_dmask;  /* k_stream, long-line mode: per tile, one bit per 128-byte chunk (lane) that holds a non-alphabet byte */
    uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */
@@ -199,6 +199,12 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       if (flags & 1u) {
          c->dirty |= 1u;
          if (a.options & MASK_NONDNA) c->overflow |= 16u;     /* SQ_CONVERT / SQ_IGNORE: k_stream is only exact on clean text -> re-run */
+      }
+      if (flags & 4u) {
+         c->dirty |= 1u;                                      /* skip bytes in a warm-up window / a NUL: the hit lines are candidates */
+         /* SQ_IGNORE on text that is mostly skip bytes (FASTQ quality lines): nearly every line becomes a candidate and the
+            exact pass scans them all -- the per-line kernel does that in one pass: re-run there, and stay */
+         if ((a.options & MASK_NONDNA) == SQ_IGNORE && (uint64_t)hits * 4 > (uint64_t)lines) c->overflow |= 16u;
       }
       if (flags & 2u) c->overflow |= 32u;                     /* re-run once with the long-line variant (then kept) */
       c->seg_nlines = lines;

@@ -116,16 +116,23 @@ __device__ __forceinline__ void stream_own4x2(uint32_t &sa, uint32_t wa, uint32_
 
 /* SQ_CONVERT (reference libseeq.c:223-228: a byte that is not A C G T N or a terminator counts as 'N'): four text bytes
  * with every byte outside the alphabet replaced by 'N' -- and NUL, which ends the line in every mode (seeqcore.h:89-111,
- * libseeq.c:267-270), by a byte of the DEAD column -- so that the walk over them is exact. */
-__device__ __forceinline__ uint32_t stream_sub4(uint32_t w)
+ * libseeq.c:267-270), by a byte of the DEAD column -- so that the walk over them is exact.
+ * SQ_IGNORE (libseeq.c:265-266: such a byte is skipped, but counted in coordinates): replaced by 'H', a byte of column 4,
+ * which the skip variant of the table (seeq_dfa_skip_variant) maps every state onto itself with. */
+template <int SUB = 1>
+__device__ __forceinline__ uint32_t stream_sub4(uint32_t w, uint32_t &nuls)
 {
+   /* opaque: the tile-wide alphabet check has computed fused_bad4 of the same word; without this the compiler keeps all
+      its intermediates (three values per word, 32 words) in scratch on EVERY tile to reuse them here */
+   asm volatile("" : "+v"(w));
    const uint32_t bad = fused_bad4(w);
    if (bad == 0) return w;
    uint32_t f = (((bad & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | bad) & 0x80808080u;      /* 0x80 per byte outside the alphabet */
    uint32_t z = ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;         /* 0x80 per NUL byte */
+   nuls |= z;
    f = f | (f - (f >> 7));                                                      /* -> 0xFF */
    z = z | (z - (z >> 7));
-   w = (w & ~f) | (0x4E4E4E4Eu & f);                                            /* 'N' */
+   w = (w & ~f) | ((SUB == 2 ? 0x48484848u : 0x4E4E4E4Eu) & f);                 /* 'N' / 'H' (column 4: skip) */
    return (w & ~z) | (0x4C4C4C4Cu & z);                                         /* column 6: DEAD until the next newline */
 }
 
@@ -153,10 +160,15 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
  * unchanged; candidates inside a header are discarded by the exact pass, which looks at the first byte of the line. */
 /* LL: long-line mode -- per-tile "dirty" flags and the segment's last newline for the window walk of the exact pass
  * (kept out of the read-length kernel: its tile loop has no register to spare). */
-/* SUB (SQ_CONVERT): tiles that hold such bytes are walked over a corrected copy (stream_sub4) held in registers: the
- * verdicts are exact on any text and nothing needs re-running.  (SQ_IGNORE skips such bytes, which stretches the text a
- * match spans beyond what a chunk's warm-up covers: there the scan is still redone on the per-line kernels.) */
-template <int CH, int WU, bool ILP2, bool FA, bool LL, bool SUB = false>
+/* SUB = 1 (SQ_CONVERT): tiles that hold such bytes are walked over a corrected copy (stream_sub4) held in registers: the
+ * verdicts are exact on any text and nothing needs re-running.
+ * A NUL ends its line for the chain that meets it, but not for the chains behind it on the same line: a tile with a NUL
+ * flags the scan as a superset (wg_part flag 4) and the exact pass verifies the candidates.
+ * SUB = 2 (SQ_IGNORE, read-length lines): the same with skip bytes.  Skipped bytes stretch the text a match spans, so a
+ * chain whose warm-up window holds one has not seen enough of the line when its own bytes begin: it reports the line its
+ * first byte lies in as a candidate whatever the walk says (a made-up first hit), the wave flags the scan as a superset
+ * (wg_part flag 4) and the exact pass, which knows how to skip, verifies the candidates. */
+template <int CH, int WU, bool ILP2, bool FA, bool LL, int SUB = 0>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
@@ -209,32 +221,51 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
       }
       /* ---- alphabet check, done with before the walk starts (nothing of it stays live) ---- */
+      uint32_t fake = 0;                                  /* SUB == 2: bit 0 / 1 = chain A / B reports its first byte's line unseen */
       {
-         uint32_t bad = 0;
+         uint32_t bad = 0, bad_mid = 0, bad_tail = 0;     /* (SUB == 2: bytes 32..63 and 96..127 apart -- the warm-up windows of chain B and of the next lane's chain A) */
 #pragma unroll
-         for (int q = 0; q < NQ; q++) bad |= fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);
+         for (int q = 0; q < NQ; q++) {
+            const uint32_t b = fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);
+            if (SUB == 2 && (q == NQ / 2 - 2 || q == NQ / 2 - 1)) bad_mid |= b;
+            else if (SUB == 2 && q >= NQ - 2) bad_tail |= b;
+            else bad |= b;
+         }
+         bad |= bad_mid | bad_tail;
          /* a byte outside the alphabet anywhere in the tile: the scan's verdicts need verifying */
          uint64_t badlanes = __ballot(bad != 0);
          uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(badlanes != 0 ? 1 : 0);
          if (SUB) {
-            if (flag) {                                   /* wave-uniform */
-#pragma unroll
-               for (int q = 0; q < NQ; q++) {
-                  v[q].x = stream_sub4(v[q].x); v[q].y = stream_sub4(v[q].y); v[q].z = stream_sub4(v[q].z); v[q].w = stream_sub4(v[q].w);
-               }
-            }
             /* the 32 bytes before the tile belong to another tile: looked at on their own (the same for all lanes) */
             const uint32_t pbad = fused_bad4(pa.x) | fused_bad4(pa.y) | fused_bad4(pa.z) | fused_bad4(pa.w) |
                                   fused_bad4(pb.x) | fused_bad4(pb.y) | fused_bad4(pb.z) | fused_bad4(pb.w);
-            if (__builtin_amdgcn_readfirstlane(pbad != 0 ? 1 : 0)) {
-               pa.x = stream_sub4(pa.x); pa.y = stream_sub4(pa.y); pa.z = stream_sub4(pa.z); pa.w = stream_sub4(pa.w);
-               pb.x = stream_sub4(pb.x); pb.y = stream_sub4(pb.y); pb.z = stream_sub4(pb.z); pb.w = stream_sub4(pb.w);
+            const bool pre = __builtin_amdgcn_readfirstlane(pbad != 0 ? 1 : 0) != 0;
+            if (SUB == 2 && (flag || pre)) {              /* (wave-uniform) whose warm-up window holds a byte that will be skipped? */
+               fake = (stream_from_prev_lane(bad_tail, pbad) ? 1u : 0u) | (bad_mid ? 2u : 0u);
+               if (__ballot(fake != 0)) wv_dirty |= 4u;   /* the hit lines of this scan are a superset: the exact pass decides */
             }
-            flag = 0; badlanes = 0;                       /* handled: only a newline (or NUL) ends a line now */
+            uint32_t nuls = 0, pnuls = 0;
+            if (flag) {                                   /* wave-uniform */
+#pragma unroll
+               for (int q = 0; q < NQ; q++) {
+                  v[q].x = stream_sub4<SUB>(v[q].x, nuls); v[q].y = stream_sub4<SUB>(v[q].y, nuls);
+                  v[q].z = stream_sub4<SUB>(v[q].z, nuls); v[q].w = stream_sub4<SUB>(v[q].w, nuls);
+               }
+            }
+            if (pre) {
+               pa.x = stream_sub4<SUB>(pa.x, pnuls); pa.y = stream_sub4<SUB>(pa.y, pnuls); pa.z = stream_sub4<SUB>(pa.z, pnuls); pa.w = stream_sub4<SUB>(pa.w, pnuls);
+               pb.x = stream_sub4<SUB>(pb.x, pnuls); pb.y = stream_sub4<SUB>(pb.y, pnuls); pb.z = stream_sub4<SUB>(pb.z, pnuls); pb.w = stream_sub4<SUB>(pb.w, pnuls);
+            }
+            /* handled: only a newline or a NUL ends a line now.  A NUL does so for the chain that meets it, not for the chains
+               behind it on the same line: the scan's hit lines become candidates, and for the window walk of the exact pass
+               (LL) the lanes that hold one count as not clean */
+            flag = 0;
+            badlanes = __ballot(nuls != 0);
+            if (badlanes | __ballot(pnuls != 0)) wv_dirty |= 4u;
          }
          asm volatile("" : "+s"(flag));                   /* pinned here: the walk below needs the registers */
          wv_dirty |= flag;
-         if (LL && lane == 0) { a.tile_dirty[tile] = flag; a.tile_dmask[tile] = badlanes; }
+         if (LL && lane == 0) { a.tile_dirty[tile] = (flag || badlanes) ? 1u : 0u; a.tile_dmask[tile] = badlanes; }
       }
       uint32_t hmask[NM], nmask[NM];
       if (ILP2 && CH == 128) {
@@ -291,6 +322,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          }
          hmask[r] = hm; nmask[r] = nm;                    /* first character of the group = bit 31 */
       }
+      }
+      if (SUB == 2 && ILP2 && CH == 128) {                /* made-up first hits at the first byte of a chain (see SUB) */
+         if (fake & 1u) hmask[0] |= 0x80000000u;
+         if (fake & 2u) hmask[NM / 2] |= 0x80000000u;
       }
       /* ---- bookkeeping: what the tile owns ---- */
       if (partial) {                                      /* filler bytes are nobody's newlines */

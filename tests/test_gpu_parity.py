@@ -698,16 +698,17 @@ for dirty in (False, True):
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"]
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
         sc.close(); p.close()
-        # SQ_CONVERT: k_stream walks a corrected copy of tiles with non-DNA bytes (default variant); SQ_IGNORE (and
-        # SQ_CONVERT on the 64-byte-chunk variant): k_stream on clean text, a non-DNA byte makes the library re-run on a per-line kernel
+        # SQ_CONVERT / SQ_IGNORE: k_stream walks a corrected copy of tiles with non-DNA bytes (default variant)
         for nd in (dev.SQ_CONVERT, dev.SQ_IGNORE):
             p = dev.Pattern(pat, 3)
             sc = dev.Scanner()
             for opt in (SQ_BEST, SQ_ALL):
                 exp = o.buffer_scan(pat, 3, buf, opt | nd)
                 got = sc.scan_host(p, buf, opt | nd, dev.WANT_RECORDS)
-                exact_on_dirty = nd == dev.SQ_CONVERT and %d == 128
-                assert (sc.last_kernel() == "k_stream") == (not dirty or exact_on_dirty), (dirty, nd, sc.last_kernel())
+                # (the 128-byte-chunk variant walks a corrected copy under SQ_CONVERT; under SQ_IGNORE it does on read-length
+                #  input -- this buffer's average line is long, so there a non-DNA byte sends the scan to a per-line kernel)
+                if not dirty or (nd == dev.SQ_CONVERT and %d == 128):
+                    assert sc.last_kernel() == "k_stream", (dirty, nd, sc.last_kernel())
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (dirty, nd, opt)
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, nd, opt)
             sc.close(); p.close()
@@ -905,13 +906,60 @@ def test_every_byte_value_alone(gpu, capi, oracle):
             for opt, want in ((0, dev.WANT_COUNTLINES), (SQ_ALL, dev.WANT_RECORDS), (SQ_BEST, dev.WANT_RECORDS)):
                 exp = oracle.buffer_scan(PAT20, 3, buf, opt | nd)
                 got = sc.scan_host(pat, buf, opt | nd, want)
+                # SQ_FAIL: flagged tiles -> candidates verified; SQ_CONVERT: walked over a corrected copy; SQ_IGNORE: the same
+                # with skip bytes, unless most lines become candidates (here every line holds the byte): then the per-line kernel
                 if nd != SQ_IGNORE:
-                    assert sc.last_kernel() == "k_stream", (b, nd)      # SQ_FAIL: per-candidate check; SQ_CONVERT: corrected copy
+                    assert sc.last_kernel() == "k_stream", (b, nd)
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (b, nd, opt)
                 if want == dev.WANT_RECORDS:
                     assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (b, nd, opt)
     sc.close()
     pat.close()
+
+
+def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle):
+    """SQ_IGNORE skips a byte that is neither a base nor a terminator (but counts it in coordinates), SQ_CONVERT reads it as
+    N (reference libseeq.c:223-228, 265-270).  Pattern copies with 0..4 such bytes INSIDE them, at every offset relative
+    to k_stream's 64-byte chains (so that skipped bytes fall into warm-up windows and matches straddle chunk and tile
+    boundaries), plus NULs and lines made of foreign bytes only.  Read-length lines: k_stream serves both modes itself."""
+    from seeq_amd import device as dev
+    rng = random.Random(4242)
+    foreign = "-.XH*+|!@8(\tZ"
+    for (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), (PAT40, 5)):
+        core = dev.plain_pattern(pattern).replace("N", "A")
+        lines = []
+        for i in range(3000):
+            n = rng.choice([60, 100, 149, 150, 151, 152, 200])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            if rng.random() < 0.6:
+                c = list(_mutate(rng, core, rng.randint(0, tau + 1)))
+                for _ in range(rng.choice([0, 1, 1, 2, 4])):
+                    c.insert(rng.randrange(0, len(c) + 1), rng.choice(foreign))
+                p = rng.randrange(0, max(1, n - len(c)))
+                t[p:p + len(c)] = c
+            if rng.random() < 0.1:
+                t[rng.randrange(len(t))] = rng.choice(foreign)
+            if rng.random() < 0.01:
+                t[rng.randrange(len(t))] = "\0"
+            if rng.random() < 0.01:
+                t = [rng.choice(foreign) for _ in range(rng.choice([1, 5, 40]))]
+            lines.append("".join(t))
+        buf = ("\n".join(lines) + "\n").encode("latin-1")
+        pat = dev.Pattern(pattern, tau)
+        sc = dev.Scanner()
+        for nd in (SQ_IGNORE, SQ_CONVERT, SQ_FAIL):
+            for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
+                exp = oracle.buffer_scan(pattern, tau, buf, opt | nd)
+                got = sc.scan_host(pat, buf, opt | nd, dev.WANT_RECORDS)
+                assert sc.last_kernel() == "k_stream", (pattern, nd, sc.last_kernel())     # (foreign bytes are rare enough here: no fall-back)
+                assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, nd, opt)
+                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, nd, opt)
+            expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL | nd)
+            c1 = sc.scan_host(pat, buf, nd, dev.WANT_COUNTLINES)
+            c2 = sc.scan_host(pat, buf, nd, dev.WANT_COUNTMATCH)
+            assert c1["nmatchlines"] == expa["nmatchlines"] and c2["nhits"] == len(expa["records"]), (pattern, nd)
+        sc.close()
+        pat.close()
 
 
 def test_stream_fuzz_long_lines(gpu, capi, oracle):

@@ -183,3 +183,25 @@ def test_bench_launches_its_own_ranks(gpu):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["results"]["lines"] == 600000
     assert line["results"]["oracle_lines_checked"] >= 100000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,reads", [("best", 30_000_000), ("cfg5", 18_000_000)])
+def test_two_real_segments_full_size_parity(gpu, workload, reads):
+    """More than one REAL segment (3.75 GiB each: 30 M x 151 B = 4.5 GB, 18 M x 251 B = 4.5 GB) through `bench.py`'s
+    full-size check: a 1 M-line prefix, every 97th block of 64 Ki lines and both sides of the segment seam, records bit for
+    bit against the oracle plus per-range line / matching-line counts.  (The small-segment tests use SEEQ_SEGMENT_BYTES;
+    this one is the seam at its real size, for the complete automaton and for the partition filter + two-word exact pass.)"""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--reads", str(reads), "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-per-call"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    chk = line["results"]["oracle_check"]
+    assert line["results"]["lines"] == reads and chk["result"] == "bit-exact"
+    assert chk["oracle_lines_checked"] >= 1_000_000 and chk["segment_seams_checked"] >= 1
+    assert line["roofline"]["launches_per_step"] >= 2
