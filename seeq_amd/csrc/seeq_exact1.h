@@ -130,7 +130,7 @@ template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st,
  * with <= 2 records instead of scanning them again. */
 /* WALK: compile the window walk in (long-line inputs); without it the per-character loop carries no walk state */
 template <int MODE, int W, int OPT, bool WALK>
-__global__ __launch_bounds__(256) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
+__global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
 {
    __shared__ __align__(8) uint32_t s_eqf[256 * W];
    __shared__ __align__(8) uint32_t s_eqr[256 * W];

@@ -156,13 +156,15 @@ template <> struct fused_state_t<2> {
 __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslices)
 {
    __shared__ uint32_t s_red[4][4];
-   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0, flags = 0;
+   uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0, flags = 0, busy = 0, crowded = 0;
    for (uint32_t i = threadIdx.x; i < nslices; i += 256) {
       if (a.wg_lastnl) { const uint32_t l = a.wg_lastnl[i]; lastnl = l > lastnl ? l : lastnl; }
       lines += a.wg_part[4 * i + 0];
       hdrs += a.wg_part[4 * i + 1];
       const uint32_t h = a.wg_part[4 * i + 2];
       flags |= a.wg_part[4 * i + 3];
+      busy += a.wg_part[4 * i + 0] != 0;                     /* waves that saw text / of them, those drowning in made-up candidates */
+      crowded += (a.wg_part[4 * i + 3] >> 3) & 1u;
       hits += h & 0x7FFFFFFFu;
       mx = (h & 0x7FFFFFFFu) > mx ? (h & 0x7FFFFFFFu) : mx;
       ovf |= h >> 31;
@@ -176,12 +178,14 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       mx = o > mx ? o : mx;
       ovf |= __shfl_xor(ovf, d, 64);
       flags |= __shfl_xor(flags, d, 64);
+      busy += __shfl_xor(busy, d, 64);
+      crowded += __shfl_xor(crowded, d, 64);
       const uint32_t ol = __shfl_xor(lastnl, d, 64);
       lastnl = ol > lastnl ? ol : lastnl;
    }
-   __shared__ uint32_t s_last[4], s_flags[4];
+   __shared__ uint32_t s_last[4], s_flags[4], s_busy[4], s_crowded[4];
    const int w = threadIdx.x >> 6;
-   if ((threadIdx.x & 63) == 0) { s_last[w] = lastnl; s_flags[w] = flags; }
+   if ((threadIdx.x & 63) == 0) { s_last[w] = lastnl; s_flags[w] = flags; s_busy[w] = busy; s_crowded[w] = crowded; }
    if ((threadIdx.x & 63) == 0) { s_red[w][0] = lines; s_red[w][1] = hdrs; s_red[w][2] = hits; s_red[w][3] = mx | (ovf << 31); }
    __syncthreads();
    if (threadIdx.x == 0) {
@@ -203,8 +207,11 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       if (flags & 4u) {
          c->dirty |= 1u;                                      /* skip bytes in a warm-up window / a NUL: the hit lines are candidates */
          /* SQ_IGNORE on text that is mostly skip bytes (FASTQ quality lines): nearly every line becomes a candidate and the
-            exact pass scans them all -- the per-line kernel does that in one pass: re-run there, and stay */
-         if ((a.options & MASK_NONDNA) == SQ_IGNORE && (uint64_t)hits * 4 > (uint64_t)lines) c->overflow |= 16u;
+            exact pass scans them all -- the per-line kernel does that in one pass: re-run there, and stay.  (Decided by the
+            waves: more than half of those that saw text made up more candidates than a quarter of their lines.) */
+         busy = s_busy[0] + s_busy[1] + s_busy[2] + s_busy[3];
+         crowded = s_crowded[0] + s_crowded[1] + s_crowded[2] + s_crowded[3];
+         if ((a.options & MASK_NONDNA) == SQ_IGNORE && crowded * 2 > busy) c->overflow |= 16u;
       }
       if (flags & 2u) c->overflow |= 32u;                     /* re-run once with the long-line variant (then kept) */
       c->seg_nlines = lines;

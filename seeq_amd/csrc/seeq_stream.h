@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
    uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0, wv_lastnl = 0;    /* wave-uniform */
    bool wv_overflow = false;
-   uint32_t wv_dirty = 0;
+   uint32_t wv_dirty = 0, wv_fakes = 0;
    uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
    const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
    const uint64_t last = a.nbytes - 1;
@@ -242,7 +242,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
             const bool pre = __builtin_amdgcn_readfirstlane(pbad != 0 ? 1 : 0) != 0;
             if (SUB == 2 && (flag || pre)) {              /* (wave-uniform) whose warm-up window holds a byte that will be skipped? */
                fake = (stream_from_prev_lane(bad_tail, pbad) ? 1u : 0u) | (bad_mid ? 2u : 0u);
-               if (__ballot(fake != 0)) wv_dirty |= 4u;   /* the hit lines of this scan are a superset: the exact pass decides */
+               const uint32_t nfake = (uint32_t)__popcll(__ballot((fake & 1u) != 0)) + (uint32_t)__popcll(__ballot((fake & 2u) != 0));
+               if (nfake) wv_dirty |= 4u;                 /* the hit lines of this scan are a superset: the exact pass decides */
+               wv_fakes += nfake;
             }
             uint32_t nuls = 0, pnuls = 0;
             if (flag) {                                   /* wave-uniform */
@@ -425,7 +427,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          a.tile_cl[tile] = tot_n + extra - tot_d - hd_extra;    /* counted lines: headers excluded */
          a.tile_hits[tile] = tot_h;
       }
-      if (!LL && CH == 128 && ILP2 && tot_h && !tot_n) wv_dirty |= 2u;   /* a hit inside a line of >= a whole tile: ask for the long-line variant (of this configuration) */
+      /* a hit inside a line of >= a whole tile: ask for the long-line variant (of this configuration).  (Not for the tile
+         the buffer ends in: without a newline it need not be a long line, just the tail of the last one.) */
+      if (!LL && CH == 128 && ILP2 && tot_h && !tot_n && !partial && !(t0 <= last && last < t0 + TB)) wv_dirty |= 2u;
       wv_lines += tot_n + extra;
       wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;
@@ -436,7 +440,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       a.wg_part[4 * gwave + 1] = wv_hdrs;
       if (LL) a.wg_lastnl[gwave] = wv_lastnl;    /* offset + 1 of the last newline this wave saw */
       a.wg_part[4 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
-      a.wg_part[4 * gwave + 3] = wv_dirty;       /* 1: a byte outside the alphabet, 2: wants the long-line variant (k_fused_post acts on them) */
+      if (SUB == 2 && wv_fakes * 4 > wv_lines) wv_dirty |= 8u;    /* more made-up candidates than a quarter of my lines */
+      a.wg_part[4 * gwave + 3] = wv_dirty;       /* 1: a byte outside the alphabet, 2: wants the long-line variant, 4: superset, 8: see above (k_fused_post acts on them) */
    }
 }
 

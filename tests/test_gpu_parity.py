@@ -925,7 +925,8 @@ def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle)
     from seeq_amd import device as dev
     rng = random.Random(4242)
     foreign = "-.XH*+|!@8(\tZ"
-    for (pattern, tau) in ((PAT20, 3), ("GATTAGC", 1), (PAT40, 5)):
+    # (heavy: most lines hold foreign bytes -- SQ_IGNORE may hand the text to the per-line kernel; light: few do -- it must not)
+    for (pattern, tau, heavy) in ((PAT20, 3, True), (PAT20, 3, False), ("GATTAGC", 1, False), (PAT40, 5, True), (PAT40, 5, False)):
         core = dev.plain_pattern(pattern).replace("N", "A")
         lines = []
         for i in range(3000):
@@ -933,15 +934,15 @@ def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle)
             t = [rng.choice("ACGT") for _ in range(n)]
             if rng.random() < 0.6:
                 c = list(_mutate(rng, core, rng.randint(0, tau + 1)))
-                for _ in range(rng.choice([0, 1, 1, 2, 4])):
+                for _ in range(rng.choice([0, 1, 1, 2, 4]) if heavy or rng.random() < 0.1 else 0):
                     c.insert(rng.randrange(0, len(c) + 1), rng.choice(foreign))
                 p = rng.randrange(0, max(1, n - len(c)))
                 t[p:p + len(c)] = c
-            if rng.random() < 0.1:
+            if rng.random() < (0.1 if heavy else 0.02):
                 t[rng.randrange(len(t))] = rng.choice(foreign)
             if rng.random() < 0.01:
                 t[rng.randrange(len(t))] = "\0"
-            if rng.random() < 0.01:
+            if rng.random() < (0.01 if heavy else 0.003):
                 t = [rng.choice(foreign) for _ in range(rng.choice([1, 5, 40]))]
             lines.append("".join(t))
         buf = ("\n".join(lines) + "\n").encode("latin-1")
@@ -951,7 +952,8 @@ def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle)
             for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
                 exp = oracle.buffer_scan(pattern, tau, buf, opt | nd)
                 got = sc.scan_host(pat, buf, opt | nd, dev.WANT_RECORDS)
-                assert sc.last_kernel() == "k_stream", (pattern, nd, sc.last_kernel())     # (foreign bytes are rare enough here: no fall-back)
+                if nd != SQ_IGNORE or not heavy:
+                    assert sc.last_kernel() == "k_stream", (pattern, nd, heavy, sc.last_kernel())
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, nd, opt)
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, nd, opt)
             expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL | nd)
