@@ -1176,7 +1176,7 @@ static int run_segments(seeqdev_scan *s)
    unsigned fused_grid = 1;
    int nw = 4;
    unsigned nslices = 1;                      /* hit slices: one per wave */
-   const int stream_wu = use_stream && pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
+   const int stream_wu = !use_stream ? 8 : pat->sdfa_warm <= 16 ? 4 : pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
    const void *stream_fn = nullptr;
    bool stream_ilp2 = false, stream_ll = false;
    int stream_sub = 0;                        /* 0, 1: SQ_CONVERT ('N' for non-DNA bytes), 2: SQ_IGNORE (skip bytes) */
@@ -1188,16 +1188,16 @@ static int run_segments(seeqdev_scan *s)
          stream_ilp2 = stream_ch == 128 && !kn.stream_ilp1;
          stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
          stream_sub = can_sub ? ((options & MASK_NONDNA) == SQ_IGNORE ? 2 : 1) : 0;
-#define SEEQ_STREAM_FN(...) (const void *)k_stream<__VA_ARGS__>
-         stream_fn = stream_sub == 2 ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, 2) : SEEQ_STREAM_FN(128, 8, true, false, false, 2))
-                   : stream_sub ? (stream_ll ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true, 1) : SEEQ_STREAM_FN(128, 8, true, false, true, 1))
-                                             : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false, 1) : SEEQ_STREAM_FN(128, 8, true, false, false, 1)))
-                   : stream_ll ? (fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, true) : SEEQ_STREAM_FN(128, 8, true, true, true))
-                                        : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, true) : SEEQ_STREAM_FN(128, 8, true, false, true)))
-                   : fasta ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, true, false) : SEEQ_STREAM_FN(128, 8, true, true, false))
-                   : stream_ch == 128 ? (stream_ilp2 ? (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, true, false, false) : SEEQ_STREAM_FN(128, 8, true, false, false))
-                                                     : (stream_wu == 6 ? SEEQ_STREAM_FN(128, 6, false, false, false) : SEEQ_STREAM_FN(128, 8, false, false, false)))
-                                      : (stream_wu == 6 ? SEEQ_STREAM_FN(64, 6, false, false, false) : SEEQ_STREAM_FN(64, 8, false, false, false));
+         /* the k_stream instance of this scan: <bytes per lane, warm-up dwords, two walks per lane, FASTA, long lines, SUB> */
+#define SEEQ_STREAM_FN(...) (stream_wu == 4 ? (const void *)k_stream<128, 4, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_stream<128, 6, __VA_ARGS__> \
+                                                                                                            : (const void *)k_stream<128, 8, __VA_ARGS__>)
+         stream_fn = stream_sub == 2 ? SEEQ_STREAM_FN(true, false, false, 2)
+                   : stream_sub ? (stream_ll ? SEEQ_STREAM_FN(true, false, true, 1) : SEEQ_STREAM_FN(true, false, false, 1))
+                   : stream_ll ? (fasta ? SEEQ_STREAM_FN(true, true, true) : SEEQ_STREAM_FN(true, false, true))
+                   : fasta ? SEEQ_STREAM_FN(true, true, false)
+                   : stream_ch == 128 ? (stream_ilp2 ? SEEQ_STREAM_FN(true, false, false) : SEEQ_STREAM_FN(false, false, false))
+                   : (stream_wu == 4 ? (const void *)k_stream<64, 4, false, false, false> : stream_wu == 6 ? (const void *)k_stream<64, 6, false, false, false>
+                                                                                                           : (const void *)k_stream<64, 8, false, false, false>);
 #undef SEEQ_STREAM_FN
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          int per_cu = occupancy_of(s, stream_fn, 64 * nw, dfa_lds);
@@ -1318,17 +1318,8 @@ static int run_segments(seeqdev_scan *s)
          const unsigned nsl = nslices;
          f.slice_cap = f.cap_tmp / nsl;
          if (use_stream) {
-#define SEEQ_STREAM_LAUNCH(...) hipLaunchKernelGGL((k_stream<__VA_ARGS__>), dim3(fgrid), dim3(64 * STREAM_NW), dfa_lds, st, f)
-            if (stream_sub == 2) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, 2); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, 2); }
-            else if (stream_sub && stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true, 1); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true, 1); }
-            else if (stream_sub) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false, 1); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false, 1); }
-            else if (stream_ll && fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, true); else SEEQ_STREAM_LAUNCH(128, 8, true, true, true); }
-            else if (stream_ll) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, true); else SEEQ_STREAM_LAUNCH(128, 8, true, false, true); }
-            else if (fasta) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, true, false); else SEEQ_STREAM_LAUNCH(128, 8, true, true, false); }
-            else if (stream_ch == 128 && stream_ilp2) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, true, false, false); else SEEQ_STREAM_LAUNCH(128, 8, true, false, false); }
-            else if (stream_ch == 128) { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(128, 6, false, false, false); else SEEQ_STREAM_LAUNCH(128, 8, false, false, false); }
-            else { if (stream_wu == 6) SEEQ_STREAM_LAUNCH(64, 6, false, false, false); else SEEQ_STREAM_LAUNCH(64, 8, false, false, false); }
-#undef SEEQ_STREAM_LAUNCH
+            void *kargs[] = {&f};
+            HIP_TRY(hipLaunchKernel(stream_fn, dim3(fgrid), dim3(64 * STREAM_NW), kargs, dfa_lds, st), EIO);
          }
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st, f);
          else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st, f);

@@ -59,9 +59,6 @@ __device__ __forceinline__ fused_v4u dfa_load16(const uint8_t *text, uint64_t of
 #define STREAM_OR(K) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K \
                          : "=v"(ad) : "v"(state), "v"(wm))
 #define STREAM_HIT asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(state), "v"(acc_new) : "vcc")
-#define STREAM_NL(K) asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" \
-                         : "+v"(nm) : "v"(w), "v"(ten) : "vcc")
-
 typedef __attribute__((address_space(3))) const uint16_t stream_lds_cu16;
 
 /* four warm-up characters: walk only */
@@ -75,16 +72,42 @@ __device__ __forceinline__ void stream_warm4(uint32_t &state, uint32_t w)
    STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad;
 }
 
-/* four owned characters: walk, first-hit mask, newline mask */
-__device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_t &hm, uint32_t &nm,
-                                            uint32_t acc_new, uint32_t ten)
+/* four owned characters: walk, first-hit mask (the newline masks are made apart from the walk: stream_nl_masks) */
+__device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_t &hm, uint32_t acc_new)
 {
    const uint32_t wm = w & 0x0E0E0E0Eu;
    uint32_t ad;
-   STREAM_OR(0); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(0);
-   STREAM_OR(1); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(1);
-   STREAM_OR(2); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(2);
-   STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT; STREAM_NL(3);
+   STREAM_OR(0); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
+   STREAM_OR(1); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
+   STREAM_OR(2); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
+   STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
+}
+
+/* The exact newline mask of 32 characters (eight text words; first character = bit 31), without a compare per
+ * character: per word the four "is '\n'" flags as bytes of 0 / 1, then v_dot4_u32_u8 with the weights 8 4 2 1 (x 16 for
+ * the first word of a pair) drops them into the mask, two words per shift.  `clean` (wave-uniform: the tile holds only
+ * bytes of the alphabet, or has been corrected): every such byte but '\n' has bit 6 set, so ~bit 6 is the flag -- the
+ * dot product then sums the NON-newline flags and the mask is its complement.  Otherwise the exact zero-byte test of
+ * w ^ 0x0A0A0A0A.  3.5 (clean) / 6.5 VALU per word instead of 8. */
+__device__ __forceinline__ uint32_t stream_nl_mask32(const fused_v4u &a, const fused_v4u &b, bool clean)
+{
+   const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+   uint32_t nm = 0;
+   if (clean) {
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+         const uint32_t p0 = (w[k] >> 6) & 0x01010101u, p1 = (w[k + 1] >> 6) & 0x01010101u;
+         nm = __builtin_amdgcn_udot4(p0, 0x10204080u, __builtin_amdgcn_udot4(p1, 0x01020408u, nm << 8, false), false);
+      }
+      return ~nm;
+   }
+#pragma unroll
+   for (int k = 0; k < 8; k += 2) {
+      const uint32_t x0 = w[k] ^ 0x0A0A0A0Au, x1 = w[k + 1] ^ 0x0A0A0A0Au;
+      const uint32_t f0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u, f1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u;
+      nm = __builtin_amdgcn_udot4(f0 >> 7, 0x10204080u, __builtin_amdgcn_udot4(f1 >> 7, 0x01020408u, nm << 8, false), false);
+   }
+   return nm;
 }
 
 /* Two independent walks interleaved (chains A and B of one lane): twice the gathers in flight per wave. */
@@ -94,9 +117,7 @@ __device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_
    sa = *(stream_lds_cu16 *)(uintptr_t)ada; sb = *(stream_lds_cu16 *)(uintptr_t)adb;
 #define STREAM_EV2(K) \
    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hma) : "v"(sa), "v"(acc_new) : "vcc"); \
-   asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nma) : "v"(wa), "v"(ten) : "vcc"); \
-   asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hmb) : "v"(sb), "v"(acc_new) : "vcc"); \
-   asm("v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(nmb) : "v"(wb), "v"(ten) : "vcc");
+   asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hmb) : "v"(sb), "v"(acc_new) : "vcc");
 
 __device__ __forceinline__ void stream_warm4x2(uint32_t &sa, uint32_t wa, uint32_t &sb, uint32_t wb)
 {
@@ -105,9 +126,7 @@ __device__ __forceinline__ void stream_warm4x2(uint32_t &sa, uint32_t wa, uint32
    STREAM_X2(0) STREAM_X2(1) STREAM_X2(2) STREAM_X2(3)
 }
 
-__device__ __forceinline__ void stream_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &nma,
-                                              uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t &nmb,
-                                              uint32_t acc_new, uint32_t ten)
+__device__ __forceinline__ void stream_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t acc_new)
 {
    const uint32_t wma = wa & 0x0E0E0E0Eu, wmb = wb & 0x0E0E0E0Eu;
    uint32_t ada, adb;
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
    constexpr int NM = CH / 32;                            /* mask registers per lane */
    constexpr uint32_t TB = 64u * CH;                      /* tile bytes */
-   static_assert(WU == 6 || WU == 8, "warm-up is 24 or 32 bytes");
+   static_assert(WU == 4 || WU == 6 || WU == 8, "warm-up is 16, 24 or 32 bytes");
    extern __shared__ __align__(16) uint8_t dsmem[];
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -185,7 +204,6 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
    }
    __syncthreads();                                       /* the only barrier: the table is read-only from here */
    const uint32_t acc_new = a.dfa_final_base;              /* state value of ACC_NEW (seeq_dfa_build_stream) */
-   const uint32_t ten = 0x0Au;
 
    const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
    uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0, wv_lastnl = 0;    /* wave-uniform */
@@ -222,6 +240,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       }
       /* ---- alphabet check, done with before the walk starts (nothing of it stays live) ---- */
       uint32_t fake = 0;                                  /* SUB == 2: bit 0 / 1 = chain A / B reports its first byte's line unseen */
+      bool tile_clean = false;                            /* wave-uniform: only alphabet bytes in my tile (or corrected): the cheap newline test holds */
       {
          uint32_t bad = 0, bad_mid = 0, bad_tail = 0;     /* (SUB == 2: bytes 32..63 and 96..127 apart -- the warm-up windows of chain B and of the next lane's chain A) */
 #pragma unroll
@@ -267,6 +286,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          }
          asm volatile("" : "+s"(flag));                   /* pinned here: the walk below needs the registers */
          wv_dirty |= flag;
+         tile_clean = flag == 0;
          if (LL && lane == 0) { a.tile_dirty[tile] = (flag || badlanes) ? 1u : 0u; a.tile_dmask[tile] = badlanes; }
       }
       uint32_t hmask[NM], nmask[NM];
@@ -278,23 +298,25 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
             stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].x, pa.x), sb, v[NQ / 2 - 2].x);
             stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].y, pa.y), sb, v[NQ / 2 - 2].y);
          }
-         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].z, pa.z), sb, v[NQ / 2 - 2].z);
-         stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].w, pa.w), sb, v[NQ / 2 - 2].w);
+         if (WU >= 6) {
+            stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].z, pa.z), sb, v[NQ / 2 - 2].z);
+            stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].w, pa.w), sb, v[NQ / 2 - 2].w);
+         }
          stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].x, pb.x), sb, v[NQ / 2 - 1].x);
          stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].y, pb.y), sb, v[NQ / 2 - 1].y);
          stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].z, pb.z), sb, v[NQ / 2 - 1].z);
          stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].w, pb.w), sb, v[NQ / 2 - 1].w);
 #pragma unroll
          for (int r = 0; r < NM / 2; r++) {
-            uint32_t hma = 0, nma = 0, hmb = 0, nmb = 0;
+            uint32_t hma = 0, hmb = 0;
 #pragma unroll
             for (int q = 2 * r; q < 2 * r + 2; q++) {
-               stream_own4x2(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, acc_new, ten);
-               stream_own4x2(sa, v[q].y, hma, nma, sb, v[q + NQ / 2].y, hmb, nmb, acc_new, ten);
-               stream_own4x2(sa, v[q].z, hma, nma, sb, v[q + NQ / 2].z, hmb, nmb, acc_new, ten);
-               stream_own4x2(sa, v[q].w, hma, nma, sb, v[q + NQ / 2].w, hmb, nmb, acc_new, ten);
+               stream_own4x2(sa, v[q].x, hma, sb, v[q + NQ / 2].x, hmb, acc_new);
+               stream_own4x2(sa, v[q].y, hma, sb, v[q + NQ / 2].y, hmb, acc_new);
+               stream_own4x2(sa, v[q].z, hma, sb, v[q + NQ / 2].z, hmb, acc_new);
+               stream_own4x2(sa, v[q].w, hma, sb, v[q + NQ / 2].w, hmb, acc_new);
             }
-            hmask[r] = hma; nmask[r] = nma; hmask[r + NM / 2] = hmb; nmask[r + NM / 2] = nmb;
+            hmask[r] = hma; hmask[r + NM / 2] = hmb;
          }
       } else {
       /* ---- warm-up over the previous lane's last 4*WU bytes, from the root state ---- */
@@ -304,8 +326,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
             stream_warm4(state, stream_from_prev_lane(v[NQ - 2].x, pa.x));
             stream_warm4(state, stream_from_prev_lane(v[NQ - 2].y, pa.y));
          }
-         stream_warm4(state, stream_from_prev_lane(v[NQ - 2].z, pa.z));
-         stream_warm4(state, stream_from_prev_lane(v[NQ - 2].w, pa.w));
+         if (WU >= 6) {
+            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].z, pa.z));
+            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].w, pa.w));
+         }
          stream_warm4(state, stream_from_prev_lane(v[NQ - 1].x, pb.x));
          stream_warm4(state, stream_from_prev_lane(v[NQ - 1].y, pb.y));
          stream_warm4(state, stream_from_prev_lane(v[NQ - 1].z, pb.z));
@@ -314,17 +338,20 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       /* ---- the owned chunk ---- */
 #pragma unroll
       for (int r = 0; r < NM; r++) {
-         uint32_t hm = 0, nm = 0;
+         uint32_t hm = 0;
 #pragma unroll
          for (int q = 2 * r; q < 2 * r + 2; q++) {
-            stream_own4(state, v[q].x, hm, nm, acc_new, ten);
-            stream_own4(state, v[q].y, hm, nm, acc_new, ten);
-            stream_own4(state, v[q].z, hm, nm, acc_new, ten);
-            stream_own4(state, v[q].w, hm, nm, acc_new, ten);
+            stream_own4(state, v[q].x, hm, acc_new);
+            stream_own4(state, v[q].y, hm, acc_new);
+            stream_own4(state, v[q].z, hm, acc_new);
+            stream_own4(state, v[q].w, hm, acc_new);
          }
-         hmask[r] = hm; nmask[r] = nm;                    /* first character of the group = bit 31 */
+         hmask[r] = hm;                                   /* first character of the group = bit 31 */
       }
       }
+      /* ---- newline masks, apart from the walk: SWAR flags + dot products (stream_nl_mask32) ---- */
+#pragma unroll
+      for (int r = 0; r < NM; r++) nmask[r] = stream_nl_mask32(v[2 * r], v[2 * r + 1], tile_clean);
       if (SUB == 2 && ILP2 && CH == 128) {                /* made-up first hits at the first byte of a chain (see SUB) */
          if (fake & 1u) hmask[0] |= 0x80000000u;
          if (fake & 2u) hmask[NM / 2] |= 0x80000000u;
