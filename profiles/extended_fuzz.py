@@ -8,6 +8,7 @@ o = Oracle()
 LONG = len(sys.argv) > 1 and sys.argv[1] == "long"      # long lines: the LL variant of k_stream + the window walk of k_exact1
 tot = 0; ks = {}
 BASE = int(os.environ.get("FUZZ_SEED", "100"))          # FUZZ_SEED=<n>: another set of 12 seeds
+FOREIGN = float(os.environ.get("FUZZ_FOREIGN", "0"))    # FUZZ_FOREIGN=<p>: every seed plants foreign bytes, in a fraction p of the lines (and a few NULs)
 for seed in range(BASE, BASE + 12):
     rng = random.Random(seed)
     for it in range(25):
@@ -33,11 +34,15 @@ for seed in range(BASE, BASE + 12):
                     t[p:p + len(c)] = list(c)
             if rng.random() < 0.03 and n: t[rng.randrange(n)] = "N"
             if seed % 3 == 0 and rng.random() < (0.3 if LONG else 0.01) and n: t[rng.randrange(n)] = rng.choice("!*+BJXZ.\t\r@>")
+            if FOREIGN and n:
+                for _rep in range(rng.choice([1, 1, 2, 5])):
+                    if rng.random() < FOREIGN: t[rng.randrange(n)] = rng.choice("!*+BJXZH-.\t\r@")
+                if rng.random() < FOREIGN / 20: t[rng.randrange(n)] = "\0"
             lines.append("".join(t)[:n])
         fasta = seed % 4 == 1
         if fasta:
             lines = [(">h%d " % i + l[:30]) if rng.random() < 0.3 else l for i, l in enumerate(lines)]
-        buf = ("\n".join(lines) + ("\n" if it % 2 else "")).encode()
+        buf = ("\n".join(lines) + ("\n" if it % 2 else "")).encode("latin-1")
         p = dev.Pattern(pattern, tau); sc = dev.Scanner()
         nd = [0, dev.SQ_CONVERT, dev.SQ_IGNORE][seed % 3] if not fasta else 0
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):

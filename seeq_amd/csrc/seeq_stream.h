@@ -221,13 +221,15 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       uint32_t lane_off = (uint32_t)lane * CH;
       asm volatile("" : "+v"(lane_off));
       const uint64_t my = t0 + lane_off;
-      const bool partial = t0 + TB > lim;                 /* wave-uniform */
+      /* wave-uniform; the segment's last tile, cut short (32-bit scalar compares: a 64-bit one would go through VGPRs) */
+      const bool partial = tile + 1 == a.ntiles && (a.seg_len % TB) != 0;
       fused_v4u v[NQ];
       if (!partial) {
          const uint8_t *p = a.text + my;
 #pragma unroll
          for (int q = 0; q < NQ; q++)
-            v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * q);   /* (nt loads: the eight loads of a 128-B line no longer merge in L1 -- 2x slower) */
+            v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * q);   /* (nt loads: the eight loads of a 128-B line no longer merge in L1 -- 2x slower;
+                                                                                     a uniform base + per-load 32-bit offsets instead of one 64-bit address with immediates: 20 % slower) */
       } else {
 #pragma unroll
          for (int q = 0; q < NQ; q++) v[q] = dfa_load16(a.text, my + 16 * q, lim);       /* '\n' beyond the segment */
