@@ -311,9 +311,9 @@ static void *reader_main(void *arg)
                got = (size_t)r;
             }
          } else {
-            pthread_setcancelstate(PTHREAD_CANCEL_ENABLE, &unused);
+            /* (not cancellable: chunk_read joins its pread threads, and a regular file never blocks for long --
+               seeqClose waits for this chunk and the reader then sees reader_stop) */
             got = chunk_read(s->fdi, sl->buf + sl->len, sl->cap - sl->len);
-            pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &unused);
          }
          s->t_read += now_s() - t0;
          if (got == 0) { eof = 1; break; }
