@@ -95,7 +95,7 @@ struct Counters {
    uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
-   uint32_t seg_tmp_hits;   /* k_fused: hit lines of this segment (summed per workgroup) */
+   uint32_t seg_tmp_hits;   /* (spare) */
    uint32_t seg_nmatch;     /* lines of the segment with >= 1 verified hit (superset filters) */
    uint32_t dirty;          /* k_stream: the text holds bytes outside {ACGTN, acgtn, '\n'}: its hit lines need verifying */
    uint64_t need_records;   /* total */

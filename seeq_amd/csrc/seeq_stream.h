@@ -2,7 +2,7 @@
  * seeq_stream.h -- k_stream: line-agnostic, table-driven scan.  The text is read ONCE, coalesced by
  * construction, and the per-character work is one LDS gather.
  *
- * k_direct / k_dfa give every lane one LINE; the lane then fetches its line with strided loads, which
+ * k_direct gives every lane one LINE; the lane then fetches its line with strided loads, which
  * re-reads the text from L2 / HBM a second time and is what bounds those kernels.  Here a lane owns a
  * fixed CHUNK of CH consecutive bytes (a wave owns a tile of 64 * CH bytes), whatever the line structure;
  * with CH = 128 every 128-byte memory line is consumed whole by one lane (eight back-to-back 16-byte loads
@@ -17,8 +17,9 @@
  *     state ACC_NEW; the lane records it in a bit mask (v_cmp + v_addc per character).  A line that spans
  *     chunks can be reported by more than one lane: duplicates are adjacent after the ordered compaction
  *     and are dropped by k_stream_bounds.
- *   - Newlines are found exactly (SDWA byte compare + v_addc into a second mask); the rank of a hit's line
- *     is the number of newlines before the hit, so lines are numbered without ever building a line index.
+ *   - Newlines are found exactly, apart from the walk (stream_nl_mask32: per text word four flags by SWAR, dropped into
+ *     the mask by v_dot4_u32_u8); the rank of a hit's line is the number of newlines before the hit, so lines are
+ *     numbered without ever building a line index.
  *   - Bytes outside {A,C,G,T,N,a,c,g,t,n,'\n'} alias onto table columns; such a byte sets Counters.dirty and
  *     every reported line is then verified by the exact pass (k_exact1 COUNT), and only then.  On
  *     clean input the exact pass trusts the filter.
