@@ -92,7 +92,7 @@ struct Counters {
    uint64_t records;
    uint64_t headers;
    /* workspace overflow report */
-   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant */
+   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant; 64: a hit entry points outside its segment (a bug: the scan fails) */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
    uint32_t seg_tmp_hits;   /* (spare) */
@@ -715,6 +715,7 @@ struct ScanKnobs {
    int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
+   int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -832,6 +833,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
+      v = getenv("SEEQ_STREAM_WU");    kn.min_wu = v ? atoi(v) : 0;
       s->ncu = 256;
       int dev = 0;
       hipDeviceProp_t prop;
@@ -1176,7 +1178,8 @@ static int run_segments(seeqdev_scan *s)
    unsigned fused_grid = 1;
    int nw = 4;
    unsigned nslices = 1;                      /* hit slices: one per wave */
-   const int stream_wu = !use_stream ? 8 : pat->sdfa_warm <= 16 ? 4 : pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
+   int stream_wu = !use_stream ? 8 : pat->sdfa_warm <= 16 ? 4 : pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
+   if (stream_wu < kn.min_wu) stream_wu = kn.min_wu >= 8 ? 8 : 6;
    const void *stream_fn = nullptr;
    bool stream_ilp2 = false, stream_ll = false;
    int stream_sub = 0;                        /* 0, 1: SQ_CONVERT ('N' for non-DNA bytes), 2: SQ_IGNORE (skip bytes) */
@@ -1502,6 +1505,11 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
       size_t nl = s->cap_lines, nhl = s->cap_hitlines, nrec = s->cap_records;
       if (h.overflow & 1u) nl = (size_t)h.need_lines + (h.need_lines >> 3) + 64;
       if (h.overflow & 2u) nhl = (size_t)h.need_hitlines + (h.need_hitlines >> 3) + 64;
+      if (h.overflow & 64u) {
+         snprintf(g_last_error, sizeof g_last_error, "internal inconsistency in the hit list (k_stream_bounds)");
+         errno = EIO;
+         return -1;
+      }
       if (h.overflow & 8u) s->no_stream = true;
       if (h.overflow & 16u) s->no_stream_nd = true;
       if (h.overflow & 32u) s->force_ll = true;

@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       const uint64_t need = (uint64_t)mx * nslices + (uint64_t)nslices * 64;
       if (need > c->need_hitlines) c->need_hitlines = need > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)need;
       if (ovf) { atomicOr(&c->overflow, 2u); hits = 0; }
+      /* a hit list overflowed, in this segment or in an earlier one: the run is void (seeqdevScanFetch grows the workspace
+         and runs it again) and k_stream_reorder / k_fused_reorder write nothing any more -- so no later kernel of this
+         run may look at the (stale) hit arrays either: no hit lines from here on */
+      if (c->overflow & 2u) hits = 0;
       c->seg_nhitlines = hits;
       c->seg_nrec = hits;                                   /* (k_seg_mid's job; the slices cannot hold more than cap_hitlines) */
       if (hits > c->need_hitlines) c->need_hitlines = hits;

@@ -538,6 +538,11 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit
       }
       if (!a.nh[k]) continue;                             /* k_stream already found the start of the line */
       const uint64_t hp = a.seg_base + a.hit_start[k];   /* a byte of the line (inside the segment); never '\n' */
+      if (hp >= a.nbytes || hp < segb || hp >= segb + a.seg_len) {       /* cannot be: an entry the scan kernel never wrote -- fail loudly, touch nothing */
+         atomicOr(&c->overflow, 64u);
+         a.hit_start[k] = 0xFFFFFFFFu;
+         continue;
+      }
       /* backwards to the byte after the previous '\n': first inside the hit's tile, then -- chromosome-long lines --
          tile by tile through the per-tile line counts (tile_cl[] holds their exclusive prefix: 4 bytes per 8 KB of
          text), and only when the line starts before the segment through the text in front of it */

@@ -964,10 +964,16 @@ def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle)
         pat.close()
 
 
-def test_stream_fuzz_long_lines(gpu, capi, oracle):
+@pytest.mark.parametrize("seg", [None, "65536"])
+def test_stream_fuzz_long_lines(gpu, capi, oracle, seg, monkeypatch):
     """Random patterns over long lines (up to 70 000 bytes, many planted hits per line, some with a non-DNA byte or as
-    FASTA records): the long-line variant of k_stream and the window walk of the exact pass against the oracle."""
+    FASTA records): the long-line variant of k_stream and the window walk of the exact pass against the oracle.
+    seg = 65536: the same with 64 KiB segments (lines longer than a segment; with the short patterns nearly every chain
+    reports a hit, the first segment's hit list overflows the default workspace and the run is repeated -- the segments
+    behind an overflowing one must not touch the hit arrays: this configuration once faulted in k_stream_bounds)."""
     from seeq_amd import device as dev
+    if seg:
+        monkeypatch.setenv("SEEQ_SEGMENT_BYTES", seg)         # (read when a scan context is created: _scan makes one per call)
     rng = random.Random(4242)
     seen = {}
     for it in range(12):
