@@ -441,6 +441,48 @@ def test_cli_pipelined_ingest_lanes_and_devices(gpu, capi):
             assert r.returncode == 0 and r.stdout == ref.stdout, (name, args, chunk, lanes, devs, r.stderr[-500:])
 
 
+def test_cli_pipeline_on_a_generated_file(gpu, capi, oracle, tmp_path):
+    """A 6 MB generated file -- reads with planted hits, empty lines, lines of 20 ... 300 KB, foreign bytes -- through the CLI
+    with chunk sizes from smaller than the longest line (the chunk has to grow) to larger than the file, 1-3 lanes and a
+    device list: `-c` and the number of `-b -f` rows against the oracle, every other output byte-identical across the
+    configurations (file order, running line numbers, growth of a chunk, the tail line carried from chunk to chunk)."""
+    rng = random.Random(77)
+    parts = []
+    for i in range(30000):
+        r = rng.random()
+        n = 0 if r < 0.01 else rng.choice([20000, 100000, 300000]) if r < 0.0015 + 0.01 else rng.choice([50, 100, 151, 151, 151, 250])
+        t = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(1 + n // 5000):
+            if n >= 30 and rng.random() < 0.3:
+                c = _mutate(rng, PAT20, rng.randint(0, 5))
+                p = rng.randrange(0, n - len(c) + 1)
+                t[p:p + len(c)] = list(c)
+        if n and rng.random() < 0.01:
+            t[rng.randrange(n)] = rng.choice("N.-X")
+        parts.append("".join(t)[:n])
+    data = ("\n".join(parts) + "\n").encode()
+    path = str(tmp_path / "generated.txt")
+    open(path, "wb").write(data)
+    exp = oracle.buffer_scan(PAT20, 3, data, SQ_BEST)
+    outs = {}
+    for chunk, lanes, devs in (("100000000", "2", None), ("4096", "1", None), ("65536", "3", "0,0"), ("1048576", "2", None), ("300001", "2", "0,0,0")):
+        env = dict(os.environ, SEEQ_CHUNK_BYTES=chunk, SEEQ_LANES=lanes)
+        if devs:
+            env["SEEQ_DEVICES"] = devs
+        for args in (["-c"], ["-b", "-f"], ["-a", "-l", "-p", "-k"], ["-i", "-c"], ["-x", "2", "-b", "-l", "-m"]):
+            r = subprocess.run([capi.CLI_PATH, "-d", "3"] + args + [PAT20, path], capture_output=True, env=env)
+            assert r.returncode == 0, (chunk, lanes, devs, args, r.stderr[-500:])
+            key = " ".join(args)
+            if key in outs:
+                assert r.stdout == outs[key], (chunk, lanes, devs, args)
+            outs[key] = r.stdout
+    assert int(outs["-c"]) == exp["nmatchlines"]
+    rows = outs["-b -f"].decode().splitlines()
+    assert len(rows) == len(exp["records"])
+    assert rows[:50] == ["%d:%d-%d:%d" % (l, s_, e - 1, d) for l, s_, e, d in exp["records"][:50].tolist()]
+    assert rows[-1] == "%d:%d-%d:%d" % tuple([int(exp["records"][-1][0]), int(exp["records"][-1][1]), int(exp["records"][-1][2]) - 1, int(exp["records"][-1][3])])
+
+
 def test_cli_pipe_streams_lines_as_they_arrive(gpu, capi):
     """`producer | seeq PATTERN`: the reference works line by line (getline, seeq.c:361), so a match shows up as soon as its
     line has been written.  The chunked reader must not sit on a pipe until 64 MiB have arrived."""
