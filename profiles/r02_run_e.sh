@@ -1,26 +1,11 @@
-#!/bin/bash
-# Round 2, GPU call e: GPU tests after the lazy-check fix ('U' before a candidate), A/B of overlap / alphabet check on one box, kernel trace.
 set -u
 O=gpurun_out/r02e; mkdir -p $O
-export TMPDIR=/tmp
-timeout -k 10 400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log
-tail -5 $O/pytest_gpu.log
-B="--steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-per-call --check-lines 0"
-timeout -k 10 200 python bench.py $B > $O/bench_best.json 2> $O/bench_best.err; echo "best exit $?"
-SEEQ_STREAM_CHECK=1 timeout -k 10 200 python bench.py $B > $O/bench_best_chk.json 2> $O/bench_best_chk.err; echo "best chk exit $?"
-SEEQ_OVERLAP=0 timeout -k 10 200 python bench.py $B > $O/bench_best_nooverlap.json 2> $O/bench_best_nooverlap.err; echo "no-overlap exit $?"
-SEEQ_OVERLAP=0 SEEQ_STREAM_CHECK=1 timeout -k 10 200 python bench.py $B > $O/bench_best_r1like.json 2> $O/bench_best_r1like.err; echo "r1like exit $?"
-REPO=$PWD; cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/prof_best -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-e2e --no-per-call --no-cpu-baseline --check-lines 0 > $REPO/$O/prof_best.log 2>&1
-cd $REPO
-find $O -name "*.csv" -size +8M -delete
-for f in $O/bench_*.json; do echo "== $f"; python3 - "$f" <<'PY'
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; tail -3 $O/pytest.log; [ $rc = 0 ] || exit 1
+timeout -k 10 200 python bench.py --workload all --no-cpu-baseline --no-e2e --no-per-call > $O/bench_all.json 2> $O/bench_all.err; echo "all exit $?"
+timeout -k 10 400 python bench.py --workload cfg5 --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-per-call > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo "cfg5 exit $?"
+for f in $O/bench_*.json; do python3 - "$f" <<'PY'
 import json,sys
-try:
-    d=json.load(open(sys.argv[1]))
-    print({k:d[k] for k in ("value","ms_per_step")}, d["device_ms_per_step"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"])
-except Exception as e: print("ERR",e)
+d=json.load(open(sys.argv[1]))
+print(sys.argv[1], round(d["value"]/1e9,3), "G lines/s", round(d["ms_per_step"],3), "ms", d["device_ms_per_step"], d["results"].get("oracle_check",{}).get("result"))
 PY
 done
-tail -n 3 $O/*.err
-head -14 $O/prof_best/*/*_kernel_stats.csv | cut -c1-200

@@ -125,9 +125,12 @@ template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st,
 /* OPT: the match option (SQ_FIRST / SQ_BEST / SQ_ALL; SQ_COUNT behaves as SQ_FIRST) as a compile-time constant for
  * the EMIT kernels -- the per-character body then has no option branches; -1 = read it from a.options (COUNT). */
 /* cache (16 B per hit line, the scan kernels' slice buffer, free by now; NULL = off): when records are wanted, the
- * COUNT pass leaves the first two emissions {end, dist} of every line there (for SQ_BEST: the best one, and it then
- * scans the whole line instead of stopping at the first hit), and the EMIT pass only recovers the starts of lines
- * with <= 2 records instead of scanning them again. */
+ * COUNT pass leaves the first four emissions of every line there, each packed as end << 6 | dist (dist <= tau < 62;
+ * an end of 2^26 or more marks the entry unusable: 0xFFFFFFFF in .x) -- for SQ_BEST the best one, and it then
+ * scans the whole line instead of stopping at the first hit -- and the EMIT pass only recovers the starts of lines
+ * with <= 4 records instead of scanning them again: one lane re-scanning a line holds its whole workgroup back for
+ * the length of the line (configs[4]: 0.3 % of the hit lines have 3 or more records -- more than half of the
+ * workgroups held one). */
 /* WALK: compile the window walk in (long-line inputs); without it the per-character loop carries no walk state */
 template <int MODE, int W, int OPT, bool WALK>
 __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
@@ -191,7 +194,8 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
       uint32_t out_cap = 0, line_no = 0;
-      uint32_t c0p = 0, c0d = 0, c1p = 0, c1d = 0, ncached = 0;       /* COUNT: what goes to the cache; EMIT: what came from it */
+      uint32_t ce0 = 0, ce1 = 0, ce2 = 0, ce3 = 0, ncached = 0;       /* COUNT: what goes to the cache; EMIT: what came from it */
+      bool wide = false;                                               /* COUNT: an emission beyond column 2^26 */
       bool from_cache = false;
       if (MODE == SQ_MODE_EMIT && !done) {
          line_no = a.hit_line[k];
@@ -199,11 +203,13 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          else { out = a.records + c->records + (by_nh ? a.nh[k] : k); out_cap = 1; }
          if (cache_ok) {
             ncached = (k + 1 < nhl ? a.nh[k + 1] : c->seg_nrec) - a.nh[k];
-            if (ncached <= 2) {                            /* the COUNT pass has seen every emission of this line */
+            if (ncached <= 4) {                            /* the COUNT pass has seen every emission of this line */
                const uint4 ce = cache[k];
-               c0p = ce.x; c0d = ce.y; c1p = ce.z; c1d = ce.w;
-               from_cache = true;
-               done = true;
+               if (ce.x != 0xFFFFFFFFu) {
+                  ce0 = ce.x; ce1 = ce.y; ce2 = ce.z; ce3 = ce.w;
+                  from_cache = true;
+                  done = true;
+               }
             }
          }
       }
@@ -264,26 +270,21 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                latch = act ? (stop ? true : zero) : latch;
                if (MODE == SQ_MODE_COUNT) {
                   if (caching) {
-                     const bool f0 = emit && nhits == 0, f1 = emit && nhits == 1;
-                     c0p = f0 ? p : c0p; c0d = f0 ? streak : c0d; c1p = f1 ? p : c1p; c1d = f1 ? streak : c1d;
+                     if (__any(emit)) {                       /* (a few times per line) */
+                        const uint32_t pk = (p << 6) | streak;
+                        ce0 = emit && nhits == 0 ? pk : ce0; ce1 = emit && nhits == 1 ? pk : ce1;
+                        ce2 = emit && nhits == 2 ? pk : ce2; ce3 = emit && nhits == 3 ? pk : ce3;
+                        wide = wide || (emit && p >= (1u << 26));
+                     }
                   }
                   nhits += emit ? 1u : 0u;
                   end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */
-               } else if (__any(emit)) {
-                  if (emit) {
-                     if (nhits < out_cap) {
-                        seeqdev_hit_t h;
-                        h.line = line_no;
-                        /* the row is free only when the scan of this line ends here (SQ_FIRST) */
-                        h.start = exact1_reverse<W>(a.text, off, a.nbytes, p, streak, eqr_base, m, tau1, match_opt != SQ_ALL ? row : nullptr);
-                        h.end = p;
-                        h.dist = streak;
-                        out[nhits] = h;
-                        a.rec_off[(out - a.records) + nhits] = off;
-                     }
-                     nhits++;
-                     if (match_opt != SQ_ALL) end = true;               /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */
-                  }
+               } else {
+                  /* EMIT: only {end, dist} into the record slot now; the starts are recovered after the forward scan
+                     (below), when the lane's LDS row is free and the lanes of the wave do it together */
+                  if (emit && nhits < out_cap) { out[nhits].end = p; out[nhits].dist = streak; }
+                  nhits += emit ? 1u : 0u;
+                  end = end || (emit && match_opt != SQ_ALL);           /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */
                }
                streak = act ? cur : streak;
                done = done || (act && end);
@@ -314,27 +315,33 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       }
       if (k < nhl) {
          if (MODE == SQ_MODE_COUNT) {
-            if (count_best) { nhits = best_d < tau1 ? 1u : 0u; c0p = best_end; c0d = best_d; }
+            if (count_best) { nhits = best_d < tau1 ? 1u : 0u; ce0 = (best_end << 6) | (best_d & 63u); wide = best_end >= (1u << 26); }
             a.nh[k] = nhits;
-            if (caching) cache[k] = make_uint4(c0p, c0d, c1p, c1d);
-         } else if (from_cache) {
-            for (uint32_t i = 0; i < ncached; i++) {
+            if (caching) cache[k] = make_uint4(wide ? 0xFFFFFFFFu : ce0, ce1, ce2, ce3);
+         } else if (match_opt == SQ_BEST && !from_cache) {
+            if (best_d < tau1) {
                seeqdev_hit_t h;
                h.line = line_no;
-               h.end = i ? c1p : c0p;
-               h.dist = i ? c1d : c0d;
+               h.start = exact1_reverse<W>(a.text, off, a.nbytes, best_end, best_d, eqr_base, m, tau1, row);
+               h.end = best_end;
+               h.dist = best_d;
+               out[0] = h;
+               a.rec_off[out - a.records] = off;
+            }
+         } else {
+            /* the emissions of this line, from the COUNT pass's cache or from the scan above: recover the starts */
+            const uint32_t n = from_cache ? ncached : (nhits < out_cap ? nhits : out_cap);
+            for (uint32_t i = 0; i < n; i++) {
+               seeqdev_hit_t h;
+               h.line = line_no;
+               if (from_cache) {
+                  const uint32_t pk = i == 0 ? ce0 : i == 1 ? ce1 : i == 2 ? ce2 : ce3;
+                  h.end = pk >> 6; h.dist = pk & 63u;
+               } else { h.end = out[i].end; h.dist = out[i].dist; }     /* (written by this lane, above) */
                h.start = exact1_reverse<W>(a.text, off, a.nbytes, h.end, h.dist, eqr_base, m, tau1, row);
                out[i] = h;
                a.rec_off[(out - a.records) + i] = off;     /* byte offset of the record's line (seeqdevScanCopyOffsets) */
             }
-         } else if (match_opt == SQ_BEST && best_d < tau1) {
-            seeqdev_hit_t h;
-            h.line = line_no;
-            h.start = exact1_reverse<W>(a.text, off, a.nbytes, best_end, best_d, eqr_base, m, tau1, row);
-            h.end = best_end;
-            h.dist = best_d;
-            out[0] = h;
-            a.rec_off[out - a.records] = off;
          }
       }
    }
