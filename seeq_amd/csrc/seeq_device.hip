@@ -95,7 +95,7 @@ struct Counters {
    uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant; 64: a hit entry points outside its segment (a bug: the scan fails) */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
-   uint32_t seg_tmp_hits;   /* (spare) */
+   uint32_t seg_novf;       /* k_exact1: 1 when a wave's overflow list (emissions beyond the first of their lines, COUNT -> EMIT) did not fit */
    uint32_t seg_nmatch;     /* lines of the segment with >= 1 verified hit (superset filters) */
    uint32_t dirty;          /* k_stream: the text holds bytes outside {ACGTN, acgtn, '\n'}: its hit lines need verifying */
    uint64_t need_records;   /* total */
@@ -533,7 +533,7 @@ __global__ void k_seg_end(ScanArgs a, int flags /* 1: hits come from nh[]; 2: nh
    if (a.use_nh == 3 && c->seg_nhitlines) c->prev_hit_line = a.hit_line[c->seg_nhitlines - 1];
    c->hits += seg_hits;
    if (a.want == SEEQDEV_WANT_RECORDS) c->records += seg_hits;
-   c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = c->seg_nmatch = 0;
+   c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = c->seg_nmatch = c->seg_novf = 0;
 }
 
 /* SINGLELINE: the buffer is one string -> one line starting at 0. */

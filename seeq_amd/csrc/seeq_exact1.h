@@ -11,6 +11,8 @@
 #define SEEQ_EXACT1_H_
 
 #define EXACT1_ROW 80          /* LDS bytes per lane: 64 text bytes + pad, 16-byte aligned */
+typedef __attribute__((address_space(3))) uint8_t exact1_lds_u8;
+typedef __attribute__((address_space(3))) const uint8_t exact1_lds_cu8;
 
 /* Reverse start recovery, reference libseeq.c:289-316, on the reversed-pattern EQ table.  `text + off` is
  * the line, i the column the match ends before.  With `row` (the lane's 64-byte LDS row, free at that
@@ -21,10 +23,11 @@ __device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *text, uint64_t
                                                    uint32_t eqr_base, uint32_t m, uint32_t tau1, uint8_t *row)
 {
    const uint8_t *line = text + off;
-   uint64_t base = ~(uint64_t)0;                          /* absolute offset of row[0]; none */
+   uint32_t lim = 0;                                      /* the row holds the `lim` bytes before the match end */
    if (row) {
       const uint64_t end = off + i;
-      base = end >= 64 ? end - 64 : 0;
+      const uint64_t base = end >= 64 ? end - 64 : 0;
+      lim = (uint32_t)(end - base);
 #pragma unroll
       for (int q = 0; q < 4; q++)
          *reinterpret_cast<fused_v4u *>(row + 16 * q) = direct_load16(text, base + 16 * q, nbytes);
@@ -34,8 +37,10 @@ __device__ __forceinline__ uint32_t exact1_reverse(const uint8_t *text, uint64_t
    uint32_t j = 0, d = tau1, last_d, ignores = 0;
    do {
       ++j;
-      const uint64_t at = off + (i - j);
-      const uint32_t b = at >= base ? (uint32_t)row[at - base] : (uint32_t)line[i - j];
+      uint32_t b;
+      /* (an LDS load and a global load: through one selected generic pointer it would be a flat load, per step) */
+      if (j <= lim) b = (uint32_t)*(exact1_lds_cu8 *)(uintptr_t)((uint32_t)(uintptr_t)(exact1_lds_u8 *)row + lim - j);
+      else b = (uint32_t)line[i - j];
       const fused_eq_t<W> ev = fused_eq_load<W>(eqr_base + (b << (W == 1 ? 2 : 3)));
       const uint32_t e = ev.w0;
       last_d = d;
@@ -125,12 +130,16 @@ template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st,
 /* OPT: the match option (SQ_FIRST / SQ_BEST / SQ_ALL; SQ_COUNT behaves as SQ_FIRST) as a compile-time constant for
  * the EMIT kernels -- the per-character body then has no option branches; -1 = read it from a.options (COUNT). */
 /* cache (16 B per hit line, the scan kernels' slice buffer, free by now; NULL = off): when records are wanted, the
- * COUNT pass leaves the first four emissions of every line there, each packed as end << 6 | dist (dist <= tau < 62;
- * an end of 2^26 or more marks the entry unusable: 0xFFFFFFFF in .x) -- for SQ_BEST the best one, and it then
- * scans the whole line instead of stopping at the first hit -- and the EMIT pass only recovers the starts of lines
- * with <= 4 records instead of scanning them again: one lane re-scanning a line holds its whole workgroup back for
- * the length of the line (configs[4]: 0.3 % of the hit lines have 3 or more records -- more than half of the
- * workgroups held one). */
+ * COUNT pass leaves {end, dist} of the FIRST emission of every line there (for SQ_BEST the best one, and COUNT then
+ * scans the whole line instead of stopping at the first hit).  Further emissions of a line (SQ_ALL: 7 % of the hit
+ * lines of configs[4] have a second one) go to overflow lists {hit-list entry, index in the line, end, dist} in the
+ * free entries above the per-line ones: ONE LIST PER WAVE of the grid (entry 0 of a wave's region = its count),
+ * filled through a counter in LDS -- no global atomics (a single global counter, even with one atomic per wave,
+ * cost 85-165 us per launch: same-address atomics serialise at ~10 ns each).  The EMIT pass (same grid) recovers
+ * the start of every line's first record and then, wave by wave, of its own overflow list, one emission per lane:
+ * no line is scanned twice and no lane scans a line alone while its workgroup waits (a single lane takes 0.3 us per
+ * character: with a cache of two emissions per line and re-scans for the rest, that tail was most of the pass).
+ * Only when a region is too small (Counters.seg_novf set) does EMIT scan the lines with more than one record again. */
 /* WALK: compile the window walk in (long-line inputs); without it the per-character loop carries no walk state */
 template <int MODE, int W, int OPT, bool WALK>
 __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
@@ -138,6 +147,8 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
    __shared__ __align__(8) uint32_t s_eqf[256 * W];
    __shared__ __align__(8) uint32_t s_eqr[256 * W];
    __shared__ __align__(16) uint8_t s_blk[256 * EXACT1_ROW];
+   __shared__ uint32_t s_novf[4];                          /* COUNT: entries in each wave's overflow list */
+   if (threadIdx.x < 4) s_novf[threadIdx.x] = 0;
    for (int i = threadIdx.x; i < 256 * W; i += 256) { s_eqf[i] = eq2[i]; s_eqr[i] = eq2[256 * W + i]; }
    __syncthreads();
    const uint32_t eqf_base = (uint32_t)(uintptr_t)(fused_lds_cu32 *)s_eqf;
@@ -153,7 +164,16 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
    const bool caching = MODE == SQ_MODE_COUNT && cache != nullptr && a.want == SEEQDEV_WANT_RECORDS;
    const bool count_best = caching && match_opt == SQ_BEST;
    const bool cache_ok = MODE == SQ_MODE_EMIT && cache != nullptr && by_nh && !(trusted && count_any);
+   /* overflow lists: the free entries above the per-line ones, split evenly over the waves of the grid (COUNT and EMIT
+      are launched with the same grid) */
+   const uint32_t ovf_r = (a.cap_hitlines > nhl ? a.cap_hitlines - nhl : 0u) / (gridDim.x * 4u);   /* entries per wave, the count included */
+   const uint32_t wave_id = threadIdx.x >> 6;
+   uint4 *ovf = cache ? cache + nhl + (size_t)(blockIdx.x * 4u + wave_id) * ovf_r : nullptr;
+   const bool ovf_lost = MODE == SQ_MODE_EMIT && c->seg_novf != 0;               /* (EMIT: the lists are complete or they are not used) */
    const bool walk = WALK && a.use_nh == 3 && hit_col != nullptr && a.stream_ch != 0;     /* window walk (below); kernel-uniform */
+   /* no byte is skipped under these options: a flagged byte ends the line, so the column of a lane needs no protecting
+      from it (nothing reads the column of a finished line) -- the per-character bodies below drop the predicated copy */
+   const bool noskip = (a.options & (SQ_IGNORE | SQ_STREAM)) == 0;
    uint8_t *row = s_blk + threadIdx.x * EXACT1_ROW;
    const uint32_t stride = gridDim.x * 256;
    /* wave-uniform trip count so that every lane of a wave takes part in the wave-level votes */
@@ -194,8 +214,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
       uint32_t out_cap = 0, line_no = 0;
-      uint32_t ce0 = 0, ce1 = 0, ce2 = 0, ce3 = 0, ncached = 0;       /* COUNT: what goes to the cache; EMIT: what came from it */
-      bool wide = false;                                               /* COUNT: an emission beyond column 2^26 */
+      uint32_t ce0 = 0, ce1 = 0, ncached = 0;                         /* {end, dist} of the first emission -- COUNT: what goes to the cache; EMIT: what came from it */
       bool from_cache = false;
       if (MODE == SQ_MODE_EMIT && !done) {
          line_no = a.hit_line[k];
@@ -203,13 +222,10 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          else { out = a.records + c->records + (by_nh ? a.nh[k] : k); out_cap = 1; }
          if (cache_ok) {
             ncached = (k + 1 < nhl ? a.nh[k + 1] : c->seg_nrec) - a.nh[k];
-            if (ncached <= 4) {                            /* the COUNT pass has seen every emission of this line */
-               const uint4 ce = cache[k];
-               if (ce.x != 0xFFFFFFFFu) {
-                  ce0 = ce.x; ce1 = ce.y; ce2 = ce.z; ce3 = ce.w;
-                  from_cache = true;
-                  done = true;
-               }
+            if (ncached <= 1 || !ovf_lost) {               /* the first record from the cache, the others from the overflow list */
+               if (ncached) { const uint4 ce = cache[k]; ce0 = ce.x; ce1 = ce.y; }
+               from_cache = true;
+               done = true;
             }
          }
       }
@@ -234,6 +250,22 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                   No latch is needed: an emission the latch suppresses never beats best_d -- after a rise from s,
                   best_d <= s already (by induction over consecutive rises), and after a zero-distance emission
                   best_d = 0.  A finished lane is fed the line-end flag: that step is idempotent. */
+               if (noskip) {
+#pragma unroll
+                  for (int cc = 0; cc < 4; cc++) {
+                     const bool term = done || (ev[cc].w0 & FUSED_FLAG_TERM) != 0;
+                     st.step(ev[cc]);
+                     const uint32_t sc = st.score < tau1 ? st.score : tau1;
+                     const uint32_t cur = term ? tau1 : sc;
+                     const bool upd = streak < best_d && (streak < cur || streak == 0);
+                     best_d = upd ? streak : best_d;
+                     best_end = upd ? pos + t4 + cc : best_end;
+                     if (walk) lastsub = cur < tau1 ? (int32_t)(pos + t4 + cc) : lastsub;
+                     streak = cur;
+                     done = term;
+                  }
+                  continue;
+               }
 #pragma unroll
                for (int cc = 0; cc < 4; cc++) {
                   const uint32_t e = done ? FUSED_FLAG_TERM : ev[cc].w0;
@@ -252,43 +284,51 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                }
                continue;
             }
-#pragma unroll
-            for (int cc = 0; cc < 4; cc++) {
-               const uint32_t e = ev[cc].w0;
-               const bool term = (e & FUSED_FLAG_TERM) != 0;
-               const bool act = !done && !(e & FUSED_FLAG_SKIP);
-               fused_state_t<W> s2 = st;
-               s2.step(ev[cc]);
-               exact1_take<W>(st, s2, act && !term);
-               const uint32_t sc = s2.score < tau1 ? s2.score : tau1;
-               const uint32_t cur = term ? tau1 : sc;
-               const bool stop = streak < cur, zero = streak == 0;
-               const uint32_t p = pos + t4 + cc;
-               if (walk) lastsub = act && cur < tau1 ? (int32_t)p : lastsub;
-               bool end = term;
-               const bool emit = act && (stop ? !latch : zero);
-               latch = act ? (stop ? true : zero) : latch;
-               if (MODE == SQ_MODE_COUNT) {
-                  if (caching) {
-                     if (__any(emit)) {                       /* (a few times per line) */
-                        const uint32_t pk = (p << 6) | streak;
-                        ce0 = emit && nhits == 0 ? pk : ce0; ce1 = emit && nhits == 1 ? pk : ce1;
-                        ce2 = emit && nhits == 2 ? pk : ce2; ce3 = emit && nhits == 3 ? pk : ce3;
-                        wide = wide || (emit && p >= (1u << 26));
-                     }
-                  }
-                  nhits += emit ? 1u : 0u;
-                  end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */
-               } else {
-                  /* EMIT: only {end, dist} into the record slot now; the starts are recovered after the forward scan
-                     (below), when the lane's LDS row is free and the lanes of the wave do it together */
-                  if (emit && nhits < out_cap) { out[nhits].end = p; out[nhits].dist = streak; }
-                  nhits += emit ? 1u : 0u;
-                  end = end || (emit && match_opt != SQ_ALL);           /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */
-               }
-               streak = act ? cur : streak;
-               done = done || (act && end);
+            /* SQ_FIRST / SQ_ALL / counting: the acceptance rules of libseeq.c:277-331 per character.  NS (no byte is
+               skipped, see `noskip`): the column is stepped in place and a finished lane's bookkeeping runs on unprotected --
+               `act` keeps it from emitting, nothing else of it is read again. */
+#define EXACT1_CHARS4(NS) \
+            _Pragma("unroll") \
+            for (int cc = 0; cc < 4; cc++) { \
+               const uint32_t e = ev[cc].w0; \
+               const bool term = (e & FUSED_FLAG_TERM) != 0; \
+               const bool act = NS ? !done : (!done && !(e & FUSED_FLAG_SKIP)); \
+               uint32_t score; \
+               if (NS) { st.step(ev[cc]); score = st.score; } \
+               else { fused_state_t<W> s2 = st; s2.step(ev[cc]); exact1_take<W>(st, s2, act && !term); score = s2.score; } \
+               const uint32_t sc = score < tau1 ? score : tau1; \
+               const uint32_t cur = term ? tau1 : sc; \
+               const bool stop = streak < cur, zero = streak == 0; \
+               const uint32_t p = pos + t4 + cc; \
+               if (walk) lastsub = (NS || act) && cur < tau1 ? (int32_t)p : lastsub; \
+               bool end = term; \
+               const bool emit = act && (stop ? !latch : zero); \
+               latch = (NS || act) ? (stop ? true : zero) : latch; \
+               if (MODE == SQ_MODE_COUNT) { \
+                  if (caching) { \
+                     if (__any(emit)) {                       /* (a few times per line) */ \
+                        const bool f0 = emit && nhits == 0; \
+                        ce0 = f0 ? p : ce0; ce1 = f0 ? streak : ce1; \
+                        if (emit && nhits >= 1) {             /* second and later: to my wave's overflow list */ \
+                           const uint32_t idx = atomicAdd(&s_novf[wave_id], 1u) + 1u; \
+                           if (idx < ovf_r) ovf[idx] = make_uint4(k, nhits, p, streak); \
+                        } \
+                     } \
+                  } \
+                  nhits += emit ? 1u : 0u; \
+                  end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */ \
+               } else { \
+                  /* EMIT: only {end, dist} into the record slot now; the starts are recovered after the forward scan \
+                     (below), when the lane's LDS row is free and the lanes of the wave do it together */ \
+                  if (emit && nhits < out_cap) { out[nhits].end = p; out[nhits].dist = streak; } \
+                  nhits += emit ? 1u : 0u; \
+                  end = end || (emit && match_opt != SQ_ALL);           /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */ \
+               } \
+               streak = (NS || act) ? cur : streak; \
+               done = done || ((NS || act) && end); \
             }
+            if (noskip) { EXACT1_CHARS4(true) } else { EXACT1_CHARS4(false) }
+#undef EXACT1_CHARS4
          }
          pos += 64;
          if (walk && win && !done) {
@@ -315,9 +355,9 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       }
       if (k < nhl) {
          if (MODE == SQ_MODE_COUNT) {
-            if (count_best) { nhits = best_d < tau1 ? 1u : 0u; ce0 = (best_end << 6) | (best_d & 63u); wide = best_end >= (1u << 26); }
+            if (count_best) { nhits = best_d < tau1 ? 1u : 0u; ce0 = best_end; ce1 = best_d; }
             a.nh[k] = nhits;
-            if (caching) cache[k] = make_uint4(wide ? 0xFFFFFFFFu : ce0, ce1, ce2, ce3);
+            if (caching) cache[k] = make_uint4(ce0, ce1, 0u, 0u);
          } else if (match_opt == SQ_BEST && !from_cache) {
             if (best_d < tau1) {
                seeqdev_hit_t h;
@@ -329,20 +369,42 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                a.rec_off[out - a.records] = off;
             }
          } else {
-            /* the emissions of this line, from the COUNT pass's cache or from the scan above: recover the starts */
-            const uint32_t n = from_cache ? ncached : (nhits < out_cap ? nhits : out_cap);
+            /* the first record whole from the COUNT pass's cache (the others: the overflow list, below), or the
+               emissions of the scan above -- then recover the starts */
+            const uint32_t n = from_cache ? (ncached ? 1u : 0u) : (nhits < out_cap ? nhits : out_cap);
             for (uint32_t i = 0; i < n; i++) {
                seeqdev_hit_t h;
                h.line = line_no;
-               if (from_cache) {
-                  const uint32_t pk = i == 0 ? ce0 : i == 1 ? ce1 : i == 2 ? ce2 : ce3;
-                  h.end = pk >> 6; h.dist = pk & 63u;
-               } else { h.end = out[i].end; h.dist = out[i].dist; }     /* (written by this lane, above) */
+               if (from_cache) { h.end = ce0; h.dist = ce1; }
+               else { h.end = out[i].end; h.dist = out[i].dist; }      /* (written by this lane, above) */
                h.start = exact1_reverse<W>(a.text, off, a.nbytes, h.end, h.dist, eqr_base, m, tau1, row);
                out[i] = h;
                a.rec_off[(out - a.records) + i] = off;     /* byte offset of the record's line (seeqdevScanCopyOffsets) */
             }
          }
+      }
+   }
+   /* COUNT: publish the length of my wave's overflow list */
+   if (MODE == SQ_MODE_COUNT && caching && ovf_r && (threadIdx.x & 63u) == 0) {
+      const uint32_t n = s_novf[wave_id];                  /* (this wave's own LDS atomics: in program order) */
+      ovf[0] = make_uint4(n, 0u, 0u, 0u);
+      if (n + 1u > ovf_r) a.cnt->seg_novf = 1u;            /* it did not fit: EMIT scans again */
+   }
+   if (MODE == SQ_MODE_COUNT && caching && !ovf_r && (threadIdx.x & 63u) == 0 && s_novf[wave_id]) a.cnt->seg_novf = 1u;
+   /* EMIT: the emissions beyond the first of their lines, one per lane */
+   if (MODE == SQ_MODE_EMIT && cache_ok && !ovf_lost && ovf_r) {
+      const uint32_t novf = ovf[0].x;
+      for (uint32_t e = 1u + (threadIdx.x & 63u); e <= novf; e += 64u) {
+         const uint4 o = ovf[e];                                    /* {hit-list entry, index in the line, end, dist} */
+         const uint64_t off = a.seg_base + a.hit_start[o.x];
+         const uint64_t slot = c->records + a.nh[o.x] + o.y;
+         seeqdev_hit_t h;
+         h.line = a.hit_line[o.x];
+         h.start = exact1_reverse<W>(a.text, off, a.nbytes, o.z, o.w, eqr_base, m, tau1, row);
+         h.end = o.z;
+         h.dist = o.w;
+         a.records[slot] = h;
+         a.rec_off[slot] = off;
       }
    }
 }

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       c->seg_nhitlines = hits;
       c->seg_nrec = hits;                                   /* (k_seg_mid's job; the slices cannot hold more than cap_hitlines) */
       if (hits > c->need_hitlines) c->need_hitlines = hits;
-      c->seg_tmp_hits = 0;
+      c->seg_novf = 0;
       lastnl = 0;
       for (int k = 0; k < 4; k++) lastnl = s_last[k] > lastnl ? s_last[k] : lastnl;
       c->seg_last_nl = lastnl;
