@@ -134,7 +134,7 @@ struct ScanArgs {
    uint32_t       stream_ntiles, stream_tile_bytes;
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
-   uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: max(32, m + tau - 1) */
+   uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: m + tau - 1 */
    Counters      *cnt;
 };
 
@@ -1289,7 +1289,7 @@ static int run_segments(seeqdev_scan *s)
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
       a.use_nh = need_nh ? (use_stream ? 3u : 1u) : 0u;
       a.filter = filter ? 1u : 0u;
-      a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1 > 32 ? pat->wlen + pat->tau - 1 : 32);
+      a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1);
       a.cnt = c;
 
       if (use_fused) {

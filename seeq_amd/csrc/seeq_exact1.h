@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          /* nothing ends the line before the first candidate (clean text), so the scan may start just before it: no
             occurrence ends before `col` (a filter: every occurrence contains a part that ends at or after the first
             candidate), and a column started skip_back >= m + tau - 1 bytes earlier has the line's own scores from there */
-         if (col > a.skip_back && (trusted || exact1_clean(a, off, off + col - a.skip_back))) pos = col - a.skip_back;
+         /* (not trusted: no byte outside the alphabet up to the candidate itself -- a skipped byte inside the warm-up
+            columns, SQ_IGNORE, would leave the fresh column short of real characters) */
+         if (col > a.skip_back && (trusted || exact1_clean(a, off, off + col))) pos = col - a.skip_back;
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
@@ -251,19 +253,22 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                   best_d <= s already (by induction over consecutive rises), and after a zero-distance emission
                   best_d = 0.  A finished lane is fed the line-end flag: that step is idempotent. */
                if (noskip) {
+                  /* (flags as integers and bitwise logic: with `||` the compiler builds exec-masked regions per
+                     character just to let finished lanes skip the wait for their EQ word) */
+                  uint32_t dn = done ? 1u : 0u;
 #pragma unroll
                   for (int cc = 0; cc < 4; cc++) {
-                     const bool term = done || (ev[cc].w0 & FUSED_FLAG_TERM) != 0;
+                     dn |= ev[cc].w0 & FUSED_FLAG_TERM;
                      st.step(ev[cc]);
                      const uint32_t sc = st.score < tau1 ? st.score : tau1;
-                     const uint32_t cur = term ? tau1 : sc;
-                     const bool upd = streak < best_d && (streak < cur || streak == 0);
+                     const uint32_t cur = dn ? tau1 : sc;
+                     const bool upd = (streak < best_d) & ((streak < cur) | (streak == 0));
                      best_d = upd ? streak : best_d;
                      best_end = upd ? pos + t4 + cc : best_end;
                      if (walk) lastsub = cur < tau1 ? (int32_t)(pos + t4 + cc) : lastsub;
                      streak = cur;
-                     done = term;
                   }
+                  done = dn != 0;
                   continue;
                }
 #pragma unroll
@@ -292,22 +297,22 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
             for (int cc = 0; cc < 4; cc++) { \
                const uint32_t e = ev[cc].w0; \
                const bool term = (e & FUSED_FLAG_TERM) != 0; \
-               const bool act = NS ? !done : (!done && !(e & FUSED_FLAG_SKIP)); \
+               const bool act = NS ? !done : (!done & !(e & FUSED_FLAG_SKIP)); \
                uint32_t score; \
                if (NS) { st.step(ev[cc]); score = st.score; } \
-               else { fused_state_t<W> s2 = st; s2.step(ev[cc]); exact1_take<W>(st, s2, act && !term); score = s2.score; } \
+               else { fused_state_t<W> s2 = st; s2.step(ev[cc]); exact1_take<W>(st, s2, act & !term); score = s2.score; } \
                const uint32_t sc = score < tau1 ? score : tau1; \
                const uint32_t cur = term ? tau1 : sc; \
                const bool stop = streak < cur, zero = streak == 0; \
                const uint32_t p = pos + t4 + cc; \
-               if (walk) lastsub = (NS || act) && cur < tau1 ? (int32_t)p : lastsub; \
+               if (walk) lastsub = ((NS || act) & (cur < tau1)) ? (int32_t)p : lastsub; \
                bool end = term; \
-               const bool emit = act && (stop ? !latch : zero); \
+               const bool emit = act & (stop ? !latch : zero); \
                latch = (NS || act) ? (stop ? true : zero) : latch; \
                if (MODE == SQ_MODE_COUNT) { \
                   if (caching) { \
                      if (__any(emit)) {                       /* (a few times per line) */ \
-                        const bool f0 = emit && nhits == 0; \
+                        const bool f0 = emit & (nhits == 0); \
                         ce0 = f0 ? p : ce0; ce1 = f0 ? streak : ce1; \
                         if (emit && nhits >= 1) {             /* second and later: to my wave's overflow list */ \
                            const uint32_t idx = atomicAdd(&s_novf[wave_id], 1u) + 1u; \
@@ -316,16 +321,16 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                      } \
                   } \
                   nhits += emit ? 1u : 0u; \
-                  end = end || (count_any && emit);        /* presence is enough: FIRST/BEST/COUNTLINES */ \
+                  end = end | (count_any & emit);        /* presence is enough: FIRST/BEST/COUNTLINES */ \
                } else { \
                   /* EMIT: only {end, dist} into the record slot now; the starts are recovered after the forward scan \
                      (below), when the lane's LDS row is free and the lanes of the wave do it together */ \
                   if (emit && nhits < out_cap) { out[nhits].end = p; out[nhits].dist = streak; } \
                   nhits += emit ? 1u : 0u; \
-                  end = end || (emit && match_opt != SQ_ALL);           /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */ \
+                  end = end | (emit & (match_opt != SQ_ALL));           /* SQ_FIRST / SQ_COUNT: libseeq.c:330 */ \
                } \
                streak = (NS || act) ? cur : streak; \
-               done = done || ((NS || act) && end); \
+               done = done | ((NS || act) & end); \
             }
             if (noskip) { EXACT1_CHARS4(true) } else { EXACT1_CHARS4(false) }
 #undef EXACT1_CHARS4

@@ -1174,3 +1174,49 @@ def test_filter_automaton_patterns(gpu, capi, oracle):
         if ci in (0, 1, 3):        # (the 20-mer at distance 4 only has a filter of 10-mers with 2 errors: not selective -> k_direct)
             assert got["kernel"] == "k_stream" and got["filter"], (pattern, tau, got["kernel"])
     assert nfilter >= 15, nfilter
+
+
+def test_all_mode_many_records_per_line(gpu, capi, oracle):
+    """SQ_ALL with several / very many records per line: the exact pass keeps a line's first emission per hit line and
+    parks the others in per-wave overflow lists (seeq_exact1.h); lines with hundreds of emissions (low-complexity text:
+    one record per position) do not fit them and take the re-scan path.  Records in order, bit-exact, for a complete
+    automaton, a filter automaton and the per-line kernel, also with FASTA headers and under SQ_IGNORE / SQ_CONVERT."""
+    from seeq_amd import device as dev
+    rng = random.Random(777)
+    core40 = "GATGTAGCACGATTAGCCTGAAAATGAGAGTACGGCGCGA"
+    for ci, (pattern, tau, unit) in enumerate([(PAT20, 3, PAT20), ("AAAAAAAA", 1, "A" * 40), (PAT40, 5, core40),
+                                               ("ACACACACAC", 2, "AC" * 30)]):
+        for dense in (False, True):
+            lines = []
+            for i in range(4000):
+                n = rng.choice([60, 150, 250, 300])
+                t = "".join(rng.choice("ACGT") for _ in range(n))
+                k = (i % 7) if not dense else (i % 3) * 3
+                if i % 2 == 0:
+                    q = 0
+                    for _ in range(k):                       # k copies of the unit, a few random characters apart
+                        if q + len(unit) > n:
+                            break
+                        t = t[:q] + unit + t[q + len(unit):]
+                        q += len(unit) + rng.randint(1, 12)
+                if dense and i % 5 == 0:
+                    t = (unit * 8)[:n]                       # an emission at (nearly) every position
+                if ci == 1 and i % 31 == 0:
+                    t = t[:n // 2] + "#!" + t[n // 2 + 2:]
+                lines.append(t[:n])
+            buf = ("\n".join(lines) + "\n").encode()
+            for opt in (SQ_ALL, SQ_ALL | SQ_IGNORE, SQ_ALL | SQ_CONVERT):
+                if opt != SQ_ALL and ci != 1:
+                    continue
+                exp = oracle.buffer_scan(pattern, tau, buf, opt)
+                for path in ("auto", "fused"):
+                    got = _scan(capi, pattern, tau, buf, opt, dev.WANT_RECORDS, False, path)
+                    assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, dense, opt, path)
+                    assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, dense, opt, path)
+                cm = _scan(capi, pattern, tau, buf, opt & ~3, dev.WANT_COUNTMATCH)
+                assert cm["nhits"] == len(exp["records"]), (pattern, dense, opt)
+            if ci == 0:
+                fa = (">hdr one\n" + "\n".join(lines[:1500]) + "\n>hdr two GATGTAGCGCGATTAGCCTG\n" + "\n".join(lines[1500:3000]) + "\n").encode()
+                exp = oracle.buffer_scan(pattern, tau, fa, SQ_ALL, fasta=True)
+                got = _scan(capi, pattern, tau, fa, SQ_ALL, dev.WANT_RECORDS, True)
+                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, dense, "fasta")
