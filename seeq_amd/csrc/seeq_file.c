@@ -22,6 +22,7 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <poll.h>
 #include <pthread.h>
 #include <sys/stat.h>
 
@@ -327,6 +328,10 @@ static void *reader_main(void *arg)
             const int waiting = s->waiting;
             pthread_mutex_unlock(&s->mu);
             if (waiting) break;
+            /* nobody waits yet -- but the caller may start to while this thread sleeps in read(2) with complete lines in
+               hand (then nobody would ever hand them over): read on only while the producer keeps delivering */
+            struct pollfd pf = { fileno(s->fdi), POLLIN, 0 };
+            if (poll(&pf, 1, 2) == 0) break;
          }
       }
       sl->avail = eof ? sl->len : nl_end;
