@@ -176,13 +176,18 @@ class SeeqObject:
         device scan (seeqdevScanHost over the newline-joined strings) instead of one GPU round trip per
         string."""
         from . import device as dev
-        data = [_utf8(x) for x in strings]
-        for b in data:
-            if b"\n" in b:
-                raise ValueError("batched matching takes one string per line: no embedded newlines")
-        if not data:
+        strings = list(strings)
+        if not strings:
             return []
-        buf = b"\n".join(data) + b"\n"
+        try:                                      # one join + one encode for the whole batch (per-string work is what
+            buf = ("\n".join(strings) + "\n").encode("utf-8")      # costs here: the device scan takes a fraction of a ms)
+        except TypeError:
+            raise TypeError("a str is required") from None
+        if b"\0" in buf:
+            raise ValueError("embedded null character")
+        if buf.count(b"\n") != len(strings):
+            raise ValueError("batched matching takes one string per line: no embedded newlines")
+        data = strings
         if not hasattr(self, "_scanner"):
             self._scanner = dev.Scanner()
             self._devpat = type("P", (), {"handle": self._lib.seeqdevPatternOf(self._sq)})()
