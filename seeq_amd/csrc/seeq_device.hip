@@ -1693,11 +1693,18 @@ extern "C" int seeqdevScanLastLaunches(const seeqdev_scan_t *s) { return s ? (in
 /* ========================================================================== */
 /* The per-string entry point is what the reference's Python module calls for every string (seeqmodule.c:858).  One
  * workgroup: all threads stage the string (read over the link from page-locked host memory when it is short, else
- * from HBM) and the tables into LDS, then one lane runs the line scan -- forward column, acceptance rules, reverse
- * start recovery -- and writes count + records straight into page-locked host memory.  One launch, one stream
- * synchronisation, no device allocation.  Long strings in line mode take the batched scan instead (libseeq_api.c). */
+ * from HBM) and the tables into LDS; then the string's positions are shared out over the 256 threads: every thread
+ * computes the capped scores of its positions from a fresh column started m + tau + 1 characters earlier (exact from
+ * there on, as in k_stream), applies the acceptance rules -- which only look at the scores of a position and the two
+ * before it (libseeq.c:277-331: emit = stop ? !latch : zero, latch = stop ? 1 : zero) -- and the emissions are compacted
+ * in order (block scan) / reduced (first, best), starts recovered by their threads, count + records written straight
+ * into page-locked host memory.  A single lane walking the string took 0.17 us per character (41 us per call at 150
+ * characters, 15 of them launch + synchronisation).  Strings with skipped bytes (SQ_IGNORE, SQ_STREAM) or longer than
+ * STRING_PAR_MAX keep the one-lane scan.  One launch, one stream synchronisation, no device allocation.  Long strings
+ * in line mode take the batched scan instead (libseeq_api.c). */
 static constexpr uint32_t STRING_LDS_MAX = 48u * 1024;      /* strings up to this are staged in LDS */
 static constexpr uint32_t STRING_ZC_MAX = 4096;             /* ... and up to this read straight from host memory */
+static constexpr uint32_t STRING_PAR_MAX = 8192;            /* ... and up to this scanned by all threads (positions fit 14 bits) */
 
 template <int W>
 __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, const uint32_t *peq, int m, int tau, int options,
@@ -1720,7 +1727,89 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
          *reinterpret_cast<uint4 *>(s_text + o) = make_uint4(c.w[0], c.w[1], c.w[2], c.w[3]);
       }
    }
+   __shared__ uint32_t s_first, s_skip, s_key, s_wave[WG / 64];
+   const bool par = n <= STRING_PAR_MAX;                  /* (=> staged) */
+   if (threadIdx.x == 0) { s_first = n; s_skip = 0; s_key = 0xFFFFFFFFu; }
    __syncthreads();
+   if (par) {
+      /* the line ends at its first terminator (or at n: bytes beyond read as NUL); a skipped byte before it -> one lane */
+      for (uint32_t j = threadIdx.x; j < n; j += WG) if (s_lut[s_text[j]] == SQC_TERM) atomicMin(&s_first, j);
+      __syncthreads();
+      const uint32_t len = s_first;
+      for (uint32_t j = threadIdx.x; j < len; j += WG) if (s_lut[s_text[j]] == SQC_SKIP) s_skip = 1u;
+      __syncthreads();
+      if (!s_skip) {
+         const int tau1 = tau + 1, topw = (m - 1) >> 5, topbit = (m - 1) & 31;
+         const int match_opt = options & 3;
+         const uint32_t *peq_f = s_peq, *peq_r = s_peq + 5 * W;
+         uint16_t *ed = reinterpret_cast<uint16_t *>(s_text + (((size_t)n + 31) & ~(size_t)15));   /* per position: emitted distance + 1, or 0 */
+         const uint32_t P = len + 1;                      /* positions 0..len; the last one is the terminator's step */
+         const uint32_t B = (P + WG - 1) / WG;
+         const uint32_t j0 = threadIdx.x * B, j1 = j0 + B < P ? j0 + B : P;
+         uint32_t cnt = 0;
+         if (j0 < P) {
+            long start = (long)j0 - 2 - (long)(m + tau - 1);
+            if (start < 0) start = 0;
+            sq_myers_t<W> st;
+            sq_myers_init<W>(st, m);
+            int s2 = tau1, s1 = tau1;                     /* capped scores of the two positions before j */
+            for (long j = start; j < (long)j1; j++) {
+               int cur = tau1;
+               if ((uint32_t)j < len) {
+                  sq_myers_step<W>(st, &peq_f[(uint32_t)s_lut[s_text[j]] * W], topw, topbit);
+                  cur = st.score < tau1 ? st.score : tau1;
+               }
+               if (j >= (long)j0) {
+                  const bool latch = s2 < s1 ? true : s2 == 0;          /* what the step before left (false at the line start) */
+                  const bool stop = s1 < cur, zero = s1 == 0;
+                  const bool emit = stop ? !latch : zero;
+                  ed[j] = emit ? (uint16_t)(s1 + 1) : (uint16_t)0;
+                  cnt += emit ? 1u : 0u;
+               }
+               s2 = s1; s1 = cur;
+            }
+         }
+         uint32_t total = 0;
+         const uint32_t excl = block_excl_scan(cnt, &total, s_wave);      /* (also orders the ed[] writes: barrier inside) */
+         sq_hit_t *rec = reinterpret_cast<sq_hit_t *>(out + 4);
+         if (match_opt == SQK_ALL) {
+            uint32_t idx = excl;
+            for (uint32_t j = j0; j < j1 && cnt; j++) {
+               if (!ed[j]) continue;
+               if (idx < cap) {
+                  sq_hit_t h;
+                  h.line = 1;
+                  h.start = sq_reverse_start<W>((const uint8_t *)s_text, j, (int)ed[j] - 1, peq_r, (const uint8_t *)s_lut, m, tau);
+                  h.end = j;
+                  h.dist = (uint32_t)ed[j] - 1u;
+                  rec[idx] = h;
+               }
+               idx++;
+            }
+            if (threadIdx.x == 0) out[0] = total;
+         } else {
+            /* SQ_BEST: smallest distance, first position; SQ_FIRST / SQ_COUNT: first position */
+            for (uint32_t j = j0; j < j1 && cnt; j++)
+               if (ed[j]) { atomicMin(&s_key, (match_opt == SQK_BEST ? ((uint32_t)ed[j] - 1u) << 14 : 0u) | j); if (match_opt != SQK_BEST) break; }
+            __syncthreads();
+            const uint32_t key = s_key;
+            if (key != 0xFFFFFFFFu) {
+               const uint32_t j = key & 0x3FFFu;
+               if (j >= j0 && j < j1 && cap) {
+                  sq_hit_t h;
+                  h.line = 1;
+                  h.start = sq_reverse_start<W>((const uint8_t *)s_text, j, (int)ed[j] - 1, peq_r, (const uint8_t *)s_lut, m, tau);
+                  h.end = j;
+                  h.dist = (uint32_t)ed[j] - 1u;
+                  rec[0] = h;
+               }
+            }
+            if (threadIdx.x == 0) out[0] = key != 0xFFFFFFFFu ? 1u : 0u;
+         }
+         __threadfence_system();
+         return;
+      }
+   }
    if (threadIdx.x != 0) return;
    const uint8_t *tp = staged ? (const uint8_t *)s_text : text;
    const uint32_t nh = sq_scan_line<W, SQ_MODE_EMIT>(tp, (uint64_t)n, 0, (const uint32_t *)s_peq, (const uint32_t *)(s_peq + 5 * W),
@@ -1733,7 +1822,8 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
 template <int W>
 static void launch_string(seeqdev_scan *s, const seeqdev_pattern *pat, const uint8_t *text, uint32_t n, int options, uint32_t cap)
 {
-   const size_t lds = n <= STRING_LDS_MAX ? (((size_t)n + 31) & ~(size_t)15) : 0;
+   size_t lds = n <= STRING_LDS_MAX ? (((size_t)n + 31) & ~(size_t)15) : 0;
+   if (n <= STRING_PAR_MAX) lds += (2 * ((size_t)n + 2) + 15) & ~(size_t)15;        /* + per-position emissions */
    hipLaunchKernelGGL(k_string<W>, dim3(1), dim3(WG), lds, s->stream, text, n, (const uint32_t *)pat->d_peq, pat->wlen, pat->tau,
                       options, s->h_strout, cap);
 }
