@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "seeq_amd.h"
 #include "seeq_kernel_core.h"
@@ -760,7 +761,8 @@ struct seeqdev_scan {
    Counters *h_cnt;            /* pinned */
    /* seeqdevStringMatch: one string per call in ONE launch (pinned, device-visible) */
    uint8_t *h_str; size_t cap_str;            /* the string (strings below STRING_ZC_MAX are read by the kernel over the link) */
-   uint32_t *h_strout; size_t cap_strout;     /* {nhits, pad[3]} + records */
+   uint32_t *h_strout; size_t cap_strout;     /* {nhits, ticket, pad[2]} + records; fine-grained (coherent) page-locked memory */
+   uint32_t  str_seq;                         /* ticket of the last k_string launch */
    /* staging for seeqdevScanHost */
    uint8_t *d_text; size_t cap_text;
    /* seeqdevScanRunMulti: per pattern of the last multi scan its counts and (host copy) its records */
@@ -1708,7 +1710,7 @@ static constexpr uint32_t STRING_PAR_MAX = 8192;            /* ... and up to thi
 
 template <int W>
 __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, const uint32_t *peq, int m, int tau, int options,
-                                               uint32_t *out, uint32_t cap)
+                                               uint32_t *out, uint32_t cap, uint32_t seq)
 {
    extern __shared__ __align__(16) uint8_t s_text[];       /* n + 16 bytes when staged */
    __shared__ uint32_t s_peq[10 * W];
@@ -1769,7 +1771,7 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
                s2 = s1; s1 = cur;
             }
          }
-         uint32_t total = 0;
+         uint32_t total = 0, nh_par = 0;
          const uint32_t excl = block_excl_scan(cnt, &total, s_wave);      /* (also orders the ed[] writes: barrier inside) */
          sq_hit_t *rec = reinterpret_cast<sq_hit_t *>(out + 4);
          if (match_opt == SQK_ALL) {
@@ -1786,7 +1788,7 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
                }
                idx++;
             }
-            if (threadIdx.x == 0) out[0] = total;
+            nh_par = total;
          } else {
             /* SQ_BEST: smallest distance, first position; SQ_FIRST / SQ_COUNT: first position */
             for (uint32_t j = j0; j < j1 && cnt; j++)
@@ -1804,9 +1806,16 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
                   rec[0] = h;
                }
             }
-            if (threadIdx.x == 0) out[0] = key != 0xFFFFFFFFu ? 1u : 0u;
+            nh_par = key != 0xFFFFFFFFu ? 1u : 0u;
          }
+         /* records first (every writer fences), then the count, then the ticket the host spins on */
          __threadfence_system();
+         __syncthreads();
+         if (threadIdx.x == 0) {
+            out[0] = nh_par;
+            __threadfence_system();
+            __hip_atomic_store(&out[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+         }
          return;
       }
    }
@@ -1817,15 +1826,16 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
                                                      reinterpret_cast<sq_hit_t *>(out + 4), cap);
    out[0] = nh;
    __threadfence_system();
+   __hip_atomic_store(&out[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int W>
-static void launch_string(seeqdev_scan *s, const seeqdev_pattern *pat, const uint8_t *text, uint32_t n, int options, uint32_t cap)
+static void launch_string(seeqdev_scan *s, const seeqdev_pattern *pat, const uint8_t *text, uint32_t n, int options, uint32_t cap, uint32_t seq)
 {
    size_t lds = n <= STRING_LDS_MAX ? (((size_t)n + 31) & ~(size_t)15) : 0;
    if (n <= STRING_PAR_MAX) lds += (2 * ((size_t)n + 2) + 15) & ~(size_t)15;        /* + per-position emissions */
    hipLaunchKernelGGL(k_string<W>, dim3(1), dim3(WG), lds, s->stream, text, n, (const uint32_t *)pat->d_peq, pat->wlen, pat->tau,
-                      options, s->h_strout, cap);
+                      options, s->h_strout, cap, seq);
 }
 
 /* data[0..n): the string (no NUL needed; a NUL inside ends it as in the reference).  On return *rec points at the
@@ -1839,7 +1849,7 @@ extern "C" int seeqdevStringMatch(seeqdev_scan_t *s, const seeqdev_pattern_t *pa
    if (use_device(s->device)) return -1;
    if (!s->h_strout) {
       s->cap_strout = 256;                                  /* records */
-      HIP_TRY(hipHostMalloc((void **)&s->h_strout, 16 + s->cap_strout * sizeof(seeqdev_hit_t), hipHostMallocDefault), ENOMEM);
+      HIP_TRY(hipHostMalloc((void **)&s->h_strout, 16 + s->cap_strout * sizeof(seeqdev_hit_t), hipHostMallocCoherent), ENOMEM);
    }
    if (!s->h_str) {
       s->cap_str = STRING_ZC_MAX + 16;
@@ -1863,13 +1873,30 @@ extern "C" int seeqdevStringMatch(seeqdev_scan_t *s, const seeqdev_pattern_t *pa
    for (int attempt = 0; attempt < 2; attempt++) {
       const uint32_t cap = (uint32_t)s->cap_strout;
       s->h_strout[0] = 0;
-      if (W <= 1) launch_string<1>(s, pat, dtext, (uint32_t)n, options, cap);
-      else if (W <= 2) launch_string<2>(s, pat, dtext, (uint32_t)n, options, cap);
-      else if (W <= 4) launch_string<4>(s, pat, dtext, (uint32_t)n, options, cap);
-      else if (W <= 8) launch_string<8>(s, pat, dtext, (uint32_t)n, options, cap);
-      else launch_string<16>(s, pat, dtext, (uint32_t)n, options, cap);
+      const uint32_t seq = ++s->str_seq ? s->str_seq : ++s->str_seq;      /* never 0 */
+      volatile uint32_t *ticket = s->h_strout + 1;
+      *ticket = 0;
+      if (W <= 1) launch_string<1>(s, pat, dtext, (uint32_t)n, options, cap, seq);
+      else if (W <= 2) launch_string<2>(s, pat, dtext, (uint32_t)n, options, cap, seq);
+      else if (W <= 4) launch_string<4>(s, pat, dtext, (uint32_t)n, options, cap, seq);
+      else if (W <= 8) launch_string<8>(s, pat, dtext, (uint32_t)n, options, cap, seq);
+      else launch_string<16>(s, pat, dtext, (uint32_t)n, options, cap, seq);
       HIP_TRY(hipGetLastError(), EIO);
-      HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+      /* The kernel's last store is its ticket, into fine-grained page-locked memory: spinning on it is shorter than the
+         runtime's completion path (hipStreamSynchronize: ~8 us).  After 200 us (long strings, a failed launch) the runtime
+         takes over. */
+      {
+         struct timespec t0, t1;
+         clock_gettime(CLOCK_MONOTONIC, &t0);
+         unsigned spins = 0;
+         while (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 63u) == 0) {
+               clock_gettime(CLOCK_MONOTONIC, &t1);
+               if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 200000L) break;
+            }
+         }
+         if (__atomic_load_n(ticket, __ATOMIC_ACQUIRE) != seq) HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+      }
       const uint32_t nh = s->h_strout[0];
       if (nh <= cap) {
          *rec = reinterpret_cast<const seeqdev_hit_t *>(s->h_strout + 4);
@@ -1880,7 +1907,7 @@ extern "C" int seeqdevStringMatch(seeqdev_scan_t *s, const seeqdev_pattern_t *pa
       (void)hipHostFree(s->h_strout);
       s->h_strout = NULL;
       s->cap_strout = (size_t)nh + (nh >> 2) + 64;
-      HIP_TRY(hipHostMalloc((void **)&s->h_strout, 16 + s->cap_strout * sizeof(seeqdev_hit_t), hipHostMallocDefault), ENOMEM);
+      HIP_TRY(hipHostMalloc((void **)&s->h_strout, 16 + s->cap_strout * sizeof(seeqdev_hit_t), hipHostMallocCoherent), ENOMEM);
    }
    errno = EIO;
    return -1;
