@@ -1741,36 +1741,13 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
       for (uint32_t j = threadIdx.x; j < len; j += WG) if (s_lut[s_text[j]] == SQC_SKIP) s_skip = 1u;
       __syncthreads();
       if (!s_skip) {
-         const int tau1 = tau + 1, topw = (m - 1) >> 5, topbit = (m - 1) & 31;
          const int match_opt = options & 3;
          const uint32_t *peq_f = s_peq, *peq_r = s_peq + 5 * W;
          uint16_t *ed = reinterpret_cast<uint16_t *>(s_text + (((size_t)n + 31) & ~(size_t)15));   /* per position: emitted distance + 1, or 0 */
          const uint32_t P = len + 1;                      /* positions 0..len; the last one is the terminator's step */
          const uint32_t B = (P + WG - 1) / WG;
          const uint32_t j0 = threadIdx.x * B, j1 = j0 + B < P ? j0 + B : P;
-         uint32_t cnt = 0;
-         if (j0 < P) {
-            long start = (long)j0 - 2 - (long)(m + tau - 1);
-            if (start < 0) start = 0;
-            sq_myers_t<W> st;
-            sq_myers_init<W>(st, m);
-            int s2 = tau1, s1 = tau1;                     /* capped scores of the two positions before j */
-            for (long j = start; j < (long)j1; j++) {
-               int cur = tau1;
-               if ((uint32_t)j < len) {
-                  sq_myers_step<W>(st, &peq_f[(uint32_t)s_lut[s_text[j]] * W], topw, topbit);
-                  cur = st.score < tau1 ? st.score : tau1;
-               }
-               if (j >= (long)j0) {
-                  const bool latch = s2 < s1 ? true : s2 == 0;          /* what the step before left (false at the line start) */
-                  const bool stop = s1 < cur, zero = s1 == 0;
-                  const bool emit = stop ? !latch : zero;
-                  ed[j] = emit ? (uint16_t)(s1 + 1) : (uint16_t)0;
-                  cnt += emit ? 1u : 0u;
-               }
-               s2 = s1; s1 = cur;
-            }
-         }
+         const uint32_t cnt = j0 < P ? sq_emit_window<W>((const uint8_t *)s_text, len, j0, j1, peq_f, (const uint8_t *)s_lut, m, tau, ed) : 0u;
          uint32_t total = 0, nh_par = 0;
          const uint32_t excl = block_excl_scan(cnt, &total, s_wave);      /* (also orders the ed[] writes: barrier inside) */
          sq_hit_t *rec = reinterpret_cast<sq_hit_t *>(out + 4);

@@ -157,6 +157,44 @@ SEEQ_HD uint32_t sq_reverse_start(const uint8_t *line, uint32_t i, int streak, c
    return (uint32_t)((int)i - jj);
 }
 
+/* ---- the acceptance rules per position (k_string: positions shared out over threads) ---- */
+/* The rules of libseeq.c:277-331 only look at three consecutive capped scores: with streak = sc[j-1], cur = sc[j]
+ * (tau+1 at the terminator's step and before the line start),
+ *    latch before step j = stop(j-1) ? 1 : zero(j-1) = sc[j-2] < sc[j-1] ? 1 : sc[j-2] == 0,
+ *    emit(j)             = stop(j) ? !latch : zero(j)  with stop(j) = sc[j-1] < sc[j], zero(j) = sc[j-1] == 0,
+ * and sc[j] itself only depends on the m + tau characters up to j: a fresh column started m + tau + 1 characters
+ * before the first position of interest gives the line's own capped scores from two positions before it on.
+ * text[0, len): the line up to its terminator, every byte of class 0..4 (no skipped bytes); positions j0 <= j < j1
+ * <= len + 1 (position len is the terminator's step).  ed[j] = emitted distance + 1, or 0.  Returns the emissions. */
+template <int W, typename TEXT, typename LUT, typename PEQ>
+SEEQ_HD uint32_t sq_emit_window(const TEXT text, uint32_t len, uint32_t j0, uint32_t j1, const PEQ peq_f, const LUT lut,
+                                int m, int tau, uint16_t *ed)
+{
+   const int tau1 = tau + 1, topw = (m - 1) >> 5, topbit = (m - 1) & 31;
+   long start = (long)j0 - 2 - (long)(m + tau - 1);
+   if (start < 0) start = 0;
+   sq_myers_t<W> st;
+   sq_myers_init<W>(st, m);
+   int s2 = tau1, s1 = tau1;                        /* capped scores of the two positions before j */
+   uint32_t cnt = 0;
+   for (long j = start; j < (long)j1; j++) {
+      int cur = tau1;
+      if ((uint32_t)j < len) {
+         sq_myers_step<W>(st, &peq_f[(uint32_t)lut[text[j]] * W], topw, topbit);
+         cur = st.score < tau1 ? st.score : tau1;
+      }
+      if (j >= (long)j0) {
+         const bool latch = s2 < s1 ? true : s2 == 0;
+         const bool stop = s1 < cur, zero = s1 == 0;
+         const bool emit = stop ? !latch : zero;
+         ed[j] = emit ? (uint16_t)(s1 + 1) : (uint16_t)0;
+         cnt += emit ? 1u : 0u;
+      }
+      s2 = s1; s1 = cur;
+   }
+   return cnt;
+}
+
 /* ---- forward scan of one line: libseeq.c:250-338 --------------------------- */
 #define SQ_MODE_ANY   0   /* does the line have >= 1 hit?  (stops at the first)      */
 #define SQ_MODE_COUNT 1   /* number of hits under SQ_ALL rules                        */

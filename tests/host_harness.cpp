@@ -61,6 +61,70 @@ extern "C" long harness_scan(const uint8_t *text, size_t n, const char *keys, in
    return run<16>(text, n, keys, m, tau, options, mode, out, cap);
 }
 
+// seeqStringMatch as k_string computes it (seeq_device.hip): the positions of the line shared out in blocks of `block`
+// (what the 256 threads of the workgroup get), each block from a fresh column through sq_emit_window, emissions then
+// taken in order (SQ_ALL), the first (SQ_FIRST) or the first with the smallest distance (SQ_BEST), starts by
+// sq_reverse_start.  Returns the number of hits, or -1 for a line the kernel leaves to its one-lane scan (a skipped
+// byte before the terminator).
+namespace {
+template <int W>
+long run_par(const uint8_t *text, size_t n, const char *keys, int m, int tau, int options, int block, uint32_t *out, size_t cap)
+{
+   std::vector<uint32_t> pf(5 * W), pr(5 * W);
+   std::vector<char> rkeys(m);
+   for (int i = 0; i < m; i++) rkeys[i] = keys[m - 1 - i];
+   seeq_build_peq(keys, m, W, pf.data());
+   seeq_build_peq(rkeys.data(), m, W, pr.data());
+   uint8_t lut[256];
+   for (int b = 0; b < 256; b++) lut[b] = sq_class_of((uint32_t)b, options);
+   uint32_t len = (uint32_t)n;
+   for (uint32_t j = 0; j < n; j++) if (lut[text[j]] == SQC_TERM) { len = j; break; }
+   for (uint32_t j = 0; j < len; j++) if (lut[text[j]] == SQC_SKIP) return -1;
+   std::vector<uint16_t> ed(len + 2, 0);
+   const uint32_t P = len + 1;
+   const uint32_t *f = pf.data(), *r = pr.data();
+   const uint8_t *l = lut;
+   for (uint32_t j0 = 0; j0 < P; j0 += (uint32_t)block)
+      sq_emit_window<W>(text, len, j0, j0 + (uint32_t)block < P ? j0 + (uint32_t)block : P, f, l, m, tau, ed.data());
+   const int mo = options & 3;
+   long nh = 0;
+   long best = -1;
+   for (uint32_t j = 0; j < P; j++) {
+      if (!ed[j]) continue;
+      if (mo == SQK_ALL) {
+         if ((size_t)nh < cap) {
+            out[3 * nh + 0] = sq_reverse_start<W>(text, j, (int)ed[j] - 1, r, l, m, tau);
+            out[3 * nh + 1] = j;
+            out[3 * nh + 2] = (uint32_t)ed[j] - 1u;
+         }
+         nh++;
+      } else if (mo == SQK_BEST) {
+         if (best < 0 || ed[j] < ed[best]) best = j;
+      } else { best = j; break; }
+   }
+   if (mo != SQK_ALL && best >= 0) {
+      if (cap) {
+         out[0] = sq_reverse_start<W>(text, (uint32_t)best, (int)ed[best] - 1, r, l, m, tau);
+         out[1] = (uint32_t)best;
+         out[2] = (uint32_t)ed[best] - 1u;
+      }
+      nh = 1;
+   }
+   return nh;
+}
+}  // namespace
+
+extern "C" long harness_string_par(const uint8_t *text, size_t n, const char *keys, int m, int tau, int options, int block,
+                                   int wforce, uint32_t *out, size_t cap)
+{
+   int W = wforce > 0 ? wforce : seeq_words_for(m);
+   if (W <= 1) return run_par<1>(text, n, keys, m, tau, options, block, out, cap);
+   if (W <= 2) return run_par<2>(text, n, keys, m, tau, options, block, out, cap);
+   if (W <= 4) return run_par<4>(text, n, keys, m, tau, options, block, out, cap);
+   if (W <= 8) return run_par<8>(text, n, keys, m, tau, options, block, out, cap);
+   return run_par<16>(text, n, keys, m, tau, options, block, out, cap);
+}
+
 extern "C" int harness_compile(const char *expr, char *keys, int *err) { return seeq_compile_pattern(expr, keys, err); }
 
 // ---- the streaming automaton of k_stream (seeq_amd/csrc/seeq_dfa.h: host-side table builder) ----

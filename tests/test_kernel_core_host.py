@@ -71,6 +71,51 @@ def test_fuzz_vs_oracle(harness, oracle):
         assert run(harness, oracle, pat, tau, text, opt, COUNT) == len(allh)
 
 
+def test_string_positions_in_blocks_vs_oracle(harness, oracle, string_cases):
+    """Host side of k_string: the positions of a string shared out in blocks (block sizes 1, 2, 7 and 'whole string'),
+    every block from a fresh column through sq_emit_window -- the function the kernel's threads call -- with the
+    acceptance rules evaluated per position from three consecutive scores: the same hits as the oracle's line-long scan,
+    for the golden string cases and random patterns / texts / options.  Strings with a skipped byte before the
+    terminator (SQ_IGNORE, SQ_STREAM) are left to the one-lane scan by the kernel (-1 here)."""
+    import ctypes as C
+    H = harness
+    H.harness_string_par.restype = C.c_long
+    H.harness_string_par.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_size_t]
+
+    def par(pat, tau, text, opt, block, wforce=0):
+        keys, _ = oracle.parse(pat)
+        tb = text.encode("latin-1")
+        out = np.zeros(3 * 4096, dtype=np.uint32)
+        n = H.harness_string_par(tb, len(tb), bytes(keys), len(keys), tau, opt, block, wforce, out.ctypes.data, 4096)
+        return None if n < 0 else [tuple(int(x) for x in out[3 * k:3 * k + 3]) for k in range(n)]
+
+    npar = 0
+    for c in string_cases:
+        for block in (1, 3, 1 << 20):
+            got = par(c["pattern"], c["tau"], c["text"], c["options"], block)
+            if got is not None:
+                npar += 1
+                assert [list(h) for h in got] == c["hits"][::-1], (c, block)
+    sys.path.insert(0, GOLDEN)
+    from make_golden import plain, rand_pattern, rand_text
+    rng = random.Random(77)
+    for _ in range(1200):
+        pat = rand_pattern(rng)
+        m = len(plain(pat))
+        tau = rng.randint(0, min(m - 1, rng.choice([0, 1, 2, 3, 3, 5, 8])))
+        text = rand_text(rng, pat, tau, rng.choice([0, 1, 5, 20, 60, 150, 250, 700]))
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL, SQ_COUNT):
+            opt = mo | rng.choice([SQ_FAIL, SQ_CONVERT, SQ_CONVERT, SQ_IGNORE]) | rng.choice([0, 0, 0, SQ_STREAM])
+            wf = rng.choice([0] + [w for w in (2, 4, 8, 16) if 32 * w >= m])
+            got = par(pat, tau, text, opt, rng.choice([1, 2, 7, 64, 1 << 20]), wf)
+            if got is None:
+                continue
+            npar += 1
+            assert got == oracle.string_match(pat, tau, text, opt)[::-1], (pat, tau, text, opt, wf)
+    assert npar > 3000
+
+
 def test_stream_automaton_vs_oracle(harness, oracle):
     """Host side of k_stream: the complete Levenshtein automaton (seeq_dfa.h) walked chunk by chunk with a warm-up,
     exactly as the kernel decomposes the text, reports a first-hit event in a line iff the oracle finds a hit in it
