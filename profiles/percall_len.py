@@ -5,7 +5,7 @@ from seeq_amd import _capi
 L = _capi.lib()
 sq = L.seeqNew(b"GATGTAGCGCGATTAGCCTG", 3, 0)
 rng = random.Random(1)
-for n in (1, 20, 75, 150, 300, 600, 2000):
+for n in (1, 20, 75, 150, 300, 600, 2000, 8000, 16000, 32000):
     strs = ["".join(rng.choice("ACGT") for _ in range(n)).encode() for _ in range(64)]
     for s in strs: L.seeqStringMatch(s, sq, 1)
     t0 = time.perf_counter(); k = 0

@@ -1706,7 +1706,7 @@ extern "C" int seeqdevScanLastLaunches(const seeqdev_scan_t *s) { return s ? (in
  * in line mode take the batched scan instead (libseeq_api.c). */
 static constexpr uint32_t STRING_LDS_MAX = 48u * 1024;      /* strings up to this are staged in LDS */
 static constexpr uint32_t STRING_ZC_MAX = 4096;             /* ... and up to this read straight from host memory */
-static constexpr uint32_t STRING_PAR_MAX = 8192;            /* ... and up to this scanned by all threads (positions fit 14 bits) */
+static constexpr uint32_t STRING_PAR_MAX = 32768;           /* ... and up to this scanned by all threads (positions fit 16 bits; longer strings in line mode take the batched scan) */
 
 template <int W>
 __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, const uint32_t *peq, int m, int tau, int options,
@@ -1769,11 +1769,11 @@ __global__ __launch_bounds__(WG) void k_string(const uint8_t *text, uint32_t n, 
          } else {
             /* SQ_BEST: smallest distance, first position; SQ_FIRST / SQ_COUNT: first position */
             for (uint32_t j = j0; j < j1 && cnt; j++)
-               if (ed[j]) { atomicMin(&s_key, (match_opt == SQK_BEST ? ((uint32_t)ed[j] - 1u) << 14 : 0u) | j); if (match_opt != SQK_BEST) break; }
+               if (ed[j]) { atomicMin(&s_key, (match_opt == SQK_BEST ? ((uint32_t)ed[j] - 1u) << 16 : 0u) | j); if (match_opt != SQK_BEST) break; }
             __syncthreads();
             const uint32_t key = s_key;
             if (key != 0xFFFFFFFFu) {
-               const uint32_t j = key & 0x3FFFu;
+               const uint32_t j = key & 0xFFFFu;
                if (j >= j0 && j < j1 && cap) {
                   sq_hit_t h;
                   h.line = 1;
@@ -1811,6 +1811,11 @@ static void launch_string(seeqdev_scan *s, const seeqdev_pattern *pat, const uin
 {
    size_t lds = n <= STRING_LDS_MAX ? (((size_t)n + 31) & ~(size_t)15) : 0;
    if (n <= STRING_PAR_MAX) lds += (2 * ((size_t)n + 2) + 15) & ~(size_t)15;        /* + per-position emissions */
+   static bool big_lds = false;                             /* (per instantiation) */
+   if (lds > 48u * 1024 && !big_lds) {                      /* beyond the default limit of dynamic LDS per workgroup */
+      (void)hipFuncSetAttribute((const void *)k_string<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      big_lds = true;
+   }
    hipLaunchKernelGGL(k_string<W>, dim3(1), dim3(WG), lds, s->stream, text, n, (const uint32_t *)pat->d_peq, pat->wlen, pat->tau,
                       options, s->h_strout, cap, seq);
 }

@@ -1073,6 +1073,30 @@ def test_long_string_match(gpu, capi, oracle):
     s.close()
 
 
+def test_string_match_every_size_class(gpu, capi, oracle):
+    """seeqStringMatch across the size classes of k_string: read from host memory (<= 4 KiB), staged from device memory,
+    positions shared out over the workgroup (<= 32 KiB, more than 64 KiB of LDS beyond 16 KiB), the batched scan beyond
+    -- dense and sparse hits, terminators and N inside, a skipped byte (one-lane scan), one- and two-word patterns."""
+    rng = random.Random(2718)
+    for pat, tau in ((PAT20, 3), ("GATGAAGCACGATTAGCCTGAAAATGAGAG", 5), ("ACGT", 1)):
+        core = pat
+        s = SQ(capi, pat, tau)
+        for n in (1, 19, 255, 256, 257, 4096, 4097, 8192, 8193, 16000, 20000, 32767, 32768, 32769, 40000):
+            t = [rng.choice("ACGT") for _ in range(n)]
+            for p in rng.sample(range(max(1, n - len(core))), min(12, max(1, n // 300))):
+                c = _mutate(rng, core, rng.randrange(0, tau + 2))
+                t[p:p + len(c)] = list(c)[:max(0, n - p)]
+            base = "".join(t)[:n]
+            texts = [base]
+            if n > 40:
+                texts.append(base[:n // 3] + "N" + base[n // 3 + 1:2 * n // 3] + "\n" + base[2 * n // 3 + 1:])
+                texts.append(base[:n // 2] + "!" + base[n // 2 + 1:])
+            for text in texts:
+                for opt in (SQ_FIRST, SQ_BEST, SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE):
+                    assert s.match(text, opt) == oracle.string_match(pat, tau, text, opt), (pat, n, opt, text[:30])
+        s.close()
+
+
 def test_mixed_reads_and_long_line(gpu, capi, oracle):
     """A file of reads (the sampled average line is short: the read-length kernels are chosen) with one 2 MB line
     that has hits: the scan notices, re-runs itself once with the long-line variant, and the results are the oracle's."""
