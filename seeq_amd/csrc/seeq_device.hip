@@ -1811,11 +1811,8 @@ static void launch_string(seeqdev_scan *s, const seeqdev_pattern *pat, const uin
 {
    size_t lds = n <= STRING_LDS_MAX ? (((size_t)n + 31) & ~(size_t)15) : 0;
    if (n <= STRING_PAR_MAX) lds += (2 * ((size_t)n + 2) + 15) & ~(size_t)15;        /* + per-position emissions */
-   static bool big_lds = false;                             /* (per instantiation) */
-   if (lds > 48u * 1024 && !big_lds) {                      /* beyond the default limit of dynamic LDS per workgroup */
+   if (lds > 48u * 1024)                                    /* beyond the default limit of dynamic LDS per workgroup (set per device: every time) */
       (void)hipFuncSetAttribute((const void *)k_string<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      big_lds = true;
-   }
    hipLaunchKernelGGL(k_string<W>, dim3(1), dim3(WG), lds, s->stream, text, n, (const uint32_t *)pat->d_peq, pat->wlen, pat->tau,
                       options, s->h_strout, cap, seq);
 }
