@@ -332,7 +332,43 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                streak = (NS || act) ? cur : streak; \
                done = done | ((NS || act) & end); \
             }
-            if (noskip) { EXACT1_CHARS4(true) } else { EXACT1_CHARS4(false) }
+            if (noskip) {
+               /* The same rules in integer arithmetic (flags as 0 / 1 words, compares as sign bits: scores are <= tau + 1
+                  < 64): as bools the compiler keeps materialising them between mask registers and 0 / 1 words, ~15 of
+                  the ~60 instructions per character of the two-word COUNT. */
+               uint32_t dn = done ? 1u : 0u, latch_u = latch ? 1u : 0u;
+               const uint32_t any_u = (MODE == SQ_MODE_COUNT ? count_any : match_opt != SQ_ALL) ? 1u : 0u;
+#pragma unroll
+               for (int cc = 0; cc < 4; cc++) {
+                  const uint32_t term_u = ev[cc].w0 & FUSED_FLAG_TERM;            /* (= 1) */
+                  st.step(ev[cc]);
+                  const uint32_t m1 = st.score | (0u - term_u);                   /* the terminator's step: tau + 1 */
+                  const uint32_t cur = m1 < tau1 ? m1 : tau1;
+                  const uint32_t stop_u = (streak - cur) >> 31, zero_u = (streak - 1u) >> 31;
+                  const uint32_t emit_u = (dn ^ 1u) & ((stop_u & (latch_u ^ 1u)) | ((stop_u ^ 1u) & zero_u));
+                  latch_u = stop_u | zero_u;
+                  const uint32_t p = pos + t4 + cc;
+                  if (walk) lastsub = cur < tau1 ? (int32_t)p : lastsub;
+                  if (MODE == SQ_MODE_COUNT) {
+                     if (caching) {
+                        if (__any(emit_u != 0)) {                /* (a few times per line) */
+                           const bool f0 = emit_u != 0 && nhits == 0;
+                           ce0 = f0 ? p : ce0; ce1 = f0 ? streak : ce1;
+                           if (emit_u != 0 && nhits >= 1) {      /* second and later: to my wave's overflow list */
+                              const uint32_t idx = atomicAdd(&s_novf[wave_id], 1u) + 1u;
+                              if (idx < ovf_r) ovf[idx] = make_uint4(k, nhits, p, streak);
+                           }
+                        }
+                     }
+                  } else {
+                     if (emit_u != 0 && nhits < out_cap) { out[nhits].end = p; out[nhits].dist = streak; }
+                  }
+                  nhits += emit_u;
+                  dn |= term_u | (any_u & emit_u);               /* presence is enough / SQ_FIRST: libseeq.c:330 */
+                  streak = cur;
+               }
+               done = dn != 0; latch = latch_u != 0;
+            } else { EXACT1_CHARS4(false) }
 #undef EXACT1_CHARS4
          }
          pos += 64;
