@@ -448,8 +448,9 @@ def main():
                 traffic = None
         notes = {
             "k_stream": "line-agnostic table-driven scan: text read once (coalesced 128 B per lane), one LDS gather and five VALU "
-                        "instructions per walk step, 1.375 steps per text byte; bound by the LDS gather unit alone (32 banks, 5.65 cycles per "
-                        "64-lane gather, ~85 % busy; VALU at ~55 % of its issue rate), above the HBM stream time: see DESIGN.md",
+                        "instructions per walk step, 1.375 steps per text byte; bound by the LDS gather unit (32 banks, 5.65 cycles per "
+                        "64-lane gather, ~85 % busy; VALU issue right behind it, but removing 18 % of it changes nothing), above the "
+                        "HBM stream time: see DESIGN.md",
             "k_direct": "one-pass per-line scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte) and "
                         "on re-reading lines from L2: see DESIGN.md",
         }
