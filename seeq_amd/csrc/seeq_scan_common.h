@@ -157,17 +157,31 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
 {
    __shared__ uint32_t s_red[4][4];
    uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0, flags = 0, busy = 0, crowded = 0;
-   for (uint32_t i = threadIdx.x; i < nslices; i += 256) {
-      if (a.wg_lastnl) { const uint32_t l = a.wg_lastnl[i]; lastnl = l > lastnl ? l : lastnl; }
-      lines += a.wg_part[4 * i + 0];
-      hdrs += a.wg_part[4 * i + 1];
-      const uint32_t h = a.wg_part[4 * i + 2];
-      flags |= a.wg_part[4 * i + 3];
-      busy += a.wg_part[4 * i + 0] != 0;                     /* waves that saw text / of them, those drowning in made-up candidates */
-      crowded += (a.wg_part[4 * i + 3] >> 3) & 1u;
-      hits += h & 0x7FFFFFFFu;
-      mx = (h & 0x7FFFFFFFu) > mx ? (h & 0x7FFFFFFFu) : mx;
-      ovf |= h >> 31;
+   /* one 16-byte load per slice, four slices per thread in flight (this kernel is one workgroup on an idle chip: its time is
+      the latency of its loads) */
+   const uint4 *part = reinterpret_cast<const uint4 *>(a.wg_part);
+   for (uint32_t i0 = threadIdx.x; i0 < nslices; i0 += 1024) {
+      uint4 pv[4];
+      uint32_t lv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const uint32_t i = i0 + 256u * u;
+         pv[u] = i < nslices ? part[i] : make_uint4(0u, 0u, 0u, 0u);
+         lv[u] = a.wg_lastnl && i < nslices ? a.wg_lastnl[i] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         lastnl = lv[u] > lastnl ? lv[u] : lastnl;
+         lines += pv[u].x;
+         hdrs += pv[u].y;
+         const uint32_t h = pv[u].z;
+         flags |= pv[u].w;
+         busy += pv[u].x != 0;                               /* waves that saw text / of them, those drowning in made-up candidates */
+         crowded += (pv[u].w >> 3) & 1u;
+         hits += h & 0x7FFFFFFFu;
+         mx = (h & 0x7FFFFFFFu) > mx ? (h & 0x7FFFFFFFu) : mx;
+         ovf |= h >> 31;
+      }
    }
 #pragma unroll
    for (int d = 32; d >= 1; d >>= 1) {

@@ -485,14 +485,28 @@ __global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t ns
    for (uint32_t sl = blockIdx.x * 4 + (threadIdx.x >> 6); sl < nslices; sl += gridDim.x * 4) {      /* one wave per slice */
       const uint32_t n = a.wg_hits[sl];
       const uint4 *slice = a.tmp + (size_t)sl * a.slice_cap;
-      for (uint32_t i = lane; i < n; i += 64) {
-         const uint4 e = slice[i];
-         const uint32_t tile = e.x & 0x7FFFFFFFu;
-         const uint32_t dst = a.tile_hits[tile] + (e.y & 0x1FFFu);
-         hit_start[dst] = e.z;
-         hit_line[dst] = (uint32_t)(c->lines + a.tile_cl[tile] + e.w + 1);     /* 1-based, reference seeq.c:377 */
-         unresolved[dst] = e.x >> 31;                        /* e.z is the hit itself: the line starts before the tile */
-         hit_col[dst] = e.y >> 13;
+      const uint32_t lines0 = (uint32_t)c->lines;
+      for (uint32_t i0 = lane; i0 < n; i0 += 256) {          /* four entries per lane in flight: the time of this kernel is load latency */
+         uint4 e[4];
+         uint32_t th[4], tc[4];
+#pragma unroll
+         for (int u = 0; u < 4; u++) e[u] = i0 + 64u * u < n ? slice[i0 + 64u * u] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+         for (int u = 0; u < 4; u++) {
+            const uint32_t tile = e[u].x & 0x7FFFFFFFu;
+            const bool ok = i0 + 64u * u < n;
+            th[u] = ok ? a.tile_hits[tile] : 0u;
+            tc[u] = ok ? a.tile_cl[tile] : 0u;
+         }
+#pragma unroll
+         for (int u = 0; u < 4; u++) {
+            if (i0 + 64u * u >= n) continue;
+            const uint32_t dst = th[u] + (e[u].y & 0x1FFFu);
+            hit_start[dst] = e[u].z;
+            hit_line[dst] = lines0 + tc[u] + e[u].w + 1u;   /* 1-based, reference seeq.c:377 */
+            unresolved[dst] = e[u].x >> 31;                  /* e.z is the hit itself: the line starts before the tile */
+            hit_col[dst] = e[u].y >> 13;
+         }
       }
    }
 }
