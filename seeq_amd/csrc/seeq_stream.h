@@ -518,6 +518,24 @@ __global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t ns
 __device__ __forceinline__ uint64_t stream_line_start_in(const uint8_t *text, uint64_t lo, uint64_t hi)
 {
    uint64_t q = hi;
+   while (q >= lo + 64) {                                  /* 64 bytes per step, the four loads in flight together (a line of reads: 2-3 steps) */
+      fused_v4u v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const fused_v4u_unaligned *>(text + q - 64 + 16 * u);
+#pragma unroll
+      for (int u = 3; u >= 0; u--) {
+         const uint32_t g3 = nl_flags(v[u].w), g2 = nl_flags(v[u].z), g1 = nl_flags(v[u].y), g0 = nl_flags(v[u].x);
+         if (g3 | g2 | g1 | g0) {
+            uint32_t byte;                                 /* index of the LAST newline among these 16 bytes */
+            if (g3) byte = 12 + ((31 - (uint32_t)__builtin_clz(g3)) >> 3);
+            else if (g2) byte = 8 + ((31 - (uint32_t)__builtin_clz(g2)) >> 3);
+            else if (g1) byte = 4 + ((31 - (uint32_t)__builtin_clz(g1)) >> 3);
+            else byte = (31 - (uint32_t)__builtin_clz(g0)) >> 3;
+            return q - 64 + 16 * u + byte + 1;
+         }
+      }
+      q -= 64;
+   }
    while (q >= lo + 16) {
       const fused_v4u v = *reinterpret_cast<const fused_v4u_unaligned *>(text + q - 16);
       const uint32_t g3 = nl_flags(v.w), g2 = nl_flags(v.z), g1 = nl_flags(v.y), g0 = nl_flags(v.x);
