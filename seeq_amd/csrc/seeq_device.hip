@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <errno.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -549,6 +550,7 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_stream.h"
+#include "seeq_pair.h"
 static_assert(STREAM_NW == STREAM_NW_HOST, "waves per k_stream workgroup");
 extern "C" {
 #include "seeq_dfa.h"
@@ -645,6 +647,14 @@ struct seeqdev_pattern {
    int       sdfa_parts;     /* 1: the complete automaton (exact verdicts); > 1: partition filter (candidates) */
    int       sdfa_warm;      /* bytes of warm-up a chunk walk needs */
    double    sdfa_pacc;      /* filter: probability that a random DNA character completes a candidate */
+   int       pair_state;     /* the pair automaton of k_pair (seeq_dfa.h section 3): 0 not tried, 1 built, -1 none fits */
+   uint16_t *d_pair;         /* its table in HBM (32-byte rows), staged into LDS by k_pair */
+   uint32_t  pair_units;     /* 16-byte units of the table (2 per row) */
+   uint32_t  pair_hit_base;  /* state values >= this are flagged rows */
+   uint32_t  pair_states;
+   int       pair_parts, pair_mp, pair_warm;
+   double    pair_pacc;      /* probability that a random DNA character completes a candidate */
+   pthread_mutex_t plan_lock;   /* the automata are built on first use; scan contexts on several threads may share a pattern */
 };
 
 extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int tau)
@@ -664,6 +674,7 @@ extern "C" seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int 
    seeqdev_pattern *p = (seeqdev_pattern *)calloc(1, sizeof *p);
    if (!p) return NULL;
    p->id = __atomic_add_fetch(&g_pattern_ids, 1ul, __ATOMIC_RELAXED);
+   pthread_mutex_init(&p->plan_lock, NULL);
    p->wlen = wlen; p->tau = tau; p->words = seeq_words_for(wlen);
    p->keys = (char *)malloc((size_t)wlen);
    if (p->keys) memcpy(p->keys, keys, (size_t)wlen);
@@ -699,9 +710,72 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
    if (p->d_peq) (void)hipFree(p->d_peq);
    if (p->d_sdfa) (void)hipFree(p->d_sdfa);
    if (p->d_sdfa_skip) (void)hipFree(p->d_sdfa_skip);
+   if (p->d_pair) (void)hipFree(p->d_pair);
+   pthread_mutex_destroy(&p->plan_lock);
    free(p->keys);
    free(p->h_peq);
    free(p);
+}
+
+/* The automata of a pattern are built on first use, once, under the pattern's lock (scan contexts on several threads
+ * may share a pattern); a table is published -- state 1 -- only when all of it sits in HBM, and a failed upload frees
+ * what it had allocated. */
+static void pattern_plan_stream(seeqdev_pattern *mp, bool complete_only)
+{
+   pthread_mutex_lock(&mp->plan_lock);
+   if (mp->sdfa_state == 0 && mp->keys) {
+      int state = -1;
+      seeq_dfa_t *d = seeq_dfa_plan_stream(mp->keys, mp->wlen, mp->tau, complete_only ? 1 : 0);
+      if (d) {
+         const size_t bytes = (size_t)d->nrows * 16;
+         uint16_t *skip = seeq_dfa_skip_variant(d);
+         uint16_t *t0 = nullptr, *t1 = nullptr;
+         if (skip && hipMalloc((void **)&t0, bytes) == hipSuccess && hipMemcpy(t0, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMalloc((void **)&t1, bytes) == hipSuccess && hipMemcpy(t1, skip, bytes, hipMemcpyHostToDevice) == hipSuccess) {
+            mp->d_sdfa = t0; mp->d_sdfa_skip = t1;
+            mp->sdfa_rows = d->nrows;
+            mp->sdfa_final_base = d->acc_final;            /* state value of ACC_NEW */
+            mp->sdfa_parts = d->nparts;
+            mp->sdfa_warm = d->warm;
+            mp->sdfa_pacc = d->p_accept;
+            state = 1;
+         } else {
+            if (t0) (void)hipFree(t0);
+            if (t1) (void)hipFree(t1);
+         }
+         free(skip);
+         seeq_dfa_free(d);
+      }
+      __atomic_store_n(&mp->sdfa_state, state, __ATOMIC_RELEASE);
+   }
+   pthread_mutex_unlock(&mp->plan_lock);
+}
+
+static void pattern_plan_pair(seeqdev_pattern *mp)
+{
+   pthread_mutex_lock(&mp->plan_lock);
+   if (mp->pair_state == 0 && mp->keys) {
+      int state = -1;
+      seeq_pair_t *d = seeq_pair_plan(mp->keys, mp->wlen, mp->tau);
+      if (d) {
+         const size_t bytes = (size_t)d->nrows * 32;
+         uint16_t *t0 = nullptr;
+         if (hipMalloc((void **)&t0, bytes) == hipSuccess && hipMemcpy(t0, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess) {
+            mp->d_pair = t0;
+            mp->pair_units = d->nrows * 2;
+            mp->pair_hit_base = d->hit_base;
+            mp->pair_states = d->nstates;
+            mp->pair_parts = d->nparts; mp->pair_mp = d->mp; mp->pair_warm = d->warm;
+            mp->pair_pacc = d->p_accept;
+            state = 1;
+         } else if (t0) {
+            (void)hipFree(t0);
+         }
+         seeq_pair_free(d);
+      }
+      __atomic_store_n(&mp->pair_state, state, __ATOMIC_RELEASE);
+   }
+   pthread_mutex_unlock(&mp->plan_lock);
 }
 
 /* ========================================================================== */
@@ -709,7 +783,7 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
 /* ========================================================================== */
 /* Experiment / test knobs, read from the environment ONCE per scan context (seeqdevScanNew). */
 struct ScanKnobs {
-   int  kernel;          /* SEEQ_FUSED_KERNEL: 0 auto, 1 "stream", 2 "direct" */
+   int  kernel;          /* SEEQ_FUSED_KERNEL: 0 auto, 1 "stream" (k_stream, never k_pair), 2 "direct", 3 "pair" (k_pair wherever the pattern has a pair automaton, selective or not) */
    int  stream_ch;       /* SEEQ_STREAM_CH: 128 (default) or 64 */
    bool stream_ilp1;     /* SEEQ_STREAM_ILP=1: one walk per lane */
    int  wgs_per_cu;      /* SEEQ_DFA_WGS: cap on k_stream workgroups per CU (0 = occupancy) */
@@ -827,7 +901,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       s->force_path = pe ? (!strcmp(pe, "generic") ? 1 : !strcmp(pe, "fused") ? 2 : 0) : 0;
       ScanKnobs &kn = s->knobs;
       const char *v;
-      v = getenv("SEEQ_FUSED_KERNEL"); kn.kernel = v ? (!strcmp(v, "stream") ? 1 : !strcmp(v, "direct") ? 2 : 0) : 0;
+      v = getenv("SEEQ_FUSED_KERNEL"); kn.kernel = v ? (!strcmp(v, "stream") ? 1 : !strcmp(v, "direct") ? 2 : !strcmp(v, "pair") ? 3 : 0) : 0;
       v = getenv("SEEQ_STREAM_CH");    kn.stream_ch = v && atoi(v) == 64 ? 64 : 128;
       v = getenv("SEEQ_STREAM_ILP");   kn.stream_ilp1 = v && atoi(v) == 1;
       v = getenv("SEEQ_DFA_WGS");      kn.wgs_per_cu = v ? atoi(v) : 0;
@@ -1143,27 +1217,7 @@ static int run_segments(seeqdev_scan *s)
       const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || can_sub || (!s->no_stream_nd && !fasta));
       if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && kn.kernel != 2) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
-         if (mp->sdfa_state == 0 && mp->keys) {
-            seeq_dfa_t *d = seeq_dfa_plan_stream(mp->keys, mp->wlen, mp->tau, kn.no_filter ? 1 : 0);
-            mp->sdfa_state = -1;
-            if (d) {
-               const size_t bytes = (size_t)d->nrows * 16;
-               uint16_t *skip = seeq_dfa_skip_variant(d);
-               if (skip && hipMalloc((void **)&mp->d_sdfa, bytes) == hipSuccess &&
-                   hipMemcpy(mp->d_sdfa, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess &&
-                   hipMalloc((void **)&mp->d_sdfa_skip, bytes) == hipSuccess &&
-                   hipMemcpy(mp->d_sdfa_skip, skip, bytes, hipMemcpyHostToDevice) == hipSuccess) {
-                  mp->sdfa_rows = d->nrows;
-                  mp->sdfa_final_base = d->acc_final;            /* state value of ACC_NEW */
-                  mp->sdfa_parts = d->nparts;
-                  mp->sdfa_warm = d->warm;
-                  mp->sdfa_pacc = d->p_accept;
-                  mp->sdfa_state = 1;
-               }
-               free(skip);
-               seeq_dfa_free(d);
-            }
-         }
+         if (__atomic_load_n(&mp->sdfa_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_stream(mp, kn.no_filter);
          stream_ch = kn.stream_ch;
          use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
          if (fasta && (stream_ch != 128 || kn.stream_ilp1)) use_stream = false;     /* FASTA: default variant only */
@@ -1174,13 +1228,29 @@ static int run_segments(seeqdev_scan *s)
          }
       }
    }
-   const bool filter = use_stream && pat->sdfa_parts > 1;
+   /* k_pair (seeq_pair.h): the same walk, two text bytes per table step, over the pattern's pair automaton -- a prefix or a
+      partition filter, so every hit line of it is a candidate.  Read-length lines under SQ_FAIL / SQ_CONVERT (aliased bytes
+      keep a superset a superset; a skipped byte, SQ_IGNORE, does not), while it makes few false candidates. */
+   bool use_pair = false;
+   {
+      const int nd = options & MASK_NONDNA;
+      const bool long_lines = (s->avg_line > 600.0 && kn.kernel != 3) || s->force_ll;      /* (a candidate inside a line of a whole tile sets force_ll) */
+      if (fusable && s->force_path != 1 && (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || nd == SQ_CONVERT) && !long_lines && !s->no_stream &&
+          (kn.kernel == 0 || kn.kernel == 3) && kn.stream_ch == 128 && !kn.stream_ilp1 && s->seg_bytes % (64u * 128u) == 0) {
+         seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
+         if (__atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
+         use_pair = mp->pair_state == 1 && (kn.kernel == 3 || mp->pair_pacc * s->avg_line <= 0.25);
+      }
+      if (use_pair) { use_stream = true; can_sub = false; stream_ch = 128; }
+   }
+   const bool filter = use_pair || (use_stream && pat->sdfa_parts > 1);
    bool use_fused = fusable && (s->avg_line <= 260.0 || use_stream) && s->force_path != 1;      /* k_direct regions are <= 16 KiB (~62 lines) */
    uint32_t tile_bytes = 0;
    unsigned fused_grid = 1;
    int nw = 4;
    unsigned nslices = 1;                      /* hit slices: one per wave */
    int stream_wu = !use_stream ? 8 : pat->sdfa_warm <= 16 ? 4 : pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
+   if (use_pair) stream_wu = pat->pair_warm <= 16 ? 4 : (pat->pair_warm + 3) / 4;
    if (stream_wu < kn.min_wu) stream_wu = kn.min_wu >= 8 ? 8 : 6;
    const void *stream_fn = nullptr;
    bool stream_ilp2 = false, stream_ll = false;
@@ -1205,6 +1275,14 @@ static int run_segments(seeqdev_scan *s)
                                                                                                            : (const void *)k_stream<64, 8, false, false, false>);
 #undef SEEQ_STREAM_FN
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
+         if (use_pair) {
+            stream_ll = false; stream_sub = 0;
+#define SEEQ_PAIR_FN(FA) (stream_wu == 4 ? (const void *)k_pair<4, FA> : stream_wu == 5 ? (const void *)k_pair<5, FA> : stream_wu == 6 ? (const void *)k_pair<6, FA> \
+                          : stream_wu == 7 ? (const void *)k_pair<7, FA> : (const void *)k_pair<8, FA>)
+            stream_fn = fasta ? SEEQ_PAIR_FN(true) : SEEQ_PAIR_FN(false);
+#undef SEEQ_PAIR_FN
+            dfa_lds = (size_t)pat->pair_units * 16;
+         }
          int per_cu = occupancy_of(s, stream_fn, 64 * nw, dfa_lds);
          if (per_cu < 0) return -1;
          if (kn.wgs_per_cu >= 1 && kn.wgs_per_cu < per_cu) per_cu = kn.wgs_per_cu;       /* experiments: workgroups per CU */
@@ -1252,7 +1330,7 @@ static int run_segments(seeqdev_scan *s)
       }
    }
    const bool use_direct = use_fused && !use_stream;
-   s->last_path = use_fused ? (use_stream ? 5 : 3) : 1;
+   s->last_path = use_fused ? (use_pair ? 6 : use_stream ? 5 : 3) : 1;
    s->last_filter = filter;
    const bool superset = use_stream;                     /* the scan kernel's hit lines are candidates: nh[] decides */
    if (superset) need_nh = true;
@@ -1291,7 +1369,7 @@ static int run_segments(seeqdev_scan *s)
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
       a.use_nh = need_nh ? (use_stream ? 3u : 1u) : 0u;
       a.filter = filter ? 1u : 0u;
-      a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1);
+      a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1) + (use_pair ? 1u : 0u);    /* (k_pair reports the second byte of a pair) */
       a.cnt = c;
 
       if (use_fused) {
@@ -1312,6 +1390,7 @@ static int run_segments(seeqdev_scan *s)
          uint32_t pos_bias = 0;
          if (use_stream) {
             f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
+            if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = pat->pair_hit_base; f.pair = 1; }
             /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
             uint64_t room = 0xFFFFFFF0ull - a.seg_len;
             if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;

@@ -297,4 +297,191 @@ static inline seeq_dfa_t *seeq_dfa_plan_stream(const char *keys, int m, int tau,
    return NULL;
 }
 
+/* ======================================================================================================================
+ * (3) The PAIR automaton (k_pair, seeq_pair.h): two text bytes per table step.
+ *
+ * k_stream pays one LDS gather per text byte (1.375 with its warm-up), and that gather unit is what holds it.  A table
+ * indexed by (state, PAIR of bases) halves the gathers -- 16 columns of u16 per state, 32 bytes a row -- but row offsets
+ * must stay 16 bit: <= 2 047 rows.  So the walk does not carry the whole pattern but its longest PREFIX whose automaton
+ * fits (headline pattern: 17 of 20 positions, 1 840 states, 59 KB): an occurrence of the pattern with <= tau errors
+ * starts with an occurrence of the prefix with <= tau errors, so every hit line is flagged; the lines flagged are
+ * CANDIDATES (random text completes such a prefix once in 10^5 bytes) and the exact pass verifies every one -- which it
+ * does anyway whenever records are wanted.
+ *
+ * The text is taken as 2-bit codes, bits 1-2 of the byte: A 0, C 1, T/U 2, G 3 in either case.  Every other byte
+ * aliases onto one of them ('\n' -> C, N -> G): an alias can only turn a mismatch into a match, so the walk stays a
+ * superset; and there is no newline column -- the walk runs across line ends (an occurrence that spans one is one more
+ * false candidate, at the start of a line).  Acceptance RESTARTS the walk at the root instead of entering an absorbing
+ * state (which only a newline could leave): the transition that completes an occurrence leads to a flagged copy of the
+ * root row (hit at the second byte of the pair) or of the row the root reaches over the second byte (hit at the first).
+ * A state value >= hit_base therefore marks a pair in which the walk accepted; position = the pair's second byte.
+ * Superset at line level, chunked walks with a warm-up of mp + tau - 1 bytes included: see seeq_pair.h.
+ *
+ * The automaton is minimised first (partition refinement on {hit flags, successor classes} per base): the saturated
+ * columns are not a minimal automaton -- headline pattern 3 342 -> 3 198 states over A C G T -- which buys a longer
+ * prefix now and then.
+ */
+#define SEEQ_PAIR_MAX_ROWS 2047         /* row byte offsets (32 B rows) in 16 bits */
+
+typedef struct {
+   uint32_t  nstates;        /* walk states after minimisation (accepting columns are not states: restart) */
+   uint32_t  nstates_raw;    /* reachable non-accepting columns before minimisation */
+   uint32_t  nrows;          /* nstates + 5 flagged rows */
+   uint32_t  hit_base;       /* state VALUE (row byte offset) of the first flagged row */
+   int       mp;             /* positions of the pattern the walk carries (prefix) */
+   int       nparts;         /* 1: a prefix with the pattern's own threshold; > 1: partition filter (threshold floor(tau / nparts) per part) */
+   int       warm;           /* mp + tau - 1: text bytes a walk started at the root needs before it sees what the line-long walk sees */
+   double    p_accept;       /* probability that a uniformly random A/C/G/T completes a candidate */
+   uint16_t *table;          /* nrows * 16 entries: table[row * 16 + first_code * 4 + second_code] = next state value */
+} seeq_pair_t;
+
+static inline void seeq_pair_free(seeq_pair_t *d) { if (d) { free(d->table); free(d); } }
+
+static const int seeq_pair_class_of_code[4] = {0, 1, 3, 2};     /* 2-bit text code (A C T G) -> class of seeq_dfa_bfs (A C G T) */
+
+/* Mealy minimisation of the restart automaton over the four bases.  next: n * 5 (seeq_dfa_bfs; state 1 = ACC).  Writes
+ * cls[s] (class of state s; cls[1] is meaningless) and returns the number of classes of the states != 1; the root's
+ * class is 0. */
+static inline uint32_t seeq_dfa_minimise_restart(const uint32_t *next, uint32_t n, uint32_t *cls)
+{
+   uint32_t *nc = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+   uint32_t HSZ = 1024;
+   while (HSZ < 4u * n) HSZ <<= 1;
+   int32_t *hash = (int32_t *)malloc((size_t)HSZ * sizeof(int32_t));
+   uint32_t *sig = (uint32_t *)malloc((size_t)n * 5 * sizeof(uint32_t));
+   uint32_t ncls = 1;
+   if (!nc || !hash || !sig) { free(nc); free(hash); free(sig); for (uint32_t s = 0; s < n; s++) cls[s] = s; return n; }
+   for (uint32_t s = 0; s < n; s++) cls[s] = 0;
+   for (;;) {
+      /* signature of s: its class, and per base the class of the target with the hit flag in bit 31 */
+      for (uint32_t s = 0; s < n; s++) {
+         uint32_t *g = sig + (size_t)s * 5;
+         g[0] = cls[s];
+         for (int c = 0; c < 4; c++) {
+            const uint32_t t = next[(size_t)s * 5 + seeq_pair_class_of_code[c]];
+            g[1 + c] = t == 1 ? (0x80000000u | cls[0]) : cls[t];
+         }
+      }
+      memset(hash, 0xFF, (size_t)HSZ * sizeof(int32_t));
+      uint32_t k = 0;
+      for (uint32_t s = 0; s < n; s++) {                  /* classes numbered in order of first appearance: the root stays 0 */
+         if (s == 1) { nc[s] = 0; continue; }
+         const uint32_t *g = sig + (size_t)s * 5;
+         uint32_t h = 2166136261u;
+         for (int i = 0; i < 5; i++) h = (h ^ g[i]) * 16777619u;
+         uint32_t slot = h & (HSZ - 1);
+         for (;;) {
+            const int32_t e = hash[slot];
+            if (e < 0) { hash[slot] = (int32_t)s; nc[s] = k++; break; }
+            if (memcmp(sig + (size_t)e * 5, g, 5 * sizeof(uint32_t)) == 0) { nc[s] = nc[e]; break; }
+            slot = (slot + 1) & (HSZ - 1);
+         }
+      }
+      memcpy(cls, nc, (size_t)n * sizeof(uint32_t));
+      if (k == ncls) break;
+      ncls = k;
+   }
+   free(nc); free(hash); free(sig);
+   return ncls;
+}
+
+/* The pair table of a restart automaton given as seeq_dfa_bfs_parts() output (n states, state 1 = ACC; consumed), or
+ * NULL when it has more than SEEQ_PAIR_MAX_ROWS rows after minimisation.  `shortest` = the shortest part: the byte after
+ * a restart must not accept on its own, i.e. shortest - t >= 2. */
+static inline seeq_pair_t *seeq_pair_from_next(uint32_t *next, uint32_t n, int rounds)
+{
+   seeq_pair_t *d = NULL;
+   uint32_t *cls = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+   uint32_t *rep = NULL;
+   if (cls) {
+      const uint32_t k = seeq_dfa_minimise_restart(next, n, cls);
+      if (k + 5 <= SEEQ_PAIR_MAX_ROWS) {
+         d = (seeq_pair_t *)calloc(1, sizeof *d);
+         rep = (uint32_t *)malloc((size_t)k * sizeof(uint32_t));          /* class -> a state of it */
+         if (d) d->table = (uint16_t *)malloc((size_t)(k + 5) * 16 * sizeof(uint16_t));
+         if (!d || !rep || !d->table) { if (d) free(d->table); free(d); d = NULL; }
+      }
+      if (d) {
+         d->nstates = k; d->nstates_raw = n - 1; d->nrows = k + 5; d->hit_base = k * 32;
+         d->p_accept = seeq_dfa_accept_rate(next, n, rounds);
+         for (uint32_t s = n; s-- > 0;) if (s != 1) rep[cls[s]] = s;
+         /* one step of the restart automaton from class q over code c: *hit set when it accepts (then back at the root) */
+#define SEEQ_PAIR_STEP(q, c, hit) (next[(size_t)rep[q] * 5 + seeq_pair_class_of_code[c]] == 1 ? ((hit) = 1, 0u) : cls[next[(size_t)rep[q] * 5 + seeq_pair_class_of_code[c]]])
+         for (uint32_t r = 0; r < d->nrows; r++) {
+            /* rows k .. k+3: flagged copies of the row the root reaches over code r - k; row k+4: flagged copy of the root row */
+            int dummy = 0;
+            const uint32_t q = r < k ? r : (r < k + 4 ? SEEQ_PAIR_STEP(0u, (int)(r - k), dummy) : 0u);
+            (void)dummy;                                     /* (every part is >= t + 2 long: one byte from the root never accepts) */
+            for (int c1 = 0; c1 < 4; c1++)
+               for (int c2 = 0; c2 < 4; c2++) {
+                  int h1 = 0, h2 = 0;
+                  const uint32_t s1 = SEEQ_PAIR_STEP(q, c1, h1);
+                  const uint32_t s2 = SEEQ_PAIR_STEP(s1, c2, h2);
+                  const uint32_t row = h2 ? k + 4 : (h1 ? k + (uint32_t)c2 : s2);
+                  d->table[(size_t)r * 16 + (size_t)(c1 * 4 + c2)] = (uint16_t)(row * 32);
+               }
+         }
+#undef SEEQ_PAIR_STEP
+      }
+   }
+   free(rep); free(cls); free(next);
+   return d;
+}
+
+/* The pair automaton of the first `mp` positions (threshold tau), or NULL when it does not fit. */
+static inline seeq_pair_t *seeq_pair_build_prefix(const char *keys, int mp, int tau)
+{
+   if (mp < tau + 2) return NULL;
+   uint32_t *next = NULL;
+   const uint32_t n = seeq_dfa_bfs(keys, mp, tau, &next);
+   if (!n) return NULL;
+   seeq_pair_t *d = seeq_pair_from_next(next, n, 4 * mp + 64);
+   if (d) { d->mp = mp; d->nparts = 1; d->warm = mp + tau - 1; }
+   return d;
+}
+
+/* The pair automaton of the partition filter of k parts (seeq_dfa_build_filter), or NULL. */
+static inline seeq_pair_t *seeq_pair_build_filter(const char *keys, int m, int tau, int k)
+{
+   int cut[SEEQ_DFA_MAX_PARTS + 1];
+   if (k < 2 || k > SEEQ_DFA_MAX_PARTS || k > m) return NULL;
+   for (int p = 0; p <= k; p++) cut[p] = (int)((long)p * m / k);
+   const int t = tau / k;
+   int longest = 0, shortest = m;
+   for (int p = 0; p < k; p++) {
+      const int len = cut[p + 1] - cut[p];
+      if (len > longest) longest = len;
+      if (len < shortest) shortest = len;
+   }
+   if (shortest < t + 2) return NULL;
+   uint32_t *next = NULL;
+   const uint32_t n = seeq_dfa_bfs_parts(keys, cut, k, t, &next);
+   if (!n) return NULL;
+   seeq_pair_t *d = seeq_pair_from_next(next, n, 4 * m + 64);
+   if (d) { d->mp = m; d->nparts = k; d->warm = longest + t - 1; }
+   return d;
+}
+
+/* What k_pair should walk for this pattern: among the longest prefix (>= tau + 2 positions) whose pair automaton fits
+ * and the partition filters of 2 .. tau + 1 parts, the one that makes the fewest false candidates, warm-up within 32
+ * bytes; NULL: none. */
+static inline seeq_pair_t *seeq_pair_plan(const char *keys, int m, int tau)
+{
+   seeq_pair_t *best = NULL;
+   if (m > 62) return NULL;
+   for (int mp = tau + 2; mp <= m && mp + tau - 1 <= 32; mp++) {
+      seeq_pair_t *d = seeq_pair_build_prefix(keys, mp, tau);
+      if (!d) break;                                        /* (sizes grow with the prefix: the first that does not fit ends the search) */
+      seeq_pair_free(best);
+      best = d;
+   }
+   for (int k = 2; k <= SEEQ_DFA_MAX_PARTS && k <= tau + 1; k++) {
+      seeq_pair_t *d = seeq_pair_build_filter(keys, m, tau, k);
+      if (!d) continue;
+      if (d->warm <= 32 && (!best || d->p_accept < best->p_accept)) { seeq_pair_free(best); best = d; }
+      else seeq_pair_free(d);
+   }
+   return best;
+}
+
 #endif

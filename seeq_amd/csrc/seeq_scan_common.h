@@ -45,7 +45,8 @@ struct FusedArgs {
    uint32_t      *wg_lastnl;   /* k_stream, per wave: segment-relative offset + 1 of the last newline it saw (0: none); else NULL */
    const uint16_t *dfa;        /* k_stream: transition table, dfa_rows x 8 u16 (seeq_dfa.h) */
    uint32_t       dfa_rows;
-   uint32_t       dfa_final_base;   /* row offset of ACC_FINAL; DEAD_FINAL = +16 */
+   uint32_t       dfa_final_base;   /* k_stream: state value of ACC_NEW; k_pair: state values >= this are flagged rows */
+   uint32_t       pair;             /* 1: k_pair (two bytes per step; everything it reports is a candidate) */
    Counters      *cnt;
 };
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_fused_post(FusedArgs a, uint32_t nslice
       flags = s_flags[0] | s_flags[1] | s_flags[2] | s_flags[3];
       if (flags & 1u) {
          c->dirty |= 1u;
-         if (a.options & MASK_NONDNA) c->overflow |= 16u;     /* SQ_CONVERT / SQ_IGNORE: k_stream is only exact on clean text -> re-run */
+         if ((a.options & MASK_NONDNA) && !a.pair) c->overflow |= 16u;     /* SQ_CONVERT / SQ_IGNORE: k_stream is only exact on clean text -> re-run (k_pair's candidates are verified anyway) */
       }
       if (flags & 4u) {
          c->dirty |= 1u;                                      /* skip bytes in a warm-up window / a NUL: the hit lines are candidates */

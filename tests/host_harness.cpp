@@ -180,3 +180,40 @@ extern "C" long harness_dfa_filter(const uint8_t *text, size_t n, const char *ke
    seeq_dfa_free(d);
    return (long)ne;
 }
+
+// ---- the pair automaton of k_pair (seeq_dfa.h section 3, seeq_pair.h) ----
+// Emulates the kernel's decomposition on the host: every `chain`-byte chain of the text (64 in the kernel) is walked on
+// its own from the root state, two bytes per step (2-bit codes = bits 1-2 of the byte), after a warm-up over the
+// `warm_bytes` bytes before it ('\n' where the buffer starts or has ended; 0 = the automaton's own warm-up rounded up to
+// whole words).  A step that lands on a flagged row inside the owned chain reports the position of the pair's second
+// byte; a flagged row met during the warm-up reports the chain's second byte (the made-up candidate of seeq_pair.h).
+// info[0..5] = states, states before minimisation, prefix length, warm-up bytes, accept rate * 1e9, parts.
+// Returns the number of events (positions in out[], ascending), -1 when no pair automaton fits.
+extern "C" long harness_pair_walk(const uint8_t *text, size_t n, const char *keys, int m, int tau, int chain, int warm_bytes,
+                                  uint64_t *out, size_t cap, uint32_t *info)
+{
+   seeq_pair_t *d = seeq_pair_plan(keys, m, tau);
+   if (!d) return -1;
+   if (info) { info[0] = d->nstates; info[1] = d->nstates_raw; info[2] = (uint32_t)d->mp; info[3] = (uint32_t)d->warm; info[4] = (uint32_t)(d->p_accept * 1e9); info[5] = (uint32_t)d->nparts; }
+   const long long W = warm_bytes > 0 ? warm_bytes : 4 * ((d->warm + 3) / 4);
+   size_t ne = 0;
+   for (size_t c0 = 0; c0 < n; c0 += (size_t)chain) {
+      uint32_t state = 0;
+      bool warm_flag = false;
+      for (long long p = (long long)c0 - W; p < (long long)c0 + chain && p < (long long)n; p += 2) {
+         const uint8_t b1 = p < 0 ? (uint8_t)'\n' : text[p];
+         const uint8_t b2 = (p + 1 < 0 || p + 1 >= (long long)n) ? (uint8_t)'\n' : text[p + 1];
+         state = d->table[(state >> 1) + (uint32_t)(((b1 >> 1) & 3) * 4 + ((b2 >> 1) & 3))];
+         const bool flagged = state >= d->hit_base;
+         if (p < (long long)c0) { warm_flag |= flagged; continue; }
+         const bool report = flagged || (p == (long long)c0 && warm_flag);
+         if (report) {
+            const uint64_t pos = (uint64_t)(p + 1 < (long long)n ? p + 1 : (long long)n - 1);
+            if (ne < cap) out[ne] = pos;
+            ne++;
+         }
+      }
+   }
+   seeq_pair_free(d);
+   return (long)ne;
+}

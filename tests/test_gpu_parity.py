@@ -114,10 +114,11 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
     """One batched scan through the device C-ABI.  path: 'generic' (newline index + k_forward<W>),
     'fused' = k_direct (one line per lane, text in registers), 'fused-stream' = k_stream (transition table in LDS:
     the pattern's complete automaton or a partition filter; k_direct when neither fits; `tile` is the chunk size
-    per lane), or 'auto' (the library's own choice); the env knobs are read when the scan context is created."""
+    per lane), 'fused-pair' = k_pair (two bytes per table step over the pattern's pair automaton, selective or not;
+    k_stream / k_direct where it does not apply: SQ_IGNORE), or 'auto' (the library's own choice); the env knobs are read when the scan context is created."""
     from seeq_amd import device as dev
     if path != "auto":
-        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream"}.get(path, "direct")
+        os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream", "fused-pair": "pair"}.get(path, "direct")
     if tile and path == "fused-stream":
         os.environ["SEEQ_STREAM_CH"] = str(tile)
     elif tile:
@@ -142,7 +143,7 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
 
 
 @pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024),
-                                       ("fused-stream", None), ("fused-stream", 64)])
+                                       ("fused-stream", None), ("fused-stream", 64), ("fused-pair", None)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
                                               ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3),
@@ -163,6 +164,8 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
                 assert got["kernel"] == "k_stream" and got["filter"]      # configs[4]: partition filter automaton
             if path == "fused":
                 assert got["kernel"] == "k_direct"
+            if path == "fused-pair" and nd != SQ_IGNORE and fusable:
+                assert got["kernel"] == "k_pair" and got["filter"]      # every pattern here has a pair automaton
             assert got["nlines"] == exp["nlines"]
             assert got["nmatchlines"] == exp["nmatchlines"]
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (name, mo, nd)
@@ -174,7 +177,7 @@ def test_batch_scan_vs_oracle(gpu, capi, oracle, name, pattern, tau, path, tile)
         assert c2["nhits"] == len(expa["records"]) and c2["nlines"] == expa["nlines"]
 
 
-@pytest.mark.parametrize("path", ["generic", "fused", "fused-stream", "auto"])
+@pytest.mark.parametrize("path", ["generic", "fused", "fused-stream", "fused-pair", "auto"])
 def test_edge_buffers(gpu, capi, oracle, path):
     """Empty / ragged / maximum-ish inputs: no trailing newline, empty lines, NUL and CR bytes, a line longer
     than the LDS window (fused: falls back to the HBM per-line scan), 70 k empty lines (fused: many passes
@@ -730,7 +733,7 @@ for dirty in (False, True):
         for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
             exp = o.buffer_scan(pat, 3, buf, opt)
             got = sc.scan_host(p, buf, opt, dev.WANT_RECORDS)
-            assert sc.last_kernel() == "k_stream", sc.last_kernel()
+            assert sc.last_kernel() in ("k_stream", "k_pair"), sc.last_kernel()
             assert got["nlines"] == exp["nlines"], (dirty, opt, got["nlines"], exp["nlines"])
             assert got["nmatchlines"] == exp["nmatchlines"], (dirty, opt, got["nmatchlines"], exp["nmatchlines"])
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, opt)
@@ -750,7 +753,7 @@ for dirty in (False, True):
                 # (the 128-byte-chunk variant walks a corrected copy under SQ_CONVERT; under SQ_IGNORE it does on read-length
                 #  input -- this buffer's average line is long, so there a non-DNA byte sends the scan to a per-line kernel)
                 if not dirty or (nd == dev.SQ_CONVERT and %d == 128):
-                    assert sc.last_kernel() == "k_stream", (dirty, nd, sc.last_kernel())
+                    assert sc.last_kernel() in ("k_stream", "k_pair"), (dirty, nd, sc.last_kernel())
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (dirty, nd, opt)
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, nd, opt)
             sc.close(); p.close()
@@ -773,7 +776,7 @@ for tail in ("\n", ""):
         exp = o.buffer_scan(pat, 3, buf, opt, fasta=True)
         got = sc.scan_host(p, buf, opt | dev.SEEQDEV_FASTA, dev.WANT_RECORDS)
         if %d == 128:
-            assert sc.last_kernel() == "k_stream", sc.last_kernel()
+            assert sc.last_kernel() in ("k_stream", "k_pair"), sc.last_kernel()
         assert got["nlines"] == exp["nlines"], ("fasta", opt, got["nlines"], exp["nlines"])
         assert got["nmatchlines"] == exp["nmatchlines"], ("fasta", opt, got["nmatchlines"], exp["nmatchlines"])
         assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), ("fasta", opt)
@@ -793,10 +796,12 @@ print("OK")
         assert r.returncode == 0 and "OK" in r.stdout, (seg, r.stdout[-500:], r.stderr[-2000:])
 
 
-def test_stream_fuzz_patterns(gpu, capi, oracle):
+@pytest.mark.parametrize("path", ["auto", "fused-stream", "fused-pair"])
+def test_stream_fuzz_patterns(gpu, capi, oracle, path):
     """Random patterns (1..26 positions, N and [..] classes, every distance k_stream takes) over random reads with
     planted mutated copies, N, lower case and a few non-DNA bytes: FIRST/BEST/ALL records and both counts through
-    the library's own kernel choice (k_stream whenever the automaton fits) against the oracle."""
+    the library's own kernel choice (k_pair while its candidates stay few, k_stream whenever the automaton fits), through
+    k_stream alone and through k_pair wherever the pattern has a pair automaton, however unselective, against the oracle."""
     from seeq_amd import device as dev
     rng = random.Random(2025)
     kernels = {}
@@ -833,16 +838,22 @@ def test_stream_fuzz_patterns(gpu, capi, oracle):
         buf = ("\n".join(lines) + ("\n" if it % 2 else "")).encode()
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
             exp = oracle.buffer_scan(pattern, tau, buf, mo)
-            got = _scan(capi, pattern, tau, buf, mo, dev.WANT_RECORDS)
+            got = _scan(capi, pattern, tau, buf, mo, dev.WANT_RECORDS, False, path)
             kernels[got["kernel"]] = kernels.get(got["kernel"], 0) + 1
             assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, tau, mo)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, mo)
         expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL)
-        c1 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTLINES)
-        c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH)
+        c1 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTLINES, False, path)
+        c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH, False, path)
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], (pattern, tau)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau)
-    assert kernels.get("k_stream", 0) >= 60, kernels          # the automaton path really is what ran, mostly
+    # the table walks really are what ran, mostly
+    if path == "fused-pair":
+        assert kernels.get("k_pair", 0) >= 60, kernels
+    elif path == "fused-stream":
+        assert kernels.get("k_stream", 0) >= 60 and not kernels.get("k_pair"), kernels
+    else:
+        assert kernels.get("k_stream", 0) + kernels.get("k_pair", 0) >= 60 and kernels.get("k_pair", 0) >= 10, kernels
 
 
 def test_device_pointer_alignment(gpu, capi, oracle):
@@ -864,7 +875,7 @@ def test_device_pointer_alignment(gpu, capi, oracle):
             for mo in (SQ_BEST, SQ_ALL):
                 exp = oracle.buffer_scan(PAT20, 3, host, mo)
                 got = sc.scan_tensor(pat, view, mo, dev.WANT_RECORDS)
-                assert sc.last_kernel() == "k_stream"
+                assert sc.last_kernel() in ("k_stream", "k_pair")
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (off, cut, mo)
                 assert np.array_equal(sc.records(got["nrecords"]).astype(np.uint64), exp["records"]), (off, cut, mo)
     sc.close()
@@ -899,7 +910,7 @@ def test_long_lines_window_walk(gpu, capi, oracle):
     for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
         exp = oracle.buffer_scan(pat, tau, buf, mo)
         got = _scan(capi, pat, tau, buf, mo, dev.WANT_RECORDS)
-        assert got["kernel"] == "k_stream"
+        assert got["kernel"] in ("k_stream", "k_pair")
         assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], mo
         assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), mo
     expa = oracle.buffer_scan(pat, tau, buf, SQ_ALL)
@@ -923,7 +934,7 @@ def test_long_lines_window_walk(gpu, capi, oracle):
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
             exp = oracle.buffer_scan(pat, tau, b2, mo, fasta=fasta)
             got = _scan(capi, pat, tau, b2, mo, dev.WANT_RECORDS, fasta)
-            assert got["kernel"] == "k_stream"
+            assert got["kernel"] in ("k_stream", "k_pair")
             assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (fasta, mo)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (fasta, mo)
         expa = oracle.buffer_scan(pat, tau, b2, SQ_ALL, fasta=fasta)
@@ -951,7 +962,7 @@ def test_every_byte_value_alone(gpu, capi, oracle):
                 # SQ_FAIL: flagged tiles -> candidates verified; SQ_CONVERT: walked over a corrected copy; SQ_IGNORE: the same
                 # with skip bytes, unless most lines become candidates (here every line holds the byte): then the per-line kernel
                 if nd != SQ_IGNORE:
-                    assert sc.last_kernel() == "k_stream", (b, nd)
+                    assert sc.last_kernel() in ("k_stream", "k_pair"), (b, nd)
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (b, nd, opt)
                 if want == dev.WANT_RECORDS:
                     assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (b, nd, opt)
@@ -995,7 +1006,7 @@ def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle)
                 exp = oracle.buffer_scan(pattern, tau, buf, opt | nd)
                 got = sc.scan_host(pat, buf, opt | nd, dev.WANT_RECORDS)
                 if nd != SQ_IGNORE or not heavy:
-                    assert sc.last_kernel() == "k_stream", (pattern, nd, heavy, sc.last_kernel())
+                    assert sc.last_kernel() in ("k_stream", "k_pair"), (pattern, nd, heavy, sc.last_kernel())
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, nd, opt)
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, nd, opt)
             expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL | nd)
@@ -1113,7 +1124,7 @@ def test_mixed_reads_and_long_line(gpu, capi, oracle):
     for mo in (SQ_BEST, SQ_ALL):
         exp = oracle.buffer_scan(PAT20, 3, buf, mo)
         got = _scan(capi, PAT20, 3, buf, mo, dev.WANT_RECORDS)
-        assert got["kernel"] == "k_stream"
+        assert got["kernel"] in ("k_stream", "k_pair")
         assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], mo
         assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), mo
 
@@ -1196,7 +1207,7 @@ def test_filter_automaton_patterns(gpu, capi, oracle):
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], (pattern, tau)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau)
         if ci in (0, 1, 3):        # (the 20-mer at distance 4 only has a filter of 10-mers with 2 errors: not selective -> k_direct)
-            assert got["kernel"] == "k_stream" and got["filter"], (pattern, tau, got["kernel"])
+            assert got["kernel"] in ("k_stream", "k_pair") and got["filter"], (pattern, tau, got["kernel"])
     assert nfilter >= 15, nfilter
 
 

@@ -225,3 +225,91 @@ def test_filter_automaton_is_a_superset(harness, oracle):
                 extra = len(got - want)
                 assert extra <= len(lines) // 3 - len(want) + 5 + 6 * (info[3] * 1e-9) * len(buf), (pat, tau, extra, info[3])
     assert seen_filter >= 8
+
+
+def _pair_events(harness, buf, keys, m, tau, chain=64, warm=0):
+    import ctypes as C
+    harness.harness_pair_walk.restype = C.c_long
+    harness.harness_pair_walk.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    out = np.zeros(1 << 17, dtype=np.uint64)
+    info = (C.c_uint32 * 6)()
+    ne = harness.harness_pair_walk(buf, len(buf), bytes(keys), m, tau, chain, warm, out.ctypes.data, out.size, info)
+    return ne, out[:max(ne, 0)], list(info)
+
+
+def test_pair_automaton_is_a_superset_and_its_first_candidate_bounds_the_scan(harness, oracle):
+    """Host side of k_pair (seeq_dfa.h section 3): the pair automaton of the pattern's longest prefix that fits, walked
+    two bytes per step in 64-byte chains with the kernel's warm-up and restart-on-accept, over text where every byte
+    outside A C G T aliases onto a base (newline -> C, N -> G):
+      (1) every line the oracle finds a hit in gets a candidate (position of a pair's second byte; the line is the one
+          that byte lies in, a newline belonging to the line it ends);
+      (2) the exact pass may start m + tau columns before a line's FIRST candidate: the oracle over that suffix reports
+          the same hits (shifted) as over the whole line -- for SQ_ALL, hence for every match option."""
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(2026)
+    cases = [("GATGTAGCGCGATTAGCCTG", 3), ("GATTAGC", 1), ("CACAGAT", 3), ("ACGT", 1), ("AC", 0), ("ACNNGT[AC]TTG", 2),
+             ("GATGTAGCGCGATTAGCCTGAAAATG", 2), ("TTTTTTTT", 2), ("GATGTAGCGCGATTAG", 4), ("GATGTAGCGCGATTAGCCTGAAAA", 3),
+             ("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5), ("AAAAAAAAAAAAAAAAAAAA", 3), ("ACGTACGTACGTACGT", 2)]
+    for _ in range(8):
+        m = rng.choice([6, 12, 20, 31, 45])
+        pat = "".join("N" if rng.random() < 0.05 else "[" + "".join(rng.sample("ACGT", 2)) + "]" if rng.random() < 0.08
+                      else rng.choice("ACGT") for _ in range(m))
+        cases.append((pat, rng.randint(0, min(5, m - 2))))
+    nwalked = 0
+    for pat, tau in cases:
+        keys, _ = oracle.parse(pat)
+        m = len(keys)
+        core = plain(pat)
+        lines = []
+        for i in range(500):
+            n = rng.choice([0, 1, 3, 20, 60, 150, 151, 400])
+            t = "".join(rng.choice("ACGT") for _ in range(n))
+            if i % 2 == 0 and n >= m:
+                cp = mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
+                q = rng.choice([0, 0, max(0, n - len(cp)), rng.randrange(max(1, n - len(cp) + 1))])   # also flush with either end of the line
+                t = (t[:q] + cp + t[q + len(cp):])[:n]
+            if i % 17 == 0 and n:
+                q = rng.randrange(n)
+                t = t[:q] + "N" + t[q + 1:]
+            lines.append(t.lower() if i % 29 == 0 else t)
+        if len(set(core)) <= 2:
+            # periodic patterns: occurrences overlap and follow each other across line ends, so walks restart inside their
+            # warm-up windows -- runs of the pattern's own bases, m - tau - 1 .. m + 2 long, at either end of short lines
+            lines = []
+            for i in range(3000):
+                unit = core[:2] if len(set(core)) == 2 else core[:1]
+                run = (unit * m)[:rng.randint(max(1, m - tau - 1), m + 2)]
+                junk = lambda k: "".join(rng.choice("ACGT") for _ in range(k))
+                lines.append(rng.choice([run + junk(rng.randint(0, 50)), junk(rng.randint(0, 50)) + run,
+                                         run, junk(rng.randint(0, 30)) + run + junk(rng.randint(0, 30))]))
+        buf = ("\n".join(lines) + ("\n" if rng.random() < 0.5 else "")).encode()
+        exp = oracle.buffer_scan(pat, tau, buf, SQ_ALL)
+        want = {}
+        for ln, st, en, di in exp["records"]:
+            want.setdefault(int(ln), []).append((int(st), int(en), int(di)))
+        starts = np.cumsum([0] + [len(x) + 1 for x in lines])            # byte offset of every line
+        for chain, warm in ((64, 0), (64, 32), (16, 0)):
+            ne, ev, info = _pair_events(harness, buf, keys, m, tau, chain, warm)
+            if ne < 0:
+                continue                                   # no prefix of >= tau + 2 positions fits: another kernel serves the pattern
+            nwalked += 1
+            assert info[0] + 5 <= 2047 and info[0] <= info[1] and tau + 2 <= info[2] <= m and info[3] <= 32
+            assert info[5] > 1 or info[3] == info[2] + tau - 1
+            first = {}
+            for p in ev:
+                p = int(p)
+                ln = int(np.searchsorted(starts, p, side="right"))        # 1-based; a newline at p belongs to the line it ends
+                first.setdefault(ln, p - int(starts[ln - 1]))
+            missing = sorted(set(want) - set(first))
+            assert not missing, (pat, tau, chain, warm, missing[:5])
+            for ln, hits in want.items():
+                col = first[ln]
+                pos = max(0, col - (m + tau))
+                line = lines[ln - 1]
+                sub = oracle.string_match(pat, tau, line[pos:], SQ_ALL)[::-1]
+                assert [(s + pos, e + pos, d) for s, e, d in sub] == hits, (pat, tau, chain, ln, col, pos)
+        if (pat, tau) == ("GATGTAGCGCGATTAGCCTG", 3):
+            assert info[2] == 17 and info[1] == 1839, info
+    assert nwalked >= 40
