@@ -650,7 +650,6 @@ struct seeqdev_pattern {
    int       pair_state;     /* the pair automaton of k_pair (seeq_dfa.h section 3): 0 not tried, 1 built, -1 none fits */
    uint16_t *d_pair;         /* its table in HBM (32-byte rows), staged into LDS by k_pair */
    uint32_t  pair_units;     /* 16-byte units of the table (2 per row) */
-   uint32_t  pair_hit_base;  /* state values >= this are flagged rows */
    uint32_t  pair_states;
    int       pair_parts, pair_mp, pair_warm;
    double    pair_pacc;      /* probability that a random DNA character completes a candidate */
@@ -758,12 +757,11 @@ static void pattern_plan_pair(seeqdev_pattern *mp)
       int state = -1;
       seeq_pair_t *d = seeq_pair_plan(mp->keys, mp->wlen, mp->tau);
       if (d) {
-         const size_t bytes = (size_t)d->nrows * 32;
+         const size_t bytes = d->table_bytes;
          uint16_t *t0 = nullptr;
          if (hipMalloc((void **)&t0, bytes) == hipSuccess && hipMemcpy(t0, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess) {
             mp->d_pair = t0;
-            mp->pair_units = d->nrows * 2;
-            mp->pair_hit_base = d->hit_base;
+            mp->pair_units = d->table_bytes / 16;
             mp->pair_states = d->nstates;
             mp->pair_parts = d->nparts; mp->pair_mp = d->mp; mp->pair_warm = d->warm;
             mp->pair_pacc = d->p_accept;
@@ -791,6 +789,7 @@ struct ScanKnobs {
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
+   int  pair_exp;        /* SEEQ_PAIR_EXP=2..4: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -910,6 +909,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       v = getenv("SEEQ_STREAM_WU");    kn.min_wu = v ? atoi(v) : 0;
+      v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
       s->ncu = 256;
       int dev = 0;
       hipDeviceProp_t prop;
@@ -1277,9 +1277,11 @@ static int run_segments(seeqdev_scan *s)
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          if (use_pair) {
             stream_ll = false; stream_sub = 0;
-#define SEEQ_PAIR_FN(FA) (stream_wu == 4 ? (const void *)k_pair<4, FA> : stream_wu == 5 ? (const void *)k_pair<5, FA> : stream_wu == 6 ? (const void *)k_pair<6, FA> \
-                          : stream_wu == 7 ? (const void *)k_pair<7, FA> : (const void *)k_pair<8, FA>)
+#define SEEQ_PAIR_FN(...) (stream_wu == 4 ? (const void *)k_pair<4, __VA_ARGS__> : stream_wu == 5 ? (const void *)k_pair<5, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_pair<6, __VA_ARGS__> \
+                          : stream_wu == 7 ? (const void *)k_pair<7, __VA_ARGS__> : (const void *)k_pair<8, __VA_ARGS__>)
             stream_fn = fasta ? SEEQ_PAIR_FN(true) : SEEQ_PAIR_FN(false);
+            if (!fasta && stream_wu == 5 && kn.pair_exp >= 2 && kn.pair_exp <= 4)       /* experiments (profiles/r03): timing only */
+               stream_fn = kn.pair_exp == 2 ? (const void *)k_pair<5, false, 2> : kn.pair_exp == 3 ? (const void *)k_pair<5, false, 3> : (const void *)k_pair<5, false, 4>;
 #undef SEEQ_PAIR_FN
             dfa_lds = (size_t)pat->pair_units * 16;
          }
@@ -1390,7 +1392,7 @@ static int run_segments(seeqdev_scan *s)
          uint32_t pos_bias = 0;
          if (use_stream) {
             f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
-            if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = pat->pair_hit_base; f.pair = 1; }
+            if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
             /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
             uint64_t room = 0xFFFFFFF0ull - a.seg_len;
             if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;

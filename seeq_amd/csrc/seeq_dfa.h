@@ -314,7 +314,8 @@ static inline seeq_dfa_t *seeq_dfa_plan_stream(const char *keys, int m, int tau,
  * false candidate, at the start of a line).  Acceptance RESTARTS the walk at the root instead of entering an absorbing
  * state (which only a newline could leave): the transition that completes an occurrence leads to a flagged copy of the
  * root row (hit at the second byte of the pair) or of the row the root reaches over the second byte (hit at the first).
- * A state value >= hit_base therefore marks a pair in which the walk accepted; position = the pair's second byte.
+ * Flagged rows have ODD state values (they are stored one byte late): bit 0 of the state marks a pair in which the walk
+ * accepted -- one v_alignbit per step shifts it into the chain's mask; position = the pair's second byte.
  * Superset at line level, chunked walks with a warm-up of mp + tau - 1 bytes included: see seeq_pair.h.
  *
  * The automaton is minimised first (partition refinement on {hit flags, successor classes} per base): the saturated
@@ -327,12 +328,15 @@ typedef struct {
    uint32_t  nstates;        /* walk states after minimisation (accepting columns are not states: restart) */
    uint32_t  nstates_raw;    /* reachable non-accepting columns before minimisation */
    uint32_t  nrows;          /* nstates + 5 flagged rows */
-   uint32_t  hit_base;       /* state VALUE (row byte offset) of the first flagged row */
+   uint32_t  table_bytes;    /* nrows * 32 + 16 (the flagged rows sit one byte late), a multiple of 16 */
    int       mp;             /* positions of the pattern the walk carries (prefix) */
    int       nparts;         /* 1: a prefix with the pattern's own threshold; > 1: partition filter (threshold floor(tau / nparts) per part) */
-   int       warm;           /* mp + tau - 1: text bytes a walk started at the root needs before it sees what the line-long walk sees */
+   int       warm;           /* text bytes a walk started at the root needs before it sees what the line-long walk sees */
    double    p_accept;       /* probability that a uniformly random A/C/G/T completes a candidate */
-   uint16_t *table;          /* nrows * 16 entries: table[row * 16 + first_code * 4 + second_code] = next state value */
+   uint8_t  *table;          /* state VALUE = byte offset of the state's row: 32 * row for a walk state, 32 * row + 1 for a
+                                flagged row (bit 0 of a state value IS the flag; 16-bit reads at odd LDS addresses are
+                                byte-exact on gfx950: profiles/microbench/lds_unaligned_u16.hip).  The u16 at
+                                table[value + 2 * (4 * first_code + second_code)] is the next state value. */
 } seeq_pair_t;
 
 static inline void seeq_pair_free(seeq_pair_t *d) { if (d) { free(d->table); free(d); } }
@@ -398,15 +402,16 @@ static inline seeq_pair_t *seeq_pair_from_next(uint32_t *next, uint32_t n, int r
       if (k + 5 <= SEEQ_PAIR_MAX_ROWS) {
          d = (seeq_pair_t *)calloc(1, sizeof *d);
          rep = (uint32_t *)malloc((size_t)k * sizeof(uint32_t));          /* class -> a state of it */
-         if (d) d->table = (uint16_t *)malloc((size_t)(k + 5) * 16 * sizeof(uint16_t));
+         if (d) { d->table_bytes = (k + 5) * 32 + 16; d->table = (uint8_t *)calloc(d->table_bytes, 1); }
          if (!d || !rep || !d->table) { if (d) free(d->table); free(d); d = NULL; }
       }
       if (d) {
-         d->nstates = k; d->nstates_raw = n - 1; d->nrows = k + 5; d->hit_base = k * 32;
+         d->nstates = k; d->nstates_raw = n - 1; d->nrows = k + 5;
          d->p_accept = seeq_dfa_accept_rate(next, n, rounds);
          for (uint32_t s = n; s-- > 0;) if (s != 1) rep[cls[s]] = s;
          /* one step of the restart automaton from class q over code c: *hit set when it accepts (then back at the root) */
 #define SEEQ_PAIR_STEP(q, c, hit) (next[(size_t)rep[q] * 5 + seeq_pair_class_of_code[c]] == 1 ? ((hit) = 1, 0u) : cls[next[(size_t)rep[q] * 5 + seeq_pair_class_of_code[c]]])
+#define SEEQ_PAIR_VALUE(row) ((row) < k ? (row) * 32u : (row) * 32u + 1u)
          for (uint32_t r = 0; r < d->nrows; r++) {
             /* rows k .. k+3: flagged copies of the row the root reaches over code r - k; row k+4: flagged copy of the root row */
             int dummy = 0;
@@ -418,9 +423,11 @@ static inline seeq_pair_t *seeq_pair_from_next(uint32_t *next, uint32_t n, int r
                   const uint32_t s1 = SEEQ_PAIR_STEP(q, c1, h1);
                   const uint32_t s2 = SEEQ_PAIR_STEP(s1, c2, h2);
                   const uint32_t row = h2 ? k + 4 : (h1 ? k + (uint32_t)c2 : s2);
-                  d->table[(size_t)r * 16 + (size_t)(c1 * 4 + c2)] = (uint16_t)(row * 32);
+                  const uint16_t val = (uint16_t)SEEQ_PAIR_VALUE(row);
+                  memcpy(d->table + SEEQ_PAIR_VALUE(r) + 2u * (uint32_t)(c1 * 4 + c2), &val, 2);
                }
          }
+#undef SEEQ_PAIR_VALUE
 #undef SEEQ_PAIR_STEP
       }
    }

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       seeqdev_hit_t *out = nullptr;
       uint32_t out_cap = 0, line_no = 0;
       uint32_t ce0 = 0, ce1 = 0, ncached = 0;                         /* {end, dist} of the first emission -- COUNT: what goes to the cache; EMIT: what came from it */
+      uint32_t cstart = 0, chas = 0;                                  /* EMIT: the cached record's start, when COUNT recovered it */
       bool from_cache = false;
       if (MODE == SQ_MODE_EMIT && !done) {
          line_no = a.hit_line[k];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          if (cache_ok) {
             ncached = (k + 1 < nhl ? a.nh[k + 1] : c->seg_nrec) - a.nh[k];
             if (ncached <= 1 || !ovf_lost) {               /* the first record from the cache, the others from the overflow list */
-               if (ncached) { const uint4 ce = cache[k]; ce0 = ce.x; ce1 = ce.y; }
+               if (ncached) { const uint4 ce = cache[k]; ce0 = ce.x; ce1 = ce.y; cstart = ce.z; chas = ce.w; }
                from_cache = true;
                done = true;
             }
@@ -398,7 +399,11 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          if (MODE == SQ_MODE_COUNT) {
             if (count_best) { nhits = best_d < tau1 ? 1u : 0u; ce0 = best_end; ce1 = best_d; }
             a.nh[k] = nhits;
-            if (caching) cache[k] = make_uint4(ce0, ce1, 0u, 0u);
+            /* one record per line at most (SQ_BEST / SQ_FIRST): its start is recovered here, where the line has just been
+               scanned (its bytes are in L1 / L2 and the lane's LDS row is free), and EMIT only copies {start, end, dist} */
+            uint32_t ce2 = 0, ce3 = 0;
+            if (caching && count_any && nhits) { ce2 = exact1_reverse<W>(a.text, off, a.nbytes, ce0, ce1, eqr_base, m, tau1, row); ce3 = 1u; }
+            if (caching) cache[k] = make_uint4(ce0, ce1, ce2, ce3);
          } else if (match_opt == SQ_BEST && !from_cache) {
             if (best_d < tau1) {
                seeqdev_hit_t h;
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                h.line = line_no;
                if (from_cache) { h.end = ce0; h.dist = ce1; }
                else { h.end = out[i].end; h.dist = out[i].dist; }      /* (written by this lane, above) */
-               h.start = exact1_reverse<W>(a.text, off, a.nbytes, h.end, h.dist, eqr_base, m, tau1, row);
+               h.start = (from_cache && chas) ? cstart : exact1_reverse<W>(a.text, off, a.nbytes, h.end, h.dist, eqr_base, m, tau1, row);
                out[i] = h;
                a.rec_off[(out - a.records) + i] = off;     /* byte offset of the record's line (seeqdevScanCopyOffsets) */
             }

@@ -13,12 +13,18 @@
  *     the SDWA v_xor of k_stream picks them: address = state ^ t.BYTE_1 / BYTE_3.  Every other byte aliases onto a base
  *     ('\n' -> C, N -> G, anything else -> whatever its bits say): an alias only turns mismatches into matches.
  *   - There is no newline column and no absorbing state: the walk runs across line ends and RESTARTS at the root when
- *     it accepts (the accepting transition leads to a flagged copy of the row it restarts in: state >= hit_base marks the
- *     pair; v_cmp + v_addc shift the flag into a mask of 32 pairs = one 64-byte chain).
+ *     it accepts (the accepting transition leads to a flagged copy of the row it restarts in; flagged rows have odd state
+ *     values, so one v_alignbit per step shifts the flag into a mask of 32 pairs = one 64-byte chain).
  *   - Two chains per lane (bytes 0-63 / 64-127) as in k_stream, each warmed up over the 4 * WU >= warm bytes before it.
  *     A walk that accepts DURING its warm-up restarts there and may then miss an occurrence that ends in its own first
  *     bytes (the restart sits inside it) while the flag is somebody else's position -- possibly on the line before: such
- *     a chain reports its own first pair as a candidate (v_max over the warm-up states, one compare at the end).
+ *     a lane reports the first pair of its chains as candidates (the warm-up states OR-ed together, bit 0 tested once).
+ *   - What else a tile needs from its text -- the alphabet check and the newline masks -- is computed word by word
+ *     BETWEEN a step's two gathers and the instructions that need their results, i.e. in the shadow of the LDS latency
+ *     the walk is made of (fast check: upper case A C G T N and newlines only -- v_perm + v_sad_u8 per word; a tile that
+ *     fails it takes the exact check of k_stream over its text fetched again; newline flags: v_perm + v_dot4 per word).
+ *     With the gathers halved the kernel is no longer held by the LDS unit (57 % busy, of which half bank conflicts) but
+ *     runs within 15 % of what the memory system delivers for this access pattern.
  *
  * Why every line with a hit gets a candidate, and why the exact pass may start m + tau columns before a line's FIRST
  * candidate (tests/test_kernel_core_host.py::test_pair_automaton_... checks both on the host against the oracle):
@@ -40,16 +46,13 @@
 #ifndef SEEQ_PAIR_H_
 #define SEEQ_PAIR_H_
 
-/* one pair of each chain: address = state ^ pair index (byte K of the prepared word), then the gather */
+/* one pair of each chain: address = state ^ pair index (byte K of the prepared word), then the gathers -- both out before
+ * anything else (left alone the scheduler walks the chains one after the other) */
 #define PAIR_X2(K) \
    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K : "=v"(ada) : "v"(sa), "v"(ta)); \
    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K : "=v"(adb) : "v"(sb), "v"(tb)); \
-   sa = *(stream_lds_cu16 *)(uintptr_t)ada; sb = *(stream_lds_cu16 *)(uintptr_t)adb; \
-   __builtin_amdgcn_sched_barrier(0);              /* both gathers go out together (left alone the scheduler walks the chains one after the other) */
-/* flagged row? -> shifted into the chain's pair mask (first pair ends up in bit 31) */
-#define PAIR_EV2 \
-   asm("v_cmp_ge_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hma) : "v"(sa), "v"(hit_base) : "vcc"); \
-   asm("v_cmp_ge_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hmb) : "v"(sb), "v"(hit_base) : "vcc");
+   if (EXP != 2) { sa = *(stream_lds_cu16 *)(uintptr_t)ada; sb = *(stream_lds_cu16 *)(uintptr_t)adb; } else { sa = ada & 0x7FE0u; sb = adb & 0x7FE0u; } \
+   __builtin_amdgcn_sched_barrier(0);
 
 /* the two pair indices of a text word, in bytes 1 and 3: {code of the first byte, code of the second} << 1 */
 __device__ __forceinline__ uint32_t pair_prep(uint32_t w)
@@ -58,21 +61,53 @@ __device__ __forceinline__ uint32_t pair_prep(uint32_t w)
    return u | (u << 10);
 }
 
-/* four warm-up bytes of each chain: walk, and remember the largest state seen (a flagged row is >= hit_base) */
-__device__ __forceinline__ void pair_warm4x2(uint32_t &sa, uint32_t wa, uint32_t &xa, uint32_t &sb, uint32_t wb, uint32_t &xb)
+/* Per text word, in the shadow of a gather: the FAST alphabet check -- the canonical byte of the word's table columns
+ * (A C T G . \n . N, upper case) against the word, differences summed by v_sad_u8: zero over a tile = nothing but upper
+ * case A C G T N and newlines (anything else, lower case included, sends the tile through the exact check) -- and the
+ * newline flags of the word (column 5), dropped into the mask by v_dot4_u32_u8 (two words per shift). */
+__device__ __forceinline__ void pair_chk(uint32_t w, uint32_t &bad, uint32_t &nm, bool first_of_two)
 {
-   const uint32_t ta = pair_prep(wa), tb = pair_prep(wb);
-   uint32_t ada, adb;
-   PAIR_X2(1) xa = sa > xa ? sa : xa; xb = sb > xb ? sb : xb;
-   PAIR_X2(3) xa = sa > xa ? sa : xa; xb = sb > xb ? sb : xb;
+   const uint32_t idx = (w >> 1) & 0x07070707u;
+   bad = __builtin_amdgcn_sad_u8(w, __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx), bad);
+   const uint32_t nf = __builtin_amdgcn_perm(0x00000100u, 0u, idx);
+   nm = first_of_two ? __builtin_amdgcn_udot4(nf, 0x10204080u, nm << 8, false) : __builtin_amdgcn_udot4(nf, 0x01020408u, nm, false);
 }
 
-/* four owned bytes of each chain: walk + pair mask */
-__device__ __forceinline__ void pair_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t hit_base)
+/* four warm-up bytes of each chain: walk; the states are OR-ed into `seen` (bit 0: the walk accepted) */
+template <int EXP>
+__device__ __forceinline__ void pair_warm4x2(uint32_t &sa, uint32_t wa, uint32_t &sb, uint32_t wb, uint32_t &seen)
 {
    const uint32_t ta = pair_prep(wa), tb = pair_prep(wb);
    uint32_t ada, adb;
-   PAIR_X2(1) PAIR_EV2 PAIR_X2(3) PAIR_EV2
+   /* (asm: as plain C the chain of ORs is re-associated into a tree evaluated after the warm-up, with every state kept -- spilled -- until then) */
+   PAIR_X2(1) asm("v_or3_b32 %0, %0, %1, %2" : "+v"(seen) : "v"(sa), "v"(sb));
+   PAIR_X2(3) asm("v_or3_b32 %0, %0, %1, %2" : "+v"(seen) : "v"(sa), "v"(sb));
+}
+
+/* four owned bytes of each chain: walk + pair masks (first pair of a chain ends up in bit 0), and the per-word checks of
+ * both words between the gathers and their use */
+template <int EXP>
+__device__ __forceinline__ void pair_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &nma, uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t &nmb,
+                                            uint32_t &bad, bool first_of_two)
+{
+   const uint32_t ta = pair_prep(wa), tb = pair_prep(wb);
+   uint32_t ada, adb;
+   /* (the empty volatile asm statements pin the side-effect-free work where it is written: without them it is all moved
+      behind the walk, with every state and every intermediate kept -- spilled -- until then) */
+   PAIR_X2(1)
+   asm volatile("" : "+v"(wa));
+   if (EXP != 4) pair_chk(wa, bad, nma, first_of_two);
+   asm volatile("" : "+v"(bad), "+v"(nma));
+   __builtin_amdgcn_sched_barrier(0);
+   hma = __builtin_amdgcn_alignbit(sa, hma, 1); hmb = __builtin_amdgcn_alignbit(sb, hmb, 1);
+   asm volatile("" : "+v"(hma), "+v"(hmb));
+   PAIR_X2(3)
+   asm volatile("" : "+v"(wb));
+   if (EXP != 4) pair_chk(wb, bad, nmb, first_of_two);
+   asm volatile("" : "+v"(bad), "+v"(nmb));
+   __builtin_amdgcn_sched_barrier(0);
+   hma = __builtin_amdgcn_alignbit(sa, hma, 1); hmb = __builtin_amdgcn_alignbit(sb, hmb, 1);
+   asm volatile("" : "+v"(hma), "+v"(hmb));
 }
 
 /* word k (0..7) of the 32 bytes held in two 16-byte pieces */
@@ -81,8 +116,19 @@ __device__ __forceinline__ uint32_t pair_word8(const fused_v4u &p, const fused_v
    return k == 0 ? p.x : k == 1 ? p.y : k == 2 ? p.z : k == 3 ? p.w : k == 4 ? q.x : k == 5 ? q.y : k == 6 ? q.z : q.w;
 }
 
+/* 16 bytes of text at byte `off` of the buffer (bytes at or beyond `lim` read as '\n': only the segment's last tile) */
+__device__ __forceinline__ fused_v4u pair_load16(const FusedArgs &a, uint64_t off, uint64_t lim, bool partial)
+{
+   if (!partial) return *reinterpret_cast<const fused_v4u_unaligned *>(a.text + off);
+   return dfa_load16(a.text, off, lim);
+}
+
+typedef uint32_t pair_u32_unaligned __attribute__((aligned(1)));
+
 /* WU: warm-up dwords (4 .. 8); FA: FASTA input (header lines: see k_stream) */
-template <int WU, bool FA>
+/* EXP (profiles/r03, SEEQ_PAIR_EXP: timing only, the results are void): 0 the kernel; 2 no LDS gathers; 3 no bookkeeping;
+ * 4 no per-word checks -- what each part of the kernel costs */
+template <int WU, bool FA, int EXP = 0>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
@@ -99,7 +145,6 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       for (uint32_t i = tid; i < a.dfa_rows; i += 64 * NW) reinterpret_cast<fused_v4u *>(dsmem)[i] = src[i];
    }
    __syncthreads();                                       /* the only barrier: the table is read-only from here */
-   const uint32_t hit_base = a.dfa_final_base;             /* state values >= this are flagged rows (seeq_pair_from_next) */
 
    const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
    uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0;    /* wave-uniform */
@@ -109,61 +154,91 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
    const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
    const uint64_t last = a.nbytes - 1;
 
-   for (uint32_t tile = gwave; tile < a.ntiles; tile += nwaves) {
+   /* persistent grid: wave w of the grid takes tiles w, w + waves, ....  (Requesting the next tile's text early was tried
+      three ways -- piece by piece into the registers the walk has passed, all of it right after the walk, double-buffered
+      in 128 registers at half the occupancy: 1.06 / 0.92 / 0.81 ms per launch against 0.78 without.  A lane's eight
+      pieces lie inside one 128-byte line and only loads issued back to back are merged into one fetch of it; and with
+      every load behind a wave-uniform branch awaited where the branch ends, or a spilled value reloaded through the same
+      in-order counter, the early request waits anyway.  Without the bookkeeping the kernel runs at 0.645 ms = 6.2 TB/s,
+      what a plain read sweep reaches: DESIGN.md section 5.) */
+   fused_v4u v[NQ];
+   uint32_t halo = 0;                                     /* lanes 0..7: the eight words before the tile (lane 0's warm-up comes from them) */
+   uint32_t tile = gwave;
+   while (tile < a.ntiles) {
       const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;
+      const bool partial = tile + 1 == a.ntiles && (a.seg_len % TB) != 0;
+      const uint32_t next = tile + nwaves;
       uint32_t lane_off = (uint32_t)lane * CH;
       asm volatile("" : "+v"(lane_off));                  /* (see k_stream: keeps the per-lane 64-bit addresses out of the loop-invariant set) */
       const uint64_t my = t0 + lane_off;
-      const bool partial = tile + 1 == a.ntiles && (a.seg_len % TB) != 0;
-      fused_v4u v[NQ];
-      if (!partial) {
-         const uint8_t *p = a.text + my;
-#pragma unroll
-         for (int q = 0; q < NQ; q++) v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * q);
-      } else {
-#pragma unroll
-         for (int q = 0; q < NQ; q++) v[q] = dfa_load16(a.text, my + 16 * q, lim);       /* '\n' beyond the segment */
-      }
-      /* the 32 bytes before the tile (lane 0's warm-up); '\n' when the buffer starts here */
-      fused_v4u pa = fused_v4u{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}, pb = pa;
-      if (t0 >= 32) {
-         pa = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 32);
-         pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
-      }
-      /* ---- alphabet check (a byte that could end a line early: the exact pass then starts at the line's first byte) ---- */
-      bool tile_clean;
       {
-         uint32_t bad = 0;
+         if (!partial) {                                  /* (all nine in one block, back to back: the eight pieces are merged into one fetch of each 128-byte line) */
+            const uint8_t *p = a.text + my;
 #pragma unroll
-         for (int q = 0; q < NQ; q++) bad |= fused_bad4(v[q].x) | fused_bad4(v[q].y) | fused_bad4(v[q].z) | fused_bad4(v[q].w);
-         uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(bad != 0) != 0 ? 1 : 0);
-         asm volatile("" : "+s"(flag));
-         wv_dirty |= flag;
-         tile_clean = flag == 0;
+            for (int q = 0; q < NQ; q++) v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(p + 16 * q);
+            /* lanes 0..7: the eight words before the tile ('\n' where the buffer starts: chosen where they are used); the lane's
+               offset is made afresh from its id -- kept alive from the top of the kernel it is spilled, and the reload waits for
+               every load in flight */
+            uint32_t lid;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+            halo = *reinterpret_cast<const pair_u32_unaligned *>(a.text + (t0 >= 32 ? t0 - 32 : 0) + ((lid & 7u) << 2));
+         } else {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) v[q] = dfa_load16(a.text, my + 16 * q, lim);       /* '\n' beyond the segment */
+            const fused_v4u h0 = dfa_load16(a.text, t0 >= 32 ? t0 - 32 : 0, lim), h1 = dfa_load16(a.text, t0 >= 32 ? t0 - 16 : 0, lim);
+            halo = pair_word8(h0, h1, 0);
+#pragma unroll
+            for (int k = 1; k < 8; k++) halo = (lane & 7) == k ? pair_word8(h0, h1, k) : halo;
+         }
       }
-      /* ---- the walk: chain A = bytes 0..63 (warm-up: the previous lane's last bytes), chain B = bytes 64..127 ---- */
-      uint32_t hm[2];
+      const bool halo_nl = t0 < 32;                       /* the buffer starts here: lane 0 warms up over newlines */
+      /* ---- the walk: chain A = bytes 0..63 (warm-up: the previous lane's last bytes), chain B = bytes 64..127; the
+              alphabet check and the newline masks ride along ---- */
+      uint32_t hm[2], nmask[NM];
+      uint32_t tile_bad;
       {
-         uint32_t sa = 0, sb = 0, xa = 0, xb = 0, hma = 0, hmb = 0;
+         uint32_t sa = 0, sb = 0, hma = 0, hmb = 0, seen = 0, bad = 0, nma = 0, nmb = 0;
 #pragma unroll
          for (int k = 8 - WU; k < 8; k++)
-            pair_warm4x2(sa, stream_from_prev_lane(pair_word8(v[NQ - 2], v[NQ - 1], k), pair_word8(pa, pb, k)), xa,
-                         sb, pair_word8(v[NQ / 2 - 2], v[NQ / 2 - 1], k), xb);
+            pair_warm4x2<EXP>(sa, stream_from_prev_lane(pair_word8(v[NQ - 2], v[NQ - 1], k), halo_nl ? 0x0A0A0A0Au : (uint32_t)__builtin_amdgcn_readlane((int)halo, k)),
+                         sb, pair_word8(v[NQ / 2 - 2], v[NQ / 2 - 1], k), seen);
 #pragma unroll
          for (int q = 0; q < NQ / 2; q++) {
-            pair_own4x2(sa, v[q].x, hma, sb, v[q + NQ / 2].x, hmb, hit_base);
-            pair_own4x2(sa, v[q].y, hma, sb, v[q + NQ / 2].y, hmb, hit_base);
-            pair_own4x2(sa, v[q].z, hma, sb, v[q + NQ / 2].z, hmb, hit_base);
-            pair_own4x2(sa, v[q].w, hma, sb, v[q + NQ / 2].w, hmb, hit_base);
+            pair_own4x2<EXP>(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, bad, true);
+            pair_own4x2<EXP>(sa, v[q].y, hma, nma, sb, v[q + NQ / 2].y, hmb, nmb, bad, false);
+            pair_own4x2<EXP>(sa, v[q].z, hma, nma, sb, v[q + NQ / 2].z, hmb, nmb, bad, true);
+            pair_own4x2<EXP>(sa, v[q].w, hma, nma, sb, v[q + NQ / 2].w, hmb, nmb, bad, false);
+            if (q & 1) { nmask[q >> 1] = nma; nmask[(q >> 1) + NM / 2] = nmb; nma = 0; nmb = 0; }
          }
-         /* accepted during the warm-up: my first pair is a candidate (see the header) */
-         hm[0] = hma | (xa >= hit_base ? 0x80000000u : 0u);
-         hm[1] = hmb | (xb >= hit_base ? 0x80000000u : 0u);
+         tile_bad = bad;
+         /* first pair of a chain in bit 31; a walk that accepted during its warm-up: my first pairs are candidates (see the header) */
+         const uint32_t fake = (seen & 1u) << 31;
+         hm[0] = __builtin_bitreverse32(hma) | fake;
+         hm[1] = __builtin_bitreverse32(hmb) | fake;
       }
-      /* ---- newline masks, apart from the walk ---- */
-      uint32_t nmask[NM];
+      if (EXP == 3) {
+         wv_hitlines += (uint32_t)__popc(hm[0] ^ hm[1] ^ nmask[0] ^ nmask[1] ^ nmask[2] ^ nmask[3]) + tile_bad;
+         tile = next;
+         continue;
+      }
+      /* the fast check failed somewhere in the tile (wave-uniform): the exact alphabet check and the exact newline masks, over
+         the tile's text fetched again piece by piece (its registers hold the next tile by now) */
+      if (__builtin_amdgcn_readfirstlane(__ballot(tile_bad != 0) != 0 ? 1 : 0)) {
+         uint32_t b2 = 0;
+#pragma unroll 1
+         for (int q = 0; q < NQ; q++) {
+            const fused_v4u x = pair_load16(a, my + 16 * q, lim, partial);
+            b2 |= fused_bad4(x.x) | fused_bad4(x.y) | fused_bad4(x.z) | fused_bad4(x.w);
+         }
+         uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(b2 != 0) != 0 ? 1 : 0);
+         asm volatile("" : "+s"(flag));
+         wv_dirty |= flag;                                /* a byte that could end a line early: the exact pass then starts at the line's first byte */
 #pragma unroll
-      for (int r = 0; r < NM; r++) nmask[r] = stream_nl_mask32(v[2 * r], v[2 * r + 1], tile_clean);
+         for (int r = 0; r < NM; r++) {
+            const fused_v4u x = pair_load16(a, my + 32 * r, lim, partial), y = pair_load16(a, my + 32 * r + 16, lim, partial);
+            nmask[r] = stream_nl_mask32(x, y, flag == 0);
+         }
+      }
       /* ---- bookkeeping: what the tile owns ---- */
       uint32_t valid = CH;                                /* bytes of my chunk inside the segment */
       if (partial) {
@@ -187,6 +262,26 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
 #pragma unroll
             for (int r = 0; r < NM; r++)
                if ((pos >> 5) == (uint32_t)r) nmask[r] &= ~(0x80000000u >> (pos & 31));
+         }
+      }
+      /* A chain that flags one line several times (the walk restarts when it accepts: every part of a partition filter
+         reports on its own) keeps the first flag per line only: of the flags before the chain's first newline and of those
+         behind its last one, the first; between two newlines (short lines) all of them.  Only the first candidate of a
+         line matters to the exact pass; every further one is a hit-list entry with nothing to do.  Wave-uniform, rare on
+         read-length lines with a prefix automaton, the rule with a partition filter. */
+      if (__ballot(((hm[0] & (hm[0] - 1u)) | (hm[1] & (hm[1] - 1u))) != 0)) {
+#pragma unroll
+         for (int x = 0; x < 2; x++) {
+            const uint32_t n0 = nmask[2 * x], n1 = nmask[2 * x + 1], h = hm[x];
+            /* first / last newline of the chain as byte offsets (64: none); pair q = bit 31 - q, its second byte = 2q + 1 */
+            const uint32_t f = n0 ? (uint32_t)__builtin_clz(n0) : (n1 ? 32u + (uint32_t)__builtin_clz(n1) : 64u);
+            const uint32_t l = n1 ? 63u - (uint32_t)__builtin_ctz(n1) : (n0 ? 31u - (uint32_t)__builtin_ctz(n0) : 64u);
+            const uint32_t na = f >= 64u ? 32u : (f + 1u) >> 1;           /* pairs whose second byte is not behind the first newline */
+            const uint32_t sc = f >= 64u ? 32u : (l + 1u) >> 1;           /* first pair whose second byte is behind the last newline */
+            const uint32_t ma = na >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> na);
+            const uint32_t mc = sc >= 32u ? 0u : 0xFFFFFFFFu >> sc;
+            const uint32_t ha = h & ma, hc = h & mc & ~ma;
+            hm[x] = (h & ~ma & ~mc) | (ha ? 0x80000000u >> (uint32_t)__builtin_clz(ha) : 0u) | (hc ? 0x80000000u >> (uint32_t)__builtin_clz(hc) : 0u);
          }
       }
       uint32_t lane_nl = 0;
@@ -272,6 +367,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       wv_lines += tot_n + extra;
       wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;
+      tile = next;
    }
    if (lane == 0) {
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
@@ -283,6 +379,5 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
 }
 
 #undef PAIR_X2
-#undef PAIR_EV2
 
 #endif

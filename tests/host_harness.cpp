@@ -203,8 +203,10 @@ extern "C" long harness_pair_walk(const uint8_t *text, size_t n, const char *key
       for (long long p = (long long)c0 - W; p < (long long)c0 + chain && p < (long long)n; p += 2) {
          const uint8_t b1 = p < 0 ? (uint8_t)'\n' : text[p];
          const uint8_t b2 = (p + 1 < 0 || p + 1 >= (long long)n) ? (uint8_t)'\n' : text[p + 1];
-         state = d->table[(state >> 1) + (uint32_t)(((b1 >> 1) & 3) * 4 + ((b2 >> 1) & 3))];
-         const bool flagged = state >= d->hit_base;
+         uint16_t nxt;
+         memcpy(&nxt, d->table + state + 2u * (uint32_t)(((b1 >> 1) & 3) * 4 + ((b2 >> 1) & 3)), 2);      /* (the kernel: state ^ index -- the same, index bits 1-4 are free in a state value) */
+         state = nxt;
+         const bool flagged = (state & 1u) != 0;
          if (p < (long long)c0) { warm_flag |= flagged; continue; }
          const bool report = flagged || (p == (long long)c0 && warm_flag);
          if (report) {
