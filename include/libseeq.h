@@ -79,7 +79,7 @@ struct seeq_t {
    void    * rdfa;
 };
 
-/* reference libseeq.h:82-86 (only used by the dead merge code below). */
+/* reference libseeq.h:82-86 (the match-stack utilities below). */
 struct mstack_t {
    size_t  size;
    size_t  pos;
@@ -94,9 +94,8 @@ char       * seeqGetString   (seeq_t * sq);
 long         seeqStringMatch (const char * data, seeq_t * sq, int options);
 const char * seeqPrintError  (void);
 int          seeqAddMatch    (seeq_t * sq, match_t match);
-/* reference libseeq.h:96-100: exported by the reference although its only
- * call sites are commented out (libseeq.c:231-234,340-343).  Kept for link
- * compatibility. */
+/* reference libseeq.h:96-100: match-stack utilities (the reference's own call
+ * sites are commented out, libseeq.c:231-234,340-343; they work here as there). */
 mstack_t   * stackNew        (size_t size);
 int          stackAddMatch   (mstack_t ** stackp, match_t match);
 int          recursive_merge (size_t start, size_t end, int tau, seeq_t * sq, mstack_t ** stackp);

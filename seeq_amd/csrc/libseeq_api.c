@@ -220,15 +220,51 @@ const char *seeqPrintError(void)
    return seeq_messages[seeqerr];
 }
 
-/* ---- dead API of the reference (libseeq.c:355-424; its only call site is commented out, libseeq.c:340):
- * exported so that objects built against libseeq.h still link, nothing more.  Every call fails with ENOSYS. ---- */
-mstack_t *stackNew(size_t size) { (void)size; seeqerr = 0; errno = ENOSYS; return NULL; }
+/* ---- the match-stack utilities of the reference (libseeq.c:355-424).  The reference itself no longer calls them (its
+ * only call site is commented out, libseeq.c:340), but libseeq.h declares them, so a caller of the drop-in may: they
+ * work as the reference's do (tests/test_capi_host.py compares them with the reference's on random stacks). ---- */
+mstack_t *stackNew(size_t size)
+{
+   if (size < 1) size = 1;
+   mstack_t *st = malloc(sizeof(mstack_t) + size * sizeof(match_t));
+   if (!st) return NULL;
+   st->size = size;
+   st->pos = 0;
+   return st;
+}
 
-int stackAddMatch(mstack_t **stackp, match_t match) { (void)stackp; (void)match; seeqerr = 0; errno = ENOSYS; return -1; }
+int stackAddMatch(mstack_t **stackp, match_t match)
+{
+   mstack_t *st = *stackp;
+   if (st->pos >= st->size) {
+      const size_t newsize = 2 * st->size;
+      mstack_t *grown = realloc(st, sizeof(mstack_t) + newsize * sizeof(match_t));
+      if (!grown) return -1;
+      *stackp = st = grown;
+      st->size = newsize;
+   }
+   st->match[st->pos++] = match;
+   return 0;
+}
 
+/* One stack per distance (stackp[0 .. sq->tau], each holding matches in text order): moves into sq->match, right to left,
+ * the matches inside [start, end) that do not overlap a match of a smaller distance -- level `tau` first, the gaps
+ * between its matches handed to level tau + 1 (reference libseeq.c:355-390). */
 int recursive_merge(size_t start, size_t end, int tau, seeq_t *sq, mstack_t **stackp)
 {
-   (void)start; (void)end; (void)tau; (void)sq; (void)stackp;
-   seeqerr = 0; errno = ENOSYS;
-   return -1;
+   if (tau > sq->tau) return 0;
+   mstack_t *st = stackp[tau];
+   size_t hi = end;
+   /* matches that reach beyond the interval are dropped.  (The reference reads match[pos-1] once more after its pos has
+      reached 0 -- one element in front of the array; here the loop stops at the bottom.) */
+   while (st->pos > 0 && st->match[st->pos - 1].end > end) st->pos--;
+   while (st->pos > 0) {
+      const match_t top = st->match[st->pos - 1];
+      if (start > top.start) break;
+      if (recursive_merge(top.end, hi, tau + 1, sq, stackp)) return -1;      /* the gap to the right of it */
+      hi = top.start;
+      st->pos--;
+      if (seeqAddMatch(sq, top)) return -1;
+   }
+   return recursive_merge(start, hi, tau + 1, sq, stackp);
 }

@@ -506,8 +506,12 @@ static int pump(fstate_t *s, seeq_engine_t *eng, const seeq_t *sq, int dev_opt, 
       pthread_mutex_unlock(&s->mu);
       /* (only this thread moves chunks out of FILLED and back; the reader only touches FREE chunks) */
       slot_t *head = &s->slot[s->head % (unsigned long)s->nslots];
-      if (s->head < filled && head->state == SL_READY &&
-          (head->eng_id != eng->id || head->opt_key != dev_opt || head->want != want)) set_state(s, head, SL_FILLED);   /* scanned for another pattern / option set */
+      /* The head chunk was scanned (or is being scanned) for another pattern / option set / kind of result: so were the
+         chunks read ahead behind it.  Wait for the scans in flight and forget all of them -- resetting the head alone left
+         it FILLED with every lane busy on chunks nobody would ever collect, and this thread asleep for good (found by the
+         advisor, round 2; tests/host_driver.c section 2b). */
+      if (s->head < filled && (head->state == SL_READY || head->state == SL_SCANNING) &&
+          (head->eng_id != eng->id || head->opt_key != dev_opt || head->want != want)) quiesce(s);
       for (unsigned long seq = s->head; seq < filled; seq++) {
          const int idx = (int)(seq % (unsigned long)s->nslots);
          slot_t *sl = &s->slot[idx];

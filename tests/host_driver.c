@@ -83,6 +83,50 @@ int main(int argc, char **argv)
    f = seeqOpen(path);
    if ((rv = seeqFileMatch(f, sq[1], 0, SQ_COUNTMATCH)) != nhits_all) return fail("SQ_COUNTMATCH", rv, nhits_all);
    seeqClose(f);
+   /* 2b. the SAME engine, match option switched every 7 lines (SQ_BEST / SQ_ALL) while read-ahead scans made for the other
+      option are in flight on every lane; then the file option switched (SQ_MATCH -> SQ_ANY -> SQ_COUNTLINES: `want` of the
+      scans changes) in the middle of the file */
+   f = seeqOpen(path);
+   if (!f) return fail("seeqOpen", 1, seeqerr);
+   n = 0;
+   for (;;) {
+      const int mo = (n / 7) % 2 ? SQ_ALL : SQ_BEST;
+      const long rv2 = seeqFileMatch(f, sq[1], mo, SQ_ANY);
+      if (rv2 <= 0) break;
+      n++;
+      if (f->line != n) return fail("2b line number", (long)f->line, (long)n);
+      orc_match_t exp[256];
+      const long ne = orc_string_match(lines[n - 1], keys[1], m[1], taus[1], mo, exp, 256);
+      if ((long)sq[1]->hits != ne) return fail("2b hits", (long)sq[1]->hits, ne);
+      for (long k = 0; k < ne; k++)
+         if (sq[1]->match[k].start != exp[k].start || sq[1]->match[k].end != exp[k].end || sq[1]->match[k].dist != exp[k].dist)
+            return fail("2b match", (long)n, k);
+   }
+   if (n != nlines) return fail("2b lines replayed", (long)n, (long)nlines);
+   seeqClose(f);
+   f = seeqOpen(path);
+   {
+      size_t at = 0;                                     /* lines consumed so far */
+      long first_match = -1;
+      for (size_t i = 0; i < nlines && first_match < 0; i++) {
+         orc_match_t e[256];
+         if (orc_string_match(lines[i], keys[1], m[1], taus[1], SQ_FIRST, e, 256) > 0) first_match = (long)i;
+      }
+      if (first_match >= 0) {
+         if (seeqFileMatch(f, sq[1], SQ_FIRST, SQ_MATCH) != 1) return fail("2b SQ_MATCH", 0, 0);
+         if ((long)f->line != first_match + 1) return fail("2b SQ_MATCH line", (long)f->line, first_match + 1);
+         at = (size_t)first_match + 1;
+      }
+      for (int i = 0; i < 3 && at < nlines; i++, at++)
+         if (seeqFileMatch(f, sq[1], SQ_ALL, SQ_ANY) != 1 || f->line != at + 1) return fail("2b SQ_ANY after SQ_MATCH", (long)f->line, (long)at + 1);
+      long rest = 0;
+      for (size_t i = at; i < nlines; i++) {
+         orc_match_t e[256];
+         rest += orc_string_match(lines[i], keys[1], m[1], taus[1], SQ_FIRST, e, 256) > 0;
+      }
+      if ((rv = seeqFileMatch(f, sq[1], 0, SQ_COUNTLINES)) != rest) return fail("2b SQ_COUNTLINES after SQ_ANY", rv, rest);
+   }
+   seeqClose(f);
    /* 3. close in the middle: read-ahead scans are in flight */
    f = seeqOpen(path);
    for (int i = 0; i < 5; i++) (void)seeqFileMatch(f, sq[1], SQ_ALL, SQ_ANY);

@@ -101,3 +101,23 @@ def test_cli_argument_errors(capi):
     assert r.returncode == 1 and "No output will be generated" in r.stderr
     r = run("-c")
     assert r.returncode == 1 and "not enough arguments" in r.stderr
+
+
+def test_match_stack_utilities_vs_reference_vectors(capi):
+    """stackNew / stackAddMatch / recursive_merge (libseeq.h; reference libseeq.c:355-424): host-only utilities that a
+    caller of the drop-in may use although the reference itself no longer does.  300 random stacks per distance, merged by
+    the reference (tests/golden/make_stack_golden.py): the same sq->match, in the same order, and the same leftovers."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_stack_golden as G
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_stack_cases.json")))
+    assert len(cases) == 300
+    L = G.bind(C.CDLL(capi.LIB_PATH))
+    libc = C.CDLL(None)
+    nm = 0
+    for c in cases:
+        merged, left = G.run_case(L, libc, c)
+        assert merged == c["merged"] and left == c["left"], c
+        nm += len(merged)
+    assert nm > 1000

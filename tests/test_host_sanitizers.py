@@ -117,9 +117,13 @@ def test_file_api_sequences_under_sanitizers(kind):
     """tests/host_driver.c: pattern / option switch in the middle of a file, the engine freed before the file, all file
     options, a file closed while scans are in flight -- against the oracle, under the sanitizers."""
     exe = _build(kind, os.path.join(ROOT, "tests", "host_driver.c"), "host_driver")
-    for env in ({"SEEQ_CHUNK_BYTES": "300"}, {"SEEQ_CHUNK_BYTES": "5000", "SEEQ_LANES": "3", "FAKE_SEEQ_DEVICES": "2", "SEEQ_DEVICES": "0,1"},
-                {}):
-        r = _run(exe, [os.path.join(GOLDEN, "reads_small.txt")], env, text=True)
+    # (one lane and tiny chunks: every read-ahead scan is in flight when the options change -- the configuration in which
+    #  seeqFileMatch once slept for good; four fake devices listed out of order: one pattern copy per device, all freed
+    #  when the engine goes before the file)
+    for env in ({"SEEQ_CHUNK_BYTES": "300"}, {"SEEQ_CHUNK_BYTES": "300", "SEEQ_LANES": "1"},
+                {"SEEQ_CHUNK_BYTES": "5000", "SEEQ_LANES": "3", "FAKE_SEEQ_DEVICES": "2", "SEEQ_DEVICES": "0,1"},
+                {"SEEQ_CHUNK_BYTES": "2000", "SEEQ_LANES": "2", "FAKE_SEEQ_DEVICES": "4", "SEEQ_DEVICES": "3,0,2"}, {}):
+        r = _run(exe, [os.path.join(GOLDEN, "reads_small.txt")], env, text=True, timeout=600)
         if kind == "tsan" and "unexpected memory mapping" in r.stderr:
             pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
         assert r.returncode == 0 and r.stdout.strip() == "OK", (env, r.stdout[-500:], r.stderr[-3000:])

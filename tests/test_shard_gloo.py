@@ -36,7 +36,7 @@ def _scan_shard(kind, buf, opt, fasta=False):
     pat = dev.Pattern(PAT, TAU)
     sc = dev.Scanner()
     res = sc.scan_host(pat, bytes(buf), opt | (dev.SEEQDEV_FASTA if fasta else 0), dev.WANT_RECORDS)
-    assert sc.last_kernel() in ("k_stream", "k_direct")
+    assert sc.last_kernel() in ("k_pair", "k_stream", "k_direct")
     sc.close()
     pat.close()
     return res
