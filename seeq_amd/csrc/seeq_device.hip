@@ -857,6 +857,9 @@ struct seeqdev_scan {
    bool no_stream;             /* k_stream met a line it cannot address (starts > 1 GiB before its segment): use the per-line kernels */
    bool force_ll;              /* a read-length looking buffer had hits inside very long lines: use k_stream's long-line variant */
    bool no_stream_nd;          /* SQ_CONVERT / SQ_IGNORE: the text has non-DNA bytes, k_stream (exact for clean text only) is off */
+   int  fallback_ttl;          /* scans left before the three fall-back flags above are dropped and the fast path is tried again (one text with a
+                                  long line or foreign bytes must not slow a long-lived context down for good) */
+   unsigned sample_age;        /* runs since the line-length sample was taken (a reused buffer may hold other text by now) */
 };
 
 static int ws_alloc(void **p, size_t bytes)
@@ -1520,6 +1523,7 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
    if (use_device(s->device)) return -1;
    s->pat = pat; s->text = d_text; s->nbytes = nbytes; s->options = options; s->want = want;
    s->ran = false;
+   if ((s->no_stream || s->no_stream_nd || s->force_ll) && --s->fallback_ttl <= 0) s->no_stream = s->no_stream_nd = s->force_ll = false;
    /* Optimistic default workspace: lines average >= 32 bytes, one line in 8 hits, 1 record per hit line.
       A too-small workspace is detected on the device and fixed by one re-run in seeqdevScanFetch. */
    const size_t seg = nbytes < s->seg_bytes ? nbytes : s->seg_bytes;
@@ -1537,7 +1541,8 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
    /* Average line length (tile sizing of the fused kernel): caller's hint, else a 64 KiB sample. */
    if (s->line_hint > 0) {
       s->avg_line = s->line_hint;
-   } else if (!(options & SEEQDEV_SINGLELINE) && nbytes && (s->avg_text != d_text || s->avg_nbytes != nbytes)) {
+   } else if (!(options & SEEQDEV_SINGLELINE) && nbytes && (s->avg_text != d_text || s->avg_nbytes != nbytes || ++s->sample_age >= 64)) {
+      s->sample_age = 0;
       const size_t n = nbytes < SAMPLE_BYTES ? nbytes : SAMPLE_BYTES;
       HIP_TRY(hipMemcpyAsync(s->h_sample, d_text, n, hipMemcpyDeviceToHost, s->stream), EIO);
       HIP_TRY(hipStreamSynchronize(s->stream), EIO);
@@ -1596,6 +1601,7 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
       if (h.overflow & 8u) s->no_stream = true;
       if (h.overflow & 16u) s->no_stream_nd = true;
       if (h.overflow & 32u) s->force_ll = true;
+      if (h.overflow & (8u | 16u | 32u)) s->fallback_ttl = 32;
       if (h.overflow & 4u) {
          /* need_records keeps counting after the overflow, so it is the total of this run. */
          nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;
