@@ -28,7 +28,7 @@ sc.reserve(text.numel(), seg_lines + 64, max(seg_lines // 6 + 1024, 8192 * 64), 
 sc.set_profiling(True)
 opt = {"best": dev.SQ_BEST, "count": 0, "all": dev.SQ_ALL}[mode]
 want = dev.WANT_COUNTLINES if mode == "count" else dev.WANT_RECORDS
-fwd = launches = 0.0
+fwd = launches = ex = 0.0
 cnt = None
 for it in range(steps + 3):
     if it == 3:
@@ -44,6 +44,7 @@ for it in range(steps + 3):
         tm = sc.last_times_ms()
         fwd += tm["forward"]
         launches += tm["forward_launches"]
+        ex += tm["exact"]
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
-print("%-16s %-8s launch %.4f ms  step %.3f ms  matchlines %d" % (label, sc.last_kernel(), fwd / max(1, launches), 1e3 * el / steps, cnt["nmatchlines"]))
+print("%-16s %-8s launch %.4f ms  post-pass %.3f ms/step  step %.3f ms  matchlines %d" % (label, sc.last_kernel(), fwd / max(1, launches), ex / steps, 1e3 * el / steps, cnt["nmatchlines"]))
