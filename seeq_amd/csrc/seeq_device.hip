@@ -790,8 +790,6 @@ struct ScanKnobs {
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
    int  pair_exp;        /* SEEQ_PAIR_EXP=2..4: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
-   bool no_overlap;      /* SEEQ_OVERLAP=0: the post-pass of a segment on the scan's own stream (no second stream) */
-   bool no_verify;       /* SEEQ_NO_VERIFY=1: k_exact1 COUNT / EMIT behind k_pair instead of k_verify / k_emit_copy (A/B) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -821,14 +819,6 @@ struct seeqdev_scan {
       uint32_t *wg_part;             /* [4 * cap_slices] */
       uint32_t *wg_lastnl;           /* [cap_slices] k_stream: last newline seen by each wave */
    } ow;
-   /* k_pair with the post-pass of segment k on a second stream under the scan of segment k + 1: a second set of what the scan
-      kernel writes and the post-pass reads (tile arrays, slices, per-wave partials), the post-pass stream, the events that
-      order the two */
-   OnePassWs ow2;
-   size_t ow2_ftiles, ow2_slices, ow2_hitlines;
-   hipStream_t stream2;
-   hipEvent_t ev_scan[2], ev_post[2], ev_init;
-   bool have_overlap;
    size_t cap_ftiles, cap_slices;
    uint32_t *d_eqtab, *h_eqtab;   /* [256]; h_ is pinned */
    unsigned long eq_pat_id; int eq_options;   /* what d_eqtab holds (pattern generation id, option bits) */
@@ -922,8 +912,6 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       v = getenv("SEEQ_STREAM_WU");    kn.min_wu = v ? atoi(v) : 0;
-      v = getenv("SEEQ_NO_VERIFY");    kn.no_verify = v && atoi(v) == 1;
-      v = getenv("SEEQ_OVERLAP");      kn.no_overlap = v && atoi(v) == 0;
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
       s->ncu = 256;
       int dev = 0;
@@ -945,16 +933,9 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    (void)use_device(s->device);
    if (s->have_h2d_ev) { (void)hipEventDestroy(s->ev_h2d[0]); (void)hipEventDestroy(s->ev_h2d[1]); }
    (void)hipStreamSynchronize(s->stream);
-   if (s->stream2) (void)hipStreamSynchronize(s->stream2);
    {
-      void *ob[] = {s->ow.tile_cl, s->ow.tile_hits, s->ow.tile_dirty, s->ow.tile_dmask, s->ow.tmp, s->ow.wg_hits, s->ow.wg_part, s->ow.wg_lastnl,
-                    s->ow2.tile_cl, s->ow2.tile_hits, s->ow2.tmp, s->ow2.wg_hits, s->ow2.wg_part};
+      void *ob[] = {s->ow.tile_cl, s->ow.tile_hits, s->ow.tile_dirty, s->ow.tile_dmask, s->ow.tmp, s->ow.wg_hits, s->ow.wg_part, s->ow.wg_lastnl};
       for (void *b : ob) if (b) (void)hipFree(b);
-   }
-   if (s->have_overlap) {
-      for (int i = 0; i < 2; i++) { (void)hipEventDestroy(s->ev_scan[i]); (void)hipEventDestroy(s->ev_post[i]); }
-      (void)hipEventDestroy(s->ev_init);
-      (void)hipStreamDestroy(s->stream2);
    }
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
@@ -1195,37 +1176,6 @@ static int occupancy_of(seeqdev_scan *s, const void *fn, int threads, size_t lds
    return per_cu;
 }
 
-/* The second stream, its events and the second workspace set of the overlapped post-pass (sized like the first). */
-static int ensure_overlap(seeqdev_scan *s)
-{
-   if (!s->have_overlap) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);     /* (hi = the numerically lowest = most urgent: the short post-pass kernels go first) */
-      HIP_TRY(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, hi), EIO);
-      for (int i = 0; i < 2; i++) {
-         HIP_TRY(hipEventCreateWithFlags(&s->ev_scan[i], hipEventDisableTiming), EIO);
-         HIP_TRY(hipEventCreateWithFlags(&s->ev_post[i], hipEventDisableTiming), EIO);
-      }
-      HIP_TRY(hipEventCreateWithFlags(&s->ev_init, hipEventDisableTiming), EIO);
-      s->have_overlap = true;
-   }
-   if (s->ow2_ftiles < s->cap_ftiles) {
-      if (ws_alloc((void **)&s->ow2.tile_cl, s->cap_ftiles * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&s->ow2.tile_hits, s->cap_ftiles * sizeof(uint32_t))) return -1;
-      s->ow2_ftiles = s->cap_ftiles;
-   }
-   if (s->ow2_slices < s->cap_slices) {
-      if (ws_alloc((void **)&s->ow2.wg_hits, s->cap_slices * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&s->ow2.wg_part, 4 * s->cap_slices * sizeof(uint32_t))) return -1;
-      s->ow2_slices = s->cap_slices;
-   }
-   if (s->ow2_hitlines < s->cap_hitlines) {
-      if (ws_alloc((void **)&s->ow2.tmp, s->cap_hitlines * sizeof(uint4))) return -1;
-      s->ow2_hitlines = s->cap_hitlines;
-   }
-   return 0;
-}
-
 template <int W>
 static int run_segments(seeqdev_scan *s)
 {
@@ -1341,8 +1291,6 @@ static int run_segments(seeqdev_scan *s)
          int per_cu = occupancy_of(s, stream_fn, 64 * nw, dfa_lds);
          if (per_cu < 0) return -1;
          if (kn.wgs_per_cu >= 1 && kn.wgs_per_cu < per_cu) per_cu = kn.wgs_per_cu;       /* experiments: workgroups per CU */
-         /* k_pair under an overlapped post-pass (below): one workgroup per CU -- as fast as two, and half of the CU stays free */
-         if (use_pair && !kn.no_overlap && !single && nbytes > s->seg_bytes && per_cu > 1) per_cu = 1;
          fused_grid = (unsigned)(ncu * per_cu);
          if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
          nslices = fused_grid * nw;                         /* one hit slice per wave */
@@ -1405,23 +1353,15 @@ static int run_segments(seeqdev_scan *s)
       s->nev_seg = nseg;
    }
    if (s->prof) s->prof_segs = nseg;
-   /* k_pair is held by the memory system and runs as fast with one workgroup per CU as with two (profiles/r03); the post-pass
-      -- exact pass, compaction -- is instruction-bound and moves little memory.  With more than one segment the post-pass of
-      segment k therefore runs on a second stream under the scan of segment k + 1, in the half of every CU the scan leaves
-      free: the scan writes its tile arrays / slices / partials into one of two workspace sets in turn, events order the rest. */
-   const bool overlap = use_pair && nseg >= 2 && !kn.no_overlap;
-   if (overlap) {
-      if (ensure_overlap(s)) return -1;
-      HIP_TRY(hipEventRecord(s->ev_init, s->stream), EIO);         /* (the counters are cleared on the scan's stream) */
-      HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_init, 0), EIO);
-   }
+   /* (Tried: the post-pass of segment k on a second stream under k_pair of segment k + 1, k_pair on one workgroup per CU --
+      it is as fast there.  The post-pass kernels do run beside it, and take 3 to 14 times as long as alone: they are
+      made of scattered loads and the memory system is what k_pair saturates.  Net: +2 % .. -3 % per step.  Not kept;
+      tag r03-experiment-overlap-postpass, profiles/r03/overlap_trace.txt.) */
    for (size_t sg = 0; sg < nseg; sg++) {
       hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
       uint32_t stream_ntiles = 0;
-      const int wset = overlap ? (int)(sg & 1) : 0;
-      seeqdev_scan::OnePassWs &ow = wset ? s->ow2 : s->ow;
+      seeqdev_scan::OnePassWs &ow = s->ow;
       hipStream_t st = s->stream;
-      if (overlap && sg >= 2) HIP_TRY(hipStreamWaitEvent(st, s->ev_post[wset], 0), EIO);     /* the post-pass that read this workspace set is done */
       ScanArgs a;
       memset(&a, 0, sizeof a);
       a.text = (const uint8_t *)s->text;
@@ -1477,11 +1417,6 @@ static int run_segments(seeqdev_scan *s)
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st, f);
          else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
-         if (overlap) {                                   /* from here on: the post-pass stream, behind this segment's scan */
-            HIP_TRY(hipEventRecord(s->ev_scan[wset], st), EIO);
-            st = s->stream2;
-            HIP_TRY(hipStreamWaitEvent(st, s->ev_scan[wset], 0), EIO);
-         }
          hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, st, f, (uint32_t)nsl);
          if (want != SEEQDEV_WANT_COUNTLINES || superset) {
             launch_scanset(s, st, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
@@ -1525,18 +1460,12 @@ static int run_segments(seeqdev_scan *s)
                                             (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
          uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? ow.tmp : nullptr;   /* COUNT -> EMIT */
-         /* k_pair's candidates, a line yields at most one result: the lane-queue kernel k_verify + a plain copy (seeq_exact1.h) */
-         const bool use_verify = use_pair && !generic_exact && need_nh && !nh_is_count && !kn.no_verify;
+         /* (Tried behind k_pair: a lane-queue kernel -- a wave owns 256 .. 512 hit-list entries staged in LDS and a lane that has
+            finished its line takes the next entry at the next 64-byte block -- 22 % fewer instructions than k_exact1 COUNT, and
+            slower, 296 against 257 us per segment: at 4 waves per SIMD the per-block loads of a lane are not hidden.  Not kept;
+            tag r03-experiment-overlap-postpass holds it, profiles/r03/verify_ab.txt the numbers.) */
          /* ---- K4: hits per hit line ---- */
-         if (use_verify) {
-            const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
-            const size_t vblocks = (s->cap_hitlines + 4 * VERIFY_CH - 1) / (4 * VERIFY_CH);
-            const unsigned vgrid = (unsigned)(vblocks < (size_t)ncu * 4 ? (vblocks ? vblocks : 1) : (size_t)ncu * 4);
-            const bool best = (options & 3) == SQ_BEST && want == SEEQDEV_WANT_RECORDS;
-            if (fw == 2) { if (best) hipLaunchKernelGGL((k_verify<2, true>), dim3(vgrid), dim3(WG), 0, st, a, eqp, hcol, ecache); else hipLaunchKernelGGL((k_verify<2, false>), dim3(vgrid), dim3(WG), 0, st, a, eqp, hcol, ecache); }
-            else { if (best) hipLaunchKernelGGL((k_verify<1, true>), dim3(vgrid), dim3(WG), 0, st, a, eqp, hcol, ecache); else hipLaunchKernelGGL((k_verify<1, false>), dim3(vgrid), dim3(WG), 0, st, a, eqp, hcol, ecache); }
-            launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
-         } else if (need_nh) {
+         if (need_nh) {
             if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
 #define SEEQ_COUNT1(WW, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, WW, -1, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
@@ -1552,9 +1481,7 @@ static int run_segments(seeqdev_scan *s)
          /* ---- K5: records ---- */
          if (want == SEEQDEV_WANT_RECORDS) {
             hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);
-            if (use_verify) {
-               hipLaunchKernelGGL(k_emit_copy, dim3(grid_hits < 1024 ? grid_hits : 1024), dim3(WG), 0, st, a, (const uint4 *)ecache);
-            } else if (use_fused && !generic_exact) {
+            if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
                const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
 #define SEEQ_EMIT1(WW, OO, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
@@ -1575,10 +1502,8 @@ static int run_segments(seeqdev_scan *s)
       }
       hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));
       if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
-      if (overlap) HIP_TRY(hipEventRecord(s->ev_post[wset], st), EIO);
       HIP_TRY(hipGetLastError(), EIO);
    }
-   if (overlap) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_post[(nseg - 1) & 1], 0), EIO);     /* (the post-passes run in order on their stream: the last one ends them all) */
    HIP_TRY(hipMemcpyAsync(s->h_cnt, c, sizeof(Counters), hipMemcpyDeviceToHost, s->stream), EIO);
    return 0;
 }

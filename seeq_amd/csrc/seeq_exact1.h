@@ -455,162 +455,4 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
    }
 }
 
-/*
- * k_verify<W, BEST>: the exact pass over the CANDIDATES of a superset filter (k_pair) when a line yields at most one
- * result -- counting lines, SQ_FIRST, SQ_BEST -- and no byte is skipped (SQ_FAIL / SQ_CONVERT, line mode).  Same
- * arithmetic as k_exact1 (top-aligned Myers step, EQ tables, acceptance rules of libseeq.c:277-331, reverse start recovery
- * libseeq.c:289-316), other schedule:
- *   - k_exact1 gives every lane of a wave one line and waits for the longest (SQ_BEST scans to the end of the line: a
- *     wave runs for its longest lane's 3 blocks of 64 bytes while the average lane needs 1.6).  Here a wave owns a chunk of
- *     VERIFY_CH hit-list entries, staged in LDS, and a lane that has finished its line takes the next entry of the chunk
- *     at the next 64-byte block boundary (ballot + mbcnt hand the entries out in order): lanes stay busy until the chunk
- *     runs dry.
- *   - results {end, dist} overwrite the entries in LDS; when the chunk is done the wave recovers the starts in lockstep
- *     (all lanes busy with a start each) and writes nh[] (0 / 1 verdicts) and, when records are wanted, the cache entry
- *     {end, dist, start, 1} that k_emit_copy turns into the record once the verdicts have been scanned into offsets.
- */
-#define VERIFY_CH 512
-
-template <int W, bool BEST>
-__global__ __launch_bounds__(256, 4) void k_verify(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
-{
-   __shared__ __align__(8) uint32_t s_eqf[256 * W];
-   __shared__ __align__(8) uint32_t s_eqr[256 * W];
-   __shared__ __align__(16) uint8_t s_blk[256 * EXACT1_ROW];
-   __shared__ uint2 s_ent[4][VERIFY_CH];                  /* per wave: {hit_start, column of the first candidate}, then {end, dist | found << 31} */
-   for (int i = threadIdx.x; i < 256 * W; i += 256) { s_eqf[i] = eq2[i]; s_eqr[i] = eq2[256 * W + i]; }
-   __syncthreads();
-   const uint32_t eqf_base = (uint32_t)(uintptr_t)(fused_lds_cu32 *)s_eqf;
-   const uint32_t eqr_base = (uint32_t)(uintptr_t)(fused_lds_cu32 *)s_eqr;
-   const Counters *c = a.cnt;
-   const uint32_t nhl = c->seg_nhitlines;
-   const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1;
-   const bool fasta = (a.options & SEEQDEV_FASTA) != 0;
-   const uint32_t lane = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
-   const uint32_t gwave = blockIdx.x * 4u + wave_id, nwaves = gridDim.x * 4u;
-   uint8_t *row = s_blk + threadIdx.x * EXACT1_ROW;
-   uint2 *ent = s_ent[wave_id];
-   for (uint32_t base = gwave * VERIFY_CH; base < nhl; base += nwaves * VERIFY_CH) {
-      const uint32_t cn = nhl - base < VERIFY_CH ? nhl - base : (uint32_t)VERIFY_CH;
-      for (uint32_t i = lane; i < cn; i += 64) ent[i] = make_uint2(a.hit_start[base + i], hit_col[base + i]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       /* the wave's own LDS writes, before other lanes read them */
-      __builtin_amdgcn_wave_barrier();
-      uint32_t next = 0;                                  /* wave-uniform: the next entry of the chunk to hand out */
-      bool active = false;
-      uint32_t ke = 0, pos = 0, streak = tau1, best_d = tau1, best_end = 0;
-      uint64_t off = 0;
-      fused_state_t<W> st;
-      st.init(m);
-      for (;;) {
-         /* ---- idle lanes take the next entries, in order ---- */
-         const uint64_t idle = __ballot(!active);
-         if (next < cn && idle) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (!active && next + rank < cn) {
-               ke = next + rank;
-               const uint2 e = ent[ke];
-               bool skip = e.x == 0xFFFFFFFFu;            /* a repeat of the line of the entry before it */
-               off = a.seg_base + (skip ? 0u : e.x);
-               if (!skip && fasta && a.text[off] == '>') skip = true;     /* a candidate inside a FASTA header */
-               if (skip) {
-                  ent[ke] = make_uint2(0u, 0u);
-               } else {
-                  /* every occurrence of the line starts at or behind `first candidate - skip_back` (seeq_pair.h); unless a byte
-                     before it could have ended the line (dirty text): then from the line's first byte */
-                  pos = (e.y > a.skip_back && exact1_clean(a, off, off + e.y)) ? e.y - a.skip_back : 0u;
-                  st.init(m);
-                  streak = tau1; best_d = tau1; best_end = 0;
-                  active = true;
-               }
-            }
-            const uint32_t taken = (uint32_t)__popcll(idle);
-            next = next + taken < cn ? next + taken : cn;
-         }
-         if (!__any(active)) { if (next >= cn) break; continue; }
-         /* ---- one 64-byte block of every active lane's line ---- */
-         const bool was = active;
-         if (active) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-               *reinterpret_cast<fused_v4u *>(row + 16 * q) = direct_load16(a.text, off + pos + 16 * q, a.nbytes);
-         }
-         uint32_t dn = active ? 0u : 1u;
-#pragma unroll 1
-         for (uint32_t t4 = 0; t4 < 64; t4 += 4) {
-            if (!__any(dn == 0)) break;
-            const uint32_t w4 = *reinterpret_cast<const uint32_t *>(row + t4);
-            fused_eq_t<W> ev[4];
-#pragma unroll
-            for (int cc = 0; cc < 4; cc++)
-               ev[cc] = fused_eq_load<W>(eqf_base + (((w4 >> (8 * cc)) & 0xFFu) << (W == 1 ? 2 : 3)));
-#pragma unroll
-            for (int cc = 0; cc < 4; cc++) {
-               const uint32_t term_u = ev[cc].w0 & FUSED_FLAG_TERM;
-               st.step(ev[cc]);
-               const uint32_t p = pos + t4 + cc;
-               if (BEST) {
-                  /* smallest distance, first position where it is left or repeated as 0 (see k_exact1: no latch needed) */
-                  const uint32_t d1 = dn | term_u;
-                  const uint32_t sc = st.score < tau1 ? st.score : tau1;
-                  const uint32_t cur = d1 ? tau1 : sc;
-                  const bool upd = (dn == 0) & (streak < best_d) & ((streak < cur) | (streak == 0));
-                  best_d = upd ? streak : best_d;
-                  best_end = upd ? p : best_end;
-                  streak = cur;
-                  dn = d1;
-               } else {
-                  /* the first emission (libseeq.c:277-331: the latch is clear until then): the score rises, or a 0 repeats */
-                  const uint32_t m1 = st.score | (0u - term_u);
-                  const uint32_t cur = m1 < tau1 ? m1 : tau1;
-                  const uint32_t emit_u = (dn ^ 1u) & (((streak - cur) >> 31) | ((streak - 1u) >> 31));
-                  best_d = emit_u ? streak : best_d;
-                  best_end = emit_u ? p : best_end;
-                  streak = cur;
-                  dn |= term_u | emit_u;
-               }
-            }
-         }
-         pos += 64;
-         active = dn == 0;
-         if (was && !active) ent[ke] = make_uint2(best_end, best_d | (best_d < tau1 ? 0x80000000u : 0u));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      /* ---- verdicts, and the starts of the records, all lanes together ---- */
-      for (uint32_t i0 = 0; i0 < cn; i0 += 64) {
-         const uint32_t i = i0 + lane;
-         const uint2 r = i < cn ? ent[i] : make_uint2(0u, 0u);
-         const bool found = (r.y >> 31) != 0;
-         if (i < cn) a.nh[base + i] = found ? 1u : 0u;
-         if (cache && found) {
-            const uint64_t o = a.seg_base + a.hit_start[base + i];
-            const uint32_t dist = r.y & 0x7FFFFFFFu;
-            const uint32_t start = exact1_reverse<W>(a.text, o, a.nbytes, r.x, dist, eqr_base, m, tau1, row);
-            cache[base + i] = make_uint4(r.x, dist, start, 1u);
-         }
-      }
-      __builtin_amdgcn_wave_barrier();
-   }
-}
-
-/* Records of lines that yield at most one (k_verify): nh[] holds exclusive offsets by now, cache[k] = {end, dist, start, 1}. */
-__global__ __launch_bounds__(256) void k_emit_copy(ScanArgs a, const uint4 *cache)
-{
-   const Counters *c = a.cnt;
-   if (c->overflow & 4u) return;
-   const uint32_t nhl = c->seg_nhitlines;
-   const uint32_t stride = gridDim.x * 256;
-   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
-      const uint32_t lo = a.nh[k], hi = k + 1 < nhl ? a.nh[k + 1] : c->seg_nrec;
-      if (hi == lo) continue;
-      const uint4 ce = cache[k];
-      seeqdev_hit_t h;
-      h.line = a.hit_line[k];
-      h.start = ce.z; h.end = ce.x; h.dist = ce.y;
-      const uint64_t slot = c->records + lo;
-      a.records[slot] = h;
-      a.rec_off[slot] = a.seg_base + a.hit_start[k];
-   }
-}
-
 #endif
