@@ -782,8 +782,6 @@ static void pattern_plan_pair(seeqdev_pattern *mp)
 /* Experiment / test knobs, read from the environment ONCE per scan context (seeqdevScanNew). */
 struct ScanKnobs {
    int  kernel;          /* SEEQ_FUSED_KERNEL: 0 auto, 1 "stream" (k_stream, never k_pair), 2 "direct", 3 "pair" (k_pair wherever the pattern has a pair automaton, selective or not) */
-   int  stream_ch;       /* SEEQ_STREAM_CH: 128 (default) or 64 */
-   bool stream_ilp1;     /* SEEQ_STREAM_ILP=1: one walk per lane */
    int  wgs_per_cu;      /* SEEQ_DFA_WGS: cap on k_stream workgroups per CU (0 = occupancy) */
    int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
@@ -904,8 +902,6 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       ScanKnobs &kn = s->knobs;
       const char *v;
       v = getenv("SEEQ_FUSED_KERNEL"); kn.kernel = v ? (!strcmp(v, "stream") ? 1 : !strcmp(v, "direct") ? 2 : !strcmp(v, "pair") ? 3 : 0) : 0;
-      v = getenv("SEEQ_STREAM_CH");    kn.stream_ch = v && atoi(v) == 64 ? 64 : 128;
-      v = getenv("SEEQ_STREAM_ILP");   kn.stream_ilp1 = v && atoi(v) == 1;
       v = getenv("SEEQ_DFA_WGS");      kn.wgs_per_cu = v ? atoi(v) : 0;
       v = getenv("SEEQ_TILE_BYTES");   kn.tile_bytes = v ? atoi(v) : 0;
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
@@ -1207,7 +1203,7 @@ static int run_segments(seeqdev_scan *s)
       fits LDS (seeq_dfa.h): the complete Levenshtein automaton (its verdicts are exact) or, for longer patterns /
       larger distances, a partition FILTER automaton (its hit lines are candidates: the exact pass verifies them). */
    bool use_stream = false, can_sub = false;
-   int stream_ch = 128;
+   const int stream_ch = 128;                 /* bytes per lane of k_stream / k_pair */
    {
       /* SQ_FAIL: always.  SQ_CONVERT: exact through the SUB variant (non-DNA bytes replaced by 'N' in registers).
          SQ_IGNORE on read-length lines: the SUB variant with skip bytes (its hit lines become candidates where a skipped
@@ -1216,14 +1212,12 @@ static int run_segments(seeqdev_scan *s)
          kernels, for good), and not on FASTA input (header lines are made of such bytes). */
       const int nd = options & MASK_NONDNA;
       const bool long_lines = s->avg_line > 600.0 || s->force_ll;
-      can_sub = (nd == SQ_CONVERT || (nd == SQ_IGNORE && !long_lines && !s->no_stream_nd)) && !fasta && kn.stream_ch == 128 && !kn.stream_ilp1 && !kn.no_sub;
+      can_sub = (nd == SQ_CONVERT || (nd == SQ_IGNORE && !long_lines && !s->no_stream_nd)) && !fasta && !kn.no_sub;
       const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || can_sub || (!s->no_stream_nd && !fasta));
       if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && kn.kernel != 2) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (__atomic_load_n(&mp->sdfa_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_stream(mp, kn.no_filter);
-         stream_ch = kn.stream_ch;
          use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
-         if (fasta && (stream_ch != 128 || kn.stream_ilp1)) use_stream = false;     /* FASTA: default variant only */
          if (use_stream && mp->sdfa_parts > 1) {
             /* a filter: worth it while few lines are false candidates (each costs a whole-line exact scan), and only on
                read-length lines (the window walk over long lines needs exact candidates) */
@@ -1239,12 +1233,12 @@ static int run_segments(seeqdev_scan *s)
       const int nd = options & MASK_NONDNA;
       const bool long_lines = (s->avg_line > 600.0 && kn.kernel != 3) || s->force_ll;      /* (a candidate inside a line of a whole tile sets force_ll) */
       if (fusable && s->force_path != 1 && (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || nd == SQ_CONVERT) && !long_lines && !s->no_stream &&
-          (kn.kernel == 0 || kn.kernel == 3) && kn.stream_ch == 128 && !kn.stream_ilp1 && s->seg_bytes % (64u * 128u) == 0) {
+          (kn.kernel == 0 || kn.kernel == 3) && s->seg_bytes % (64u * 128u) == 0) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (__atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
          use_pair = mp->pair_state == 1 && (kn.kernel == 3 || mp->pair_pacc * s->avg_line <= 0.25);
       }
-      if (use_pair) { use_stream = true; can_sub = false; stream_ch = 128; }
+      if (use_pair) { use_stream = true; can_sub = false; }
    }
    const bool filter = use_pair || (use_stream && pat->sdfa_parts > 1);
    bool use_fused = fusable && (s->avg_line <= 260.0 || use_stream) && s->force_path != 1;      /* k_direct regions are <= 16 KiB (~62 lines) */
@@ -1256,26 +1250,22 @@ static int run_segments(seeqdev_scan *s)
    if (use_pair) stream_wu = pat->pair_warm <= 16 ? 4 : (pat->pair_warm + 3) / 4;
    if (stream_wu < kn.min_wu) stream_wu = kn.min_wu >= 8 ? 8 : 6;
    const void *stream_fn = nullptr;
-   bool stream_ilp2 = false, stream_ll = false;
+   bool stream_ll = false;
    int stream_sub = 0;                        /* 0, 1: SQ_CONVERT ('N' for non-DNA bytes), 2: SQ_IGNORE (skip bytes) */
    size_t dfa_lds = 0;
    if (use_fused) {
       if (use_stream) {
          nw = STREAM_NW;
          tile_bytes = 64u * (uint32_t)stream_ch;
-         stream_ilp2 = stream_ch == 128 && !kn.stream_ilp1;
-         stream_ll = (s->avg_line > 600.0 || s->force_ll) && stream_ch == 128 && stream_ilp2;      /* long lines: bookkeeping for the window walk */
+         stream_ll = s->avg_line > 600.0 || s->force_ll;      /* long lines: bookkeeping for the window walk */
          stream_sub = can_sub ? ((options & MASK_NONDNA) == SQ_IGNORE ? 2 : 1) : 0;
-         /* the k_stream instance of this scan: <bytes per lane, warm-up dwords, two walks per lane, FASTA, long lines, SUB> */
-#define SEEQ_STREAM_FN(...) (stream_wu == 4 ? (const void *)k_stream<128, 4, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_stream<128, 6, __VA_ARGS__> \
-                                                                                                            : (const void *)k_stream<128, 8, __VA_ARGS__>)
-         stream_fn = stream_sub == 2 ? SEEQ_STREAM_FN(true, false, false, 2)
-                   : stream_sub ? (stream_ll ? SEEQ_STREAM_FN(true, false, true, 1) : SEEQ_STREAM_FN(true, false, false, 1))
-                   : stream_ll ? (fasta ? SEEQ_STREAM_FN(true, true, true) : SEEQ_STREAM_FN(true, false, true))
-                   : fasta ? SEEQ_STREAM_FN(true, true, false)
-                   : stream_ch == 128 ? (stream_ilp2 ? SEEQ_STREAM_FN(true, false, false) : SEEQ_STREAM_FN(false, false, false))
-                   : (stream_wu == 4 ? (const void *)k_stream<64, 4, false, false, false> : stream_wu == 6 ? (const void *)k_stream<64, 6, false, false, false>
-                                                                                                           : (const void *)k_stream<64, 8, false, false, false>);
+         /* the k_stream instance of this scan: <warm-up dwords, FASTA, long lines, SUB> */
+#define SEEQ_STREAM_FN(...) (stream_wu == 4 ? (const void *)k_stream<4, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_stream<6, __VA_ARGS__> \
+                                                                                                      : (const void *)k_stream<8, __VA_ARGS__>)
+         stream_fn = stream_sub == 2 ? SEEQ_STREAM_FN(false, false, 2)
+                   : stream_sub ? (stream_ll ? SEEQ_STREAM_FN(false, true, 1) : SEEQ_STREAM_FN(false, false, 1))
+                   : stream_ll ? (fasta ? SEEQ_STREAM_FN(true, true) : SEEQ_STREAM_FN(false, true))
+                   : fasta ? SEEQ_STREAM_FN(true, false) : SEEQ_STREAM_FN(false, false);
 #undef SEEQ_STREAM_FN
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          if (use_pair) {

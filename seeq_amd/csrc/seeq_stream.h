@@ -24,8 +24,8 @@
  *     every reported line is then verified by the exact pass (k_exact1 COUNT), and only then.  On
  *     clean input the exact pass trusts the filter.
  *
- *   - ILP2: the chunk is walked as two independent chains (bytes 0-63 warm up on the previous lane's tail, bytes
- *     64-127 on the lane's own bytes 40-63), so two gathers are in flight per lane.
+ *   - The chunk is walked as two independent chains (bytes 0-63 warm up on the previous lane's tail, bytes 64-127 on
+ *     the lane's own bytes 40-63), so two gathers are in flight per lane.
  *
  * Per tile the wave emits {tile | unresolved, rank among the tile's hits | column of the hit, start of the hit's
  * line (or the hit position when the line starts before the tile), line rank inside the tile} into its private
@@ -61,28 +61,6 @@ __device__ __forceinline__ fused_v4u dfa_load16(const uint8_t *text, uint64_t of
                          : "=v"(ad) : "v"(state), "v"(wm))
 #define STREAM_HIT asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(state), "v"(acc_new) : "vcc")
 typedef __attribute__((address_space(3))) const uint16_t stream_lds_cu16;
-
-/* four warm-up characters: walk only */
-__device__ __forceinline__ void stream_warm4(uint32_t &state, uint32_t w)
-{
-   const uint32_t wm = w & 0x0E0E0E0Eu;
-   uint32_t ad;
-   STREAM_OR(0); state = *(stream_lds_cu16 *)(uintptr_t)ad;
-   STREAM_OR(1); state = *(stream_lds_cu16 *)(uintptr_t)ad;
-   STREAM_OR(2); state = *(stream_lds_cu16 *)(uintptr_t)ad;
-   STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad;
-}
-
-/* four owned characters: walk, first-hit mask (the newline masks are made apart from the walk: stream_nl_masks) */
-__device__ __forceinline__ void stream_own4(uint32_t &state, uint32_t w, uint32_t &hm, uint32_t acc_new)
-{
-   const uint32_t wm = w & 0x0E0E0E0Eu;
-   uint32_t ad;
-   STREAM_OR(0); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
-   STREAM_OR(1); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
-   STREAM_OR(2); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
-   STREAM_OR(3); state = *(stream_lds_cu16 *)(uintptr_t)ad; STREAM_HIT;
-}
 
 /* The exact newline mask of 32 characters (eight text words; first character = bit 31), without a compare per
  * character: per word the four "is '\n'" flags as bytes of 0 / 1, then v_dot4_u32_u8 with the weights 8 4 2 1 (x 16 for
@@ -188,10 +166,11 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
  * chain whose warm-up window holds one has not seen enough of the line when its own bytes begin: it reports the line its
  * first byte lies in as a candidate whatever the walk says (a made-up first hit), the wave flags the scan as a superset
  * (wg_part flag 4) and the exact pass, which knows how to skip, verifies the candidates. */
-template <int CH, int WU, bool ILP2, bool FA, bool LL, int SUB = 0>
+template <int WU, bool FA, bool LL, int SUB = 0>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
+   constexpr int CH = 128;                                /* bytes per lane: one 128-byte memory line, consumed whole by its lane */
    constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
    constexpr int NM = CH / 32;                            /* mask registers per lane */
    constexpr uint32_t TB = 64u * CH;                      /* tile bytes */
@@ -293,7 +272,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          if (LL && lane == 0) { a.tile_dirty[tile] = (flag || badlanes) ? 1u : 0u; a.tile_dmask[tile] = badlanes; }
       }
       uint32_t hmask[NM], nmask[NM];
-      if (ILP2 && CH == 128) {
+      {
          /* Two chains per lane: A = bytes 0..63 (warm-up: the previous lane's last bytes), B = bytes 64..127
             (warm-up: my own bytes before 64).  Same result, 16 % more gathers, but two of them in flight. */
          uint32_t sa = 0, sb = 0;
@@ -321,41 +300,11 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
             }
             hmask[r] = hma; hmask[r + NM / 2] = hmb;
          }
-      } else {
-      /* ---- warm-up over the previous lane's last 4*WU bytes, from the root state ---- */
-      uint32_t state = 0;
-      {
-         if (WU == 8) {
-            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].x, pa.x));
-            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].y, pa.y));
-         }
-         if (WU >= 6) {
-            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].z, pa.z));
-            stream_warm4(state, stream_from_prev_lane(v[NQ - 2].w, pa.w));
-         }
-         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].x, pb.x));
-         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].y, pb.y));
-         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].z, pb.z));
-         stream_warm4(state, stream_from_prev_lane(v[NQ - 1].w, pb.w));
-      }
-      /* ---- the owned chunk ---- */
-#pragma unroll
-      for (int r = 0; r < NM; r++) {
-         uint32_t hm = 0;
-#pragma unroll
-         for (int q = 2 * r; q < 2 * r + 2; q++) {
-            stream_own4(state, v[q].x, hm, acc_new);
-            stream_own4(state, v[q].y, hm, acc_new);
-            stream_own4(state, v[q].z, hm, acc_new);
-            stream_own4(state, v[q].w, hm, acc_new);
-         }
-         hmask[r] = hm;                                   /* first character of the group = bit 31 */
-      }
       }
       /* ---- newline masks, apart from the walk: SWAR flags + dot products (stream_nl_mask32) ---- */
 #pragma unroll
       for (int r = 0; r < NM; r++) nmask[r] = stream_nl_mask32(v[2 * r], v[2 * r + 1], tile_clean);
-      if (SUB == 2 && ILP2 && CH == 128) {                /* made-up first hits at the first byte of a chain (see SUB) */
+      if (SUB == 2) {                /* made-up first hits at the first byte of a chain (see SUB) */
          if (fake & 1u) hmask[0] |= 0x80000000u;
          if (fake & 2u) hmask[NM / 2] |= 0x80000000u;
       }
@@ -459,7 +408,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       }
       /* a hit inside a line of >= a whole tile: ask for the long-line variant (of this configuration).  (Not for the tile
          the buffer ends in: without a newline it need not be a long line, just the tail of the last one.) */
-      if (!LL && CH == 128 && ILP2 && tot_h && !tot_n && !partial && !(t0 <= last && last < t0 + TB)) wv_dirty |= 2u;
+      if (!LL && tot_h && !tot_n && !partial && !(t0 <= last && last < t0 + TB)) wv_dirty |= 2u;
       wv_lines += tot_n + extra;
       wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;

@@ -113,15 +113,12 @@ def test_long_pattern_words(gpu, capi, oracle):
 def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=None):
     """One batched scan through the device C-ABI.  path: 'generic' (newline index + k_forward<W>),
     'fused' = k_direct (one line per lane, text in registers), 'fused-stream' = k_stream (transition table in LDS:
-    the pattern's complete automaton or a partition filter; k_direct when neither fits; `tile` is the chunk size
-    per lane), 'fused-pair' = k_pair (two bytes per table step over the pattern's pair automaton, selective or not;
+    the pattern's complete automaton or a partition filter; k_direct when neither fits), 'fused-pair' = k_pair (two bytes per table step over the pattern's pair automaton, selective or not;
     k_stream / k_direct where it does not apply: SQ_IGNORE), or 'auto' (the library's own choice); the env knobs are read when the scan context is created."""
     from seeq_amd import device as dev
     if path != "auto":
         os.environ["SEEQ_FUSED_KERNEL"] = {"fused-stream": "stream", "fused-pair": "pair"}.get(path, "direct")
-    if tile and path == "fused-stream":
-        os.environ["SEEQ_STREAM_CH"] = str(tile)
-    elif tile:
+    if tile:
         os.environ["SEEQ_TILE_BYTES"] = str(tile)
     path = "fused" if path.startswith("fused-") else path
     os.environ["SEEQ_PATH"] = path
@@ -137,13 +134,12 @@ def _scan(capi, pattern, tau, buf, opt, want, fasta=False, path="auto", tile=Non
     finally:
         os.environ.pop("SEEQ_PATH", None)
         os.environ.pop("SEEQ_TILE_BYTES", None)
-        os.environ.pop("SEEQ_STREAM_CH", None)
         os.environ.pop("SEEQ_FUSED_KERNEL", None)
     return res
 
 
 @pytest.mark.parametrize("path,tile", [("generic", None), ("fused", None), ("fused", 1024),
-                                       ("fused-stream", None), ("fused-stream", 64), ("fused-pair", None)])
+                                       ("fused-stream", None), ("fused-pair", None)])
 @pytest.mark.parametrize("name,pattern,tau", [("reads_small.txt", PAT20, 3), ("fastq_small.txt", PAT20, 3),
                                               ("fasta_small.txt", PAT20, 3), ("reads250_small.txt", PAT40, 5),
                                               ("reads_small.txt", "GATTAGC", 1), ("testdata.txt", "CACAGAT", 3),
@@ -195,11 +191,11 @@ def test_edge_buffers(gpu, capi, oracle, path):
     for buf in cases:
         for opt in (SQ_ALL, SQ_ALL | SQ_CONVERT, SQ_BEST | SQ_IGNORE, SQ_FIRST):
             exp = oracle.buffer_scan("ACGT", 1, buf, opt)
-            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, {"fused": 1024, "fused-stream": 64}.get(path))
+            got = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_RECORDS, False, path, {"fused": 1024}.get(path))
             assert got["nlines"] == exp["nlines"], (buf[:20], opt)
             assert got["nmatchlines"] == exp["nmatchlines"], (buf[:20], opt)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (buf[:20], opt)
-            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, {"fused": 1024, "fused-stream": 64}.get(path))
+            cnt = _scan(capi, "ACGT", 1, buf, opt, dev.WANT_COUNTLINES, False, path, {"fused": 1024}.get(path))
             assert cnt["nmatchlines"] == exp["nmatchlines"] and cnt["nlines"] == exp["nlines"]
 
 
@@ -686,10 +682,11 @@ def _mutate(rng, pat, nerr):
     return "".join(s)
 
 
-@pytest.mark.parametrize("ch", [128, 64])
-def test_stream_chunk_and_tile_boundaries(gpu, capi, oracle, ch):
+@pytest.mark.parametrize("kernel", ["stream", "pair"])
+def test_stream_chunk_and_tile_boundaries(gpu, capi, oracle, kernel):
     """k_stream gives lanes fixed chunks of the text, so hits, newlines and whole lines straddle chunk, tile
-    (64 chunks) and segment boundaries in every possible way: pattern copies planted at every offset around
+    (64 chunks) and segment boundaries in every possible way -- under k_stream, and under k_pair wherever it applies (the
+    long lines of this text send it to k_stream's long-line variant after the first tile that says so): pattern copies planted at every offset around
     the boundaries, lines from 0 to 30 000 bytes with several hits each (one line reported by many lanes),
     non-DNA bytes before / after hits (dirty text: the filter's verdicts get verified), small segments."""
     code = r'''
@@ -703,7 +700,7 @@ o = Oracle()
 pat = "GATGTAGCGCGATTAGCCTG"
 rng = random.Random(77)
 def dna(n): return "".join(rng.choice("ACGT") for _ in range(n))
-tile = 64 * %d
+tile = 64 * 128
 for dirty in (False, True):
     parts = []
     # 1. copies ending at every offset around the first tile boundaries (one line per copy, lengths vary)
@@ -752,7 +749,7 @@ for dirty in (False, True):
                 got = sc.scan_host(p, buf, opt | nd, dev.WANT_RECORDS)
                 # (the 128-byte-chunk variant walks a corrected copy under SQ_CONVERT; under SQ_IGNORE it does on read-length
                 #  input -- this buffer's average line is long, so there a non-DNA byte sends the scan to a per-line kernel)
-                if not dirty or (nd == dev.SQ_CONVERT and %d == 128):
+                if not dirty or nd == dev.SQ_CONVERT:
                     assert sc.last_kernel() in ("k_stream", "k_pair"), (dirty, nd, sc.last_kernel())
                 assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (dirty, nd, opt)
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (dirty, nd, opt)
@@ -775,8 +772,7 @@ for tail in ("\n", ""):
     for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
         exp = o.buffer_scan(pat, 3, buf, opt, fasta=True)
         got = sc.scan_host(p, buf, opt | dev.SEEQDEV_FASTA, dev.WANT_RECORDS)
-        if %d == 128:
-            assert sc.last_kernel() in ("k_stream", "k_pair"), sc.last_kernel()
+        assert sc.last_kernel() in ("k_stream", "k_pair"), sc.last_kernel()
         assert got["nlines"] == exp["nlines"], ("fasta", opt, got["nlines"], exp["nlines"])
         assert got["nmatchlines"] == exp["nmatchlines"], ("fasta", opt, got["nmatchlines"], exp["nmatchlines"])
         assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), ("fasta", opt)
@@ -787,9 +783,9 @@ for tail in ("\n", ""):
     assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"]
     sc.close(); p.close()
 print("OK")
-''' % (ROOT, os.path.join(ROOT, "tests"), ch, ch, ch)
+''' % (ROOT, os.path.join(ROOT, "tests"))
     for seg in ("65536", "0"):                     # many small segments; one segment
-        env = dict(os.environ, SEEQ_STREAM_CH=str(ch))
+        env = dict(os.environ, SEEQ_FUSED_KERNEL=kernel)
         if seg != "0":
             env["SEEQ_SEGMENT_BYTES"] = seg
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
