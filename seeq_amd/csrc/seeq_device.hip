@@ -788,6 +788,7 @@ struct ScanKnobs {
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
    int  pair_exp;        /* SEEQ_PAIR_EXP=2..4: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
+   bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -893,8 +894,8 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    }
    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cnt, sizeof(Counters));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_cnt, sizeof(Counters), hipHostMallocDefault);
-   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 1024 * sizeof(uint32_t), hipHostMallocDefault);
-   if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 1024 * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_eqtab, 2048 * sizeof(uint32_t), hipHostMallocDefault);
+   if (e == hipSuccess) e = hipMalloc((void **)&s->d_eqtab, 2048 * sizeof(uint32_t));
    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_sample, SAMPLE_BYTES, hipHostMallocDefault);
    {
       const char *pe = getenv("SEEQ_PATH");
@@ -908,6 +909,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       v = getenv("SEEQ_STREAM_WU");    kn.min_wu = v ? atoi(v) : 0;
+      v = getenv("SEEQ_NO_MYERS");     kn.no_myers = v && atoi(v) == 1;
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
       s->ncu = 256;
       int dev = 0;
@@ -1240,7 +1242,17 @@ static int run_segments(seeqdev_scan *s)
       }
       if (use_pair) { use_stream = true; can_sub = false; }
    }
-   const bool filter = use_pair || (use_stream && pat->sdfa_parts > 1);
+   /* k_stream's Myers mode: no automaton fits (or only a filter, which serves read-length lines), the lines are too long for
+      the per-line kernels -- the same line-agnostic chunks, the bit-vector column instead of the table (seeq_stream.h) */
+   bool use_myers = false;
+   {
+      const int nd = options & MASK_NONDNA;
+      if (!use_stream && !use_pair && fusable && s->force_path != 1 && (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || nd == SQ_CONVERT) &&
+          kn.kernel != 2 && !kn.no_myers && !s->no_stream && (s->avg_line > 260.0 || s->force_ll) && s->seg_bytes % (64u * 128u) == 0) {
+         use_myers = true; use_stream = true; can_sub = false;
+      }
+   }
+   const bool filter = use_pair || (use_stream && !use_myers && pat->sdfa_parts > 1);
    bool use_fused = fusable && (s->avg_line <= 260.0 || use_stream) && s->force_path != 1;      /* k_direct regions are <= 16 KiB (~62 lines) */
    uint32_t tile_bytes = 0;
    unsigned fused_grid = 1;
@@ -1249,6 +1261,7 @@ static int run_segments(seeqdev_scan *s)
    int stream_wu = !use_stream ? 8 : pat->sdfa_warm <= 16 ? 4 : pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
    if (use_pair) stream_wu = pat->pair_warm <= 16 ? 4 : (pat->pair_warm + 3) / 4;
    if (stream_wu < kn.min_wu) stream_wu = kn.min_wu >= 8 ? 8 : 6;
+   if (use_myers) stream_wu = pat->wlen + pat->tau - 1 <= 64 ? 16 : 32;        /* (an 8-word instance exists in principle; the one-word one the compiler makes of it spills 189 registers) */
    const void *stream_fn = nullptr;
    bool stream_ll = false;
    int stream_sub = 0;                        /* 0, 1: SQ_CONVERT ('N' for non-DNA bytes), 2: SQ_IGNORE (skip bytes) */
@@ -1268,6 +1281,13 @@ static int run_segments(seeqdev_scan *s)
                    : fasta ? SEEQ_STREAM_FN(true, false) : SEEQ_STREAM_FN(false, false);
 #undef SEEQ_STREAM_FN
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
+         if (use_myers) {
+            stream_ll = true; stream_sub = 0;               /* (the window walk of the exact pass serves every line length) */
+#define SEEQ_MYERS_FN(FA, MY) (stream_wu == 16 ? (const void *)k_stream<16, FA, true, 0, MY> : (const void *)k_stream<32, FA, true, 0, MY>)
+            stream_fn = fw == 1 ? (fasta ? SEEQ_MYERS_FN(true, 1) : SEEQ_MYERS_FN(false, 1)) : (fasta ? SEEQ_MYERS_FN(true, 2) : SEEQ_MYERS_FN(false, 2));
+#undef SEEQ_MYERS_FN
+            dfa_lds = (size_t)256 * fw * sizeof(uint32_t);
+         }
          if (use_pair) {
             stream_ll = false; stream_sub = 0;
 #define SEEQ_PAIR_FN(...) (stream_wu == 4 ? (const void *)k_pair<4, __VA_ARGS__> : stream_wu == 5 ? (const void *)k_pair<5, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_pair<6, __VA_ARGS__> \
@@ -1317,15 +1337,18 @@ static int run_segments(seeqdev_scan *s)
                dst[0] = (uint32_t)v;
                if (fw == 2) dst[1] = (uint32_t)(v >> 32);
             }
+         /* third table, k_stream's Myers mode: the forward table with the newline marked (flag bits 0-1 = 3) */
+         memcpy(s->h_eqtab + (size_t)512 * fw, s->h_eqtab, (size_t)256 * fw * sizeof(uint32_t));
+         s->h_eqtab[(size_t)512 * fw + (size_t)'\n' * fw] |= 3u;
          /* the pinned staging table may still be read by an earlier copy on this stream: wait before the next rewrite */
-         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)512 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
+         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)768 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
          HIP_TRY(hipStreamSynchronize(s->stream), EIO);
          s->eq_pat_id = pat->id;
          s->eq_options = options;
       }
    }
    const bool use_direct = use_fused && !use_stream;
-   s->last_path = use_fused ? (use_pair ? 6 : use_stream ? 5 : 3) : 1;
+   s->last_path = use_fused ? (use_pair ? 6 : use_myers ? 7 : use_stream ? 5 : 3) : 1;
    s->last_filter = filter;
    const bool superset = use_stream;                     /* the scan kernel's hit lines are candidates: nh[] decides */
    if (superset) need_nh = true;
@@ -1390,6 +1413,7 @@ static int run_segments(seeqdev_scan *s)
          if (use_stream) {
             f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
             if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
+            if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
             /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
             uint64_t room = 0xFFFFFFF0ull - a.seg_len;
             if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
    uint4 *ovf = cache ? cache + nhl + (size_t)(blockIdx.x * 4u + wave_id) * ovf_r : nullptr;
    const bool ovf_lost = MODE == SQ_MODE_EMIT && c->seg_novf != 0;               /* (EMIT: the lists are complete or they are not used) */
    const bool walk = WALK && a.use_nh == 3 && hit_col != nullptr && a.stream_ch != 0;     /* window walk (below); kernel-uniform */
+   const uint32_t wback = a.skip_back > 32u ? a.skip_back : 32u;      /* columns a fresh column needs before a candidate (the table walks warm up over <= 32; the Myers mode over m + tau - 1) */
    /* no byte is skipped under these options: a flagged byte ends the line, so the column of a lane needs no protecting
       from it (nothing reads the column of a finished line) -- the per-character bodies below drop the predicated copy */
    const bool noskip = (a.options & (SQ_IGNORE | SQ_STREAM)) == 0;
@@ -377,15 +378,15 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
             /* A score <= tau in the last 32 columns of a chunk (or inside the chunk the walk stands in) may have put
                that chunk's lane into the accepting state before it could report: the chunk has to be scanned whole. */
             const int32_t b = (int32_t)(((hs + pos) & ~(a.stream_ch - 1u)) - hs);      /* start of the chunk holding `pos` */
-            if (lastsub >= b - 32 && b + (int32_t)a.stream_ch > (int32_t)wend) wend = (uint32_t)(b + (int32_t)a.stream_ch);
+            if (lastsub >= b - (int32_t)wback && b + (int32_t)a.stream_ch > (int32_t)wend) wend = (uint32_t)(b + (int32_t)a.stream_ch);
             if (pos >= wend) {
                /* the window is done and the columns behind are clean: nothing can hide before the next candidate */
                for (;;) {
                   if (!(knext < nhl && a.hit_start[knext] == 0xFFFFFFFFu)) { done = true; break; }   /* no candidate left */
                   const uint32_t cpos = hit_col[knext++];                 /* position of the repeat's first hit */
                   const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs;
-                  if (ccol > pos + 32 && exact1_clean(a, off + pos, off + ccol - 32)) {   /* jump: fresh column 32 columns before it */
-                     pos = ccol - 32; wend = cend;
+                  if (ccol > pos + wback && exact1_clean(a, off + pos, off + ccol - wback)) {   /* jump: fresh column `wback` columns before it */
+                     pos = ccol - wback; wend = cend;
                      st.init(m); streak = tau1; latch = false; lastsub = -0x40000000;
                      break;
                   }

@@ -112,6 +112,44 @@ __device__ __forceinline__ void stream_own4x2(uint32_t &sa, uint32_t wa, uint32_
    STREAM_X2(0) STREAM_EV2(0) STREAM_X2(1) STREAM_EV2(1) STREAM_X2(2) STREAM_EV2(2) STREAM_X2(3) STREAM_EV2(3)
 }
 
+/* MY (k_stream's Myers mode, below): four text bytes through the bit-vector column instead of the table.  EQ entries: the
+ * top-aligned Peq word(s) of the byte's class, or a flag in bits 0-1: 1 = the byte ends the line (NUL, a non-DNA byte under
+ * SQ_FAIL), 3 = newline.  The column is stepped in place whatever the byte (after a flagged byte it is garbage until the
+ * next newline re-initialises it, and `dead` keeps hits out until then); `seen` makes only the FIRST position with
+ * D[m][j] <= tau of a line report (what ACC_NEW / ACC_OLD do for the table walk).  OWN: record into the mask. */
+template <int W>
+__device__ __forceinline__ void stream_myers_lookup4(uint32_t w, uint32_t eqb, fused_eq_t<W> (&ev)[4])
+{
+#pragma unroll
+   for (int cc = 0; cc < 4; cc++) ev[cc] = fused_eq_load<W>(eqb + (((w >> (8 * cc)) & 0xFFu) << (W == 1 ? 2 : 3)));
+}
+
+template <int W, bool OWN>
+__device__ __forceinline__ void stream_myers_step4(const fused_eq_t<W> (&ev)[4], fused_state_t<W> &st, uint32_t m, uint32_t tau,
+                                                   uint32_t &dead, uint32_t &seen, uint32_t &hm)
+{
+#pragma unroll
+   for (int cc = 0; cc < 4; cc++) {
+      const uint32_t fl = ev[cc].w0 & 3u;
+      st.step(ev[cc]);
+      const bool nl = fl == 3u;
+      fused_state_t<W> fresh;
+      fresh.init(m);
+      exact1_take<W>(st, fresh, nl);
+      dead = nl ? 0u : (dead | (fl == 1u ? 1u : 0u));
+      const uint32_t hit = (fl == 0u && st.score <= tau && dead == 0u) ? 1u : 0u;
+      if (OWN) hm = (hm << 1) | (hit & (seen ^ 1u));
+      seen = nl ? 0u : (seen | hit);
+   }
+}
+
+/* word k (0..31) of a lane's 128-byte chunk */
+__device__ __forceinline__ uint32_t stream_word32(const fused_v4u (&v)[8], int k)
+{
+   const fused_v4u &q = v[k >> 2];
+   return (k & 3) == 0 ? q.x : (k & 3) == 1 ? q.y : (k & 3) == 2 ? q.z : q.w;
+}
+
 /* SQ_CONVERT (reference libseeq.c:223-228: a byte that is not A C G T N or a terminator counts as 'N'): four text bytes
  * with every byte outside the alphabet replaced by 'N' -- and NUL, which ends the line in every mode (seeqcore.h:89-111,
  * libseeq.c:267-270), by a byte of the DEAD column -- so that the walk over them is exact.
@@ -166,15 +204,23 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t x)
  * chain whose warm-up window holds one has not seen enough of the line when its own bytes begin: it reports the line its
  * first byte lies in as a candidate whatever the walk says (a made-up first hit), the wave flags the scan as a superset
  * (wg_part flag 4) and the exact pass, which knows how to skip, verifies the candidates. */
-template <int WU, bool FA, bool LL, int SUB = 0>
-__global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
+/* MY = 1 / 2 (words of the bit-vector column): the MYERS MODE -- patterns of <= 62 positions that have no automaton small
+ * enough for LDS, on text whose lines are too long for the per-line kernels (a chromosome per line: the reference's own
+ * benchmark, doc/response.tex:181-232, m = 27 .. 42 with up to 15 errors).  Same frame, same bookkeeping, same exact
+ * verdicts on clean text; the walk is the Myers/Hyyro column itself, one chain per lane warmed up over the 4 * WU >= m + tau
+ * - 1 bytes before it (WU = 16 or 32 words, all from the previous lane through DPP).  ~25 (W = 1) / ~35 (W = 2) VALU
+ * instructions per text byte and no table: VALU-bound at ~1 TB/s -- where the generic path, one LINE per lane, took 45 to
+ * 85 s for the 3.2 GB of that benchmark, 7 times the reference's own time on one core. */
+template <int WU, bool FA, bool LL, int SUB = 0, int MY = 0>
+__global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs a)
 {
    constexpr int NW = STREAM_NW;
    constexpr int CH = 128;                                /* bytes per lane: one 128-byte memory line, consumed whole by its lane */
    constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
    constexpr int NM = CH / 32;                            /* mask registers per lane */
    constexpr uint32_t TB = 64u * CH;                      /* tile bytes */
-   static_assert(WU == 4 || WU == 6 || WU == 8, "warm-up is 16, 24 or 32 bytes");
+   static_assert(MY ? (WU == 16 || WU == 32) : (WU == 4 || WU == 6 || WU == 8), "warm-up is 16, 24 or 32 bytes (Myers mode: 64 or 128)");
+   static_assert(!MY || SUB == 0, "the Myers mode steps every byte through its own EQ table");
    extern __shared__ __align__(16) uint8_t dsmem[];
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,7 +262,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
       }
       /* the 32 bytes before the tile (lane 0's warm-up); '\n' when the buffer starts here */
       fused_v4u pa = fused_v4u{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}, pb = pa;
-      if (t0 >= 32) {
+      if (!MY && t0 >= 32) {
          pa = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 32);
          pb = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + t0 - 16);
       }
@@ -272,7 +318,39 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_stream(FusedArgs a)
          if (LL && lane == 0) { a.tile_dirty[tile] = (flag || badlanes) ? 1u : 0u; a.tile_dmask[tile] = badlanes; }
       }
       uint32_t hmask[NM], nmask[NM];
-      {
+      if (MY) {
+         /* ---- Myers mode: one chain per lane, warmed up over the previous lane's last WU words (lane 0: the words before
+                 the tile -- one per lane 0..31 in `hal`, '\n' where the buffer starts) ---- */
+         const uint32_t eqb = (uint32_t)(uintptr_t)(fused_lds_cu32 *)(const uint32_t *)dsmem;
+         uint32_t hal = 0x0A0A0A0Au;
+         if (t0 >= 128) hal = *reinterpret_cast<const uint32_t __attribute__((aligned(1))) *>(a.text + t0 - 128 + 4 * (lane & 31));
+         constexpr int MW = MY ? MY : 1;
+         fused_state_t<MW> st;
+         st.init((uint32_t)a.m);
+         uint32_t dead = 0, seen = 0, hm = 0;
+         /* WU + 32 words, the EQ lookups of a word issued one word ahead of its column steps and no further: left alone the
+            compiler hoists the lookups of ALL words to the top (every one of them independent of the column) and spills
+            their 250 results.  The empty asm ties the next word to the state after the previous word's steps. */
+         fused_eq_t<MW> ev[2][4];
+         {
+            uint32_t w0 = stream_from_prev_lane(stream_word32(v, 32 - WU), (uint32_t)__builtin_amdgcn_readlane((int)hal, 32 - WU));
+            stream_myers_lookup4<MW>(w0, eqb, ev[0]);
+         }
+#pragma unroll
+         for (int k = 0; k < WU + 32; k++) {
+            if (k + 1 < WU + 32) {
+               const int kk = k + 1 - WU;                   /* word index in my chunk; < 0: the previous lane's */
+               uint32_t wn = kk < 0 ? stream_from_prev_lane(stream_word32(v, 32 + kk), (uint32_t)__builtin_amdgcn_readlane((int)hal, 32 + kk))
+                                    : stream_word32(v, kk);
+               asm volatile("" : "+v"(wn) : "v"(seen), "v"(st.score));
+               stream_myers_lookup4<MW>(wn, eqb, ev[(k + 1) & 1]);
+            }
+            if (k == WU) { seen = 0; hm = 0; }              /* every chain reports the first hit of a line inside its OWN bytes */
+            if (k < WU) stream_myers_step4<MW, false>(ev[k & 1], st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);
+            else stream_myers_step4<MW, true>(ev[k & 1], st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);
+            if (k >= WU && ((k - WU) & 7) == 7) { hmask[(k - WU) >> 3] = hm; hm = 0; }
+         }
+      } else {
          /* Two chains per lane: A = bytes 0..63 (warm-up: the previous lane's last bytes), B = bytes 64..127
             (warm-up: my own bytes before 64).  Same result, 16 % more gathers, but two of them in flight. */
          uint32_t sa = 0, sb = 0;

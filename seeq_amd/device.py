@@ -97,10 +97,10 @@ class Scanner:
         _check(self._lib.seeqdevScanSetLineHint(self._h, float(avg_bytes_per_line)))
 
     def last_path(self):
-        return {1: "generic", 3: "fused", 5: "fused", 6: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "generic", 3: "fused", 5: "fused", 6: "fused", 7: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
     def last_kernel(self):
-        return {1: "k_forward", 3: "k_direct", 5: "k_stream", 6: "k_pair"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "k_forward", 3: "k_direct", 5: "k_stream", 6: "k_pair", 7: "k_myers"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
     def last_filter(self):
         """True when the last k_stream run walked a partition filter automaton (candidates verified by the exact pass)."""

@@ -1056,7 +1056,7 @@ def test_stream_fuzz_long_lines(gpu, capi, oracle, seg, monkeypatch):
         expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL, fasta=fasta)
         c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH, fasta)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (it, pattern, tau)
-    assert seen.get("k_stream", 0) >= 24, seen
+    assert seen.get("k_stream", 0) + seen.get("k_myers", 0) >= 24, seen
 
 
 def test_long_string_match(gpu, capi, oracle):
