@@ -137,6 +137,8 @@ struct ScanArgs {
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
    uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: m + tau - 1 */
+   uint32_t       window_ok;    /* k_pair: every candidate the walk dropped is announced (nh[] bit 1 of the kept one) and repeats of a line
+                                   follow it in the hit list -- a line with ONE candidate is scanned over that candidate's window only */
    Counters      *cnt;
 };
 
@@ -788,6 +790,7 @@ struct ScanKnobs {
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
    int  pair_exp;        /* SEEQ_PAIR_EXP=2..4: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
+   bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
@@ -856,6 +859,7 @@ struct seeqdev_scan {
    bool no_stream;             /* k_stream met a line it cannot address (starts > 1 GiB before its segment): use the per-line kernels */
    bool force_ll;              /* a read-length looking buffer had hits inside very long lines: use k_stream's long-line variant */
    bool no_stream_nd;          /* SQ_CONVERT / SQ_IGNORE: the text has non-DNA bytes, k_stream (exact for clean text only) is off */
+   bool no_window;             /* k_pair's candidates: a line had candidates on both sides of a segment seam -- whole lines are scanned */
    int  fallback_ttl;          /* scans left before the three fall-back flags above are dropped and the fast path is tried again (one text with a
                                   long line or foreign bytes must not slow a long-lived context down for good) */
    unsigned sample_age;        /* runs since the line-length sample was taken (a reused buffer may hold other text by now) */
@@ -910,6 +914,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       v = getenv("SEEQ_STREAM_WU");    kn.min_wu = v ? atoi(v) : 0;
       v = getenv("SEEQ_NO_MYERS");     kn.no_myers = v && atoi(v) == 1;
+      v = getenv("SEEQ_NO_WINDOW");    kn.no_window = v && atoi(v) == 1;
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
       s->ncu = 256;
       int dev = 0;
@@ -1392,6 +1397,7 @@ static int run_segments(seeqdev_scan *s)
       a.use_nh = need_nh ? (use_stream ? 3u : 1u) : 0u;
       a.filter = filter ? 1u : 0u;
       a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1) + (use_pair ? 1u : 0u);    /* (k_pair reports the second byte of a pair) */
+      a.window_ok = use_pair && !s->no_window && !kn.no_window ? 1u : 0u;
       a.cnt = c;
 
       if (use_fused) {
@@ -1545,7 +1551,7 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
    if (use_device(s->device)) return -1;
    s->pat = pat; s->text = d_text; s->nbytes = nbytes; s->options = options; s->want = want;
    s->ran = false;
-   if ((s->no_stream || s->no_stream_nd || s->force_ll) && --s->fallback_ttl <= 0) s->no_stream = s->no_stream_nd = s->force_ll = false;
+   if ((s->no_stream || s->no_stream_nd || s->force_ll || s->no_window) && --s->fallback_ttl <= 0) s->no_stream = s->no_stream_nd = s->force_ll = s->no_window = false;
    /* Optimistic default workspace: lines average >= 32 bytes, one line in 8 hits, 1 record per hit line.
       A too-small workspace is detected on the device and fixed by one re-run in seeqdevScanFetch. */
    const size_t seg = nbytes < s->seg_bytes ? nbytes : s->seg_bytes;
@@ -1623,7 +1629,8 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
       if (h.overflow & 8u) s->no_stream = true;
       if (h.overflow & 16u) s->no_stream_nd = true;
       if (h.overflow & 32u) s->force_ll = true;
-      if (h.overflow & (8u | 16u | 32u)) s->fallback_ttl = 32;
+      if (h.overflow & 128u) s->no_window = true;            /* a line with candidates on both sides of a segment seam */
+      if (h.overflow & (8u | 16u | 32u | 128u)) s->fallback_ttl = 32;
       if (h.overflow & 4u) {
          /* need_records keeps counting after the overflow, so it is the total of this run. */
          nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;

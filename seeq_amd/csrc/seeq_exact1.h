@@ -199,6 +199,10 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          candidate with a fresh column.  A chromosome-long line costs its hits, not its length. */
       bool win = false;
       uint32_t wend = 0, knext = k + 1;                    /* end of the current window (column), next hit-list entry */
+      /* k_pair (window_ok): the candidates of this line are this entry and the repeats behind it, and no chain dropped any.
+         Every occurrence of the line starts within m + tau before one of them and ends within m + tau behind it
+         (seeq_pair.h): beyond `stop_at` the capped score is tau + 1 as at a terminator, and the scan ends there. */
+      uint32_t stop_at = 0xFFFFFFFFu;
       int32_t lastsub = -0x40000000;                       /* column of the last score <= tau seen */
       if (hit_col && (trusted || walk || a.filter) && !done) {
          const uint32_t col = hit_col[k];
@@ -208,6 +212,15 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          /* (not trusted: no byte outside the alphabet up to the candidate itself -- a skipped byte inside the warm-up
             columns, SQ_IGNORE, would leave the fresh column short of real characters) */
          if (col > a.skip_back && (trusted || exact1_clean(a, off, off + col))) pos = col - a.skip_back;
+         /* (COUNT only: nh[] holds offsets by the time EMIT runs; an EMIT that scans again scans on -- and finds nothing more) */
+         if (MODE == SQ_MODE_COUNT && a.window_ok) {
+            /* the line's further candidates are the repeats behind this entry (a third of the hit lines has one: an occurrence
+               near the end of a chain is seen by the next chain's warm-up, which then reports its own first pair): the scan
+               runs from before the first candidate to behind the last one */
+            uint32_t lastcol = col, unbounded = a.nh[k] & 2u;
+            for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) { lastcol = hit_col[j] - hs; unbounded |= a.nh[j] & 2u; }
+            if (!unbounded) stop_at = lastcol + m + tau1 + 1u;
+         }
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                   uint32_t dn = done ? 1u : 0u;
 #pragma unroll
                   for (int cc = 0; cc < 4; cc++) {
-                     dn |= ev[cc].w0 & FUSED_FLAG_TERM;
+                     dn |= (ev[cc].w0 & FUSED_FLAG_TERM) | (pos + t4 + cc >= stop_at ? 1u : 0u);
                      st.step(ev[cc]);
                      const uint32_t sc = st.score < tau1 ? st.score : tau1;
                      const uint32_t cur = dn ? tau1 : sc;
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
                const uint32_t any_u = (MODE == SQ_MODE_COUNT ? count_any : match_opt != SQ_ALL) ? 1u : 0u;
 #pragma unroll
                for (int cc = 0; cc < 4; cc++) {
-                  const uint32_t term_u = ev[cc].w0 & FUSED_FLAG_TERM;            /* (= 1) */
+                  const uint32_t term_u = (ev[cc].w0 & FUSED_FLAG_TERM) | (pos + t4 + cc >= stop_at ? 1u : 0u);      /* (= 1) */
                   st.step(ev[cc]);
                   const uint32_t m1 = st.score | (0u - term_u);                   /* the terminator's step: tau + 1 */
                   const uint32_t cur = m1 < tau1 ? m1 : tau1;

@@ -18,7 +18,7 @@
  *   - Two chains per lane (bytes 0-63 / 64-127) as in k_stream, each warmed up over the 4 * WU >= warm bytes before it.
  *     A walk that accepts DURING its warm-up restarts there and may then miss an occurrence that ends in its own first
  *     bytes (the restart sits inside it) while the flag is somebody else's position -- possibly on the line before: such
- *     a lane reports the first pair of its chains as candidates (the warm-up states OR-ed together, bit 0 tested once).
+ *     a chain reports its own first pair as a candidate (the warm-up states OR-ed together, bit 0 tested once).
  *   - What else a tile needs from its text -- the alphabet check and the newline masks -- is computed word by word
  *     BETWEEN a step's two gathers and the instructions that need their results, i.e. in the shadow of the LDS latency
  *     the walk is made of (fast check: upper case A C G T N and newlines only -- v_perm + v_sad_u8 per word; a tile that
@@ -73,15 +73,15 @@ __device__ __forceinline__ void pair_chk(uint32_t w, uint32_t &bad, uint32_t &nm
    nm = first_of_two ? __builtin_amdgcn_udot4(nf, 0x10204080u, nm << 8, false) : __builtin_amdgcn_udot4(nf, 0x01020408u, nm, false);
 }
 
-/* four warm-up bytes of each chain: walk; the states are OR-ed into `seen` (bit 0: the walk accepted) */
+/* four warm-up bytes of each chain: walk; the states of a chain are OR-ed into its `seen` (bit 0: the walk accepted) */
 template <int EXP>
-__device__ __forceinline__ void pair_warm4x2(uint32_t &sa, uint32_t wa, uint32_t &sb, uint32_t wb, uint32_t &seen)
+__device__ __forceinline__ void pair_warm4x2(uint32_t &sa, uint32_t wa, uint32_t &sb, uint32_t wb, uint32_t &seena, uint32_t &seenb)
 {
    const uint32_t ta = pair_prep(wa), tb = pair_prep(wb);
    uint32_t ada, adb;
    /* (asm: as plain C the chain of ORs is re-associated into a tree evaluated after the warm-up, with every state kept -- spilled -- until then) */
-   PAIR_X2(1) asm("v_or3_b32 %0, %0, %1, %2" : "+v"(seen) : "v"(sa), "v"(sb));
-   PAIR_X2(3) asm("v_or3_b32 %0, %0, %1, %2" : "+v"(seen) : "v"(sa), "v"(sb));
+   PAIR_X2(1) asm("v_or_b32 %0, %0, %1" : "+v"(seena) : "v"(sa)); asm("v_or_b32 %0, %0, %1" : "+v"(seenb) : "v"(sb));
+   PAIR_X2(3) asm("v_or_b32 %0, %0, %1" : "+v"(seena) : "v"(sa)); asm("v_or_b32 %0, %0, %1" : "+v"(seenb) : "v"(sb));
 }
 
 /* four owned bytes of each chain: walk + pair masks (first pair of a chain ends up in bit 0), and the per-word checks of
@@ -197,11 +197,11 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       uint32_t hm[2], nmask[NM];
       uint32_t tile_bad;
       {
-         uint32_t sa = 0, sb = 0, hma = 0, hmb = 0, seen = 0, bad = 0, nma = 0, nmb = 0;
+         uint32_t sa = 0, sb = 0, hma = 0, hmb = 0, seena = 0, seenb = 0, bad = 0, nma = 0, nmb = 0;
 #pragma unroll
          for (int k = 8 - WU; k < 8; k++)
             pair_warm4x2<EXP>(sa, stream_from_prev_lane(pair_word8(v[NQ - 2], v[NQ - 1], k), halo_nl ? 0x0A0A0A0Au : (uint32_t)__builtin_amdgcn_readlane((int)halo, k)),
-                         sb, pair_word8(v[NQ / 2 - 2], v[NQ / 2 - 1], k), seen);
+                         sb, pair_word8(v[NQ / 2 - 2], v[NQ / 2 - 1], k), seena, seenb);
 #pragma unroll
          for (int q = 0; q < NQ / 2; q++) {
             pair_own4x2<EXP>(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, bad, true);
@@ -212,9 +212,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          }
          tile_bad = bad;
          /* first pair of a chain in bit 31; a walk that accepted during its warm-up: my first pairs are candidates (see the header) */
-         const uint32_t fake = (seen & 1u) << 31;
-         hm[0] = __builtin_bitreverse32(hma) | fake;
-         hm[1] = __builtin_bitreverse32(hmb) | fake;
+         hm[0] = __builtin_bitreverse32(hma) | ((seena & 1u) << 31);
+         hm[1] = __builtin_bitreverse32(hmb) | ((seenb & 1u) << 31);
       }
       if (EXP == 3) {
          wv_hitlines += (uint32_t)__popc(hm[0] ^ hm[1] ^ nmask[0] ^ nmask[1] ^ nmask[2] ^ nmask[3]) + tile_bad;
@@ -269,6 +268,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          behind its last one, the first; between two newlines (short lines) all of them.  Only the first candidate of a
          line matters to the exact pass; every further one is a hit-list entry with nothing to do.  Wave-uniform, rare on
          read-length lines with a prefix automaton, the rule with a partition filter. */
+      uint32_t more = 0;                                  /* bit x: chain x dropped candidates here (the kept ones say so to the exact pass) */
       if (__ballot(((hm[0] & (hm[0] - 1u)) | (hm[1] & (hm[1] - 1u))) != 0)) {
 #pragma unroll
          for (int x = 0; x < 2; x++) {
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
             const uint32_t mc = sc >= 32u ? 0u : 0xFFFFFFFFu >> sc;
             const uint32_t ha = h & ma, hc = h & mc & ~ma;
             hm[x] = (h & ~ma & ~mc) | (ha ? 0x80000000u >> (uint32_t)__builtin_clz(ha) : 0u) | (hc ? 0x80000000u >> (uint32_t)__builtin_clz(hc) : 0u);
+            more |= hm[x] != h ? 1u << x : 0u;
          }
       }
       uint32_t lane_nl = 0;
@@ -344,8 +345,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
                      const uint32_t st1 = nlt ? (uint32_t)lane * CH + 32u * r + lz - (uint32_t)__builtin_ctz(nlt) + 1u : before;
                      const uint32_t hp = (uint32_t)lane * CH + 32u * r + lz;           /* the candidate, tile-relative */
                      const uint32_t pos = st1 ? st1 - 1u : hp;
-                     /* {tile | unresolved, rank | column of the candidate << 13, line start (or candidate) position, line rank} */
-                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord | ((hp - pos) << 13),
+                     /* {tile | unresolved, rank | column of the candidate << 13 | "its chain dropped candidates" << 31, line start (or candidate) position, line rank} */
+                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord | ((hp - pos) << 13) | (((more >> (r >> 1)) & 1u) << 31),
                                                          tile * TB + pos + a.pos_bias, nlb + nb);
                      ord++;
                   }

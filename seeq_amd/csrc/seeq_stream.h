@@ -531,8 +531,10 @@ __global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t ns
             const uint32_t dst = th[u] + (e[u].y & 0x1FFFu);
             hit_start[dst] = e[u].z;
             hit_line[dst] = lines0 + tc[u] + e[u].w + 1u;   /* 1-based, reference seeq.c:377 */
-            unresolved[dst] = e[u].x >> 31;                  /* e.z is the hit itself: the line starts before the tile */
-            hit_col[dst] = e[u].y >> 13;
+            /* bit 0: e.z is the hit itself (the line starts before the tile); bit 1 (k_pair): the chain dropped further
+               candidates of this line -- the exact pass must not stop behind this one's window */
+            unresolved[dst] = (e[u].x >> 31) | ((e[u].y >> 31) << 1);
+            hit_col[dst] = (e[u].y >> 13) & 0x3FFFFu;
          }
       }
    }
@@ -591,11 +593,14 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit
       const uint32_t ln = a.hit_line[k];
       const uint32_t prev = k ? a.hit_line[k - 1] : c->prev_hit_line;
       if (ln == prev) {                                   /* a repeat: keep the candidate's position for k_exact1's window walk */
-         hit_col[k] = a.nh[k] ? a.hit_start[k] : a.hit_start[k] + hit_col[k];
+         hit_col[k] = (a.nh[k] & 1u) ? a.hit_start[k] : a.hit_start[k] + hit_col[k];
+         /* k_pair, windows: the line's first candidate belongs to the segment before this one, whose exact pass could not
+            know of this one -- the run is void, the next one scans candidate lines to their ends (seeqdevScanFetch) */
+         if (a.window_ok && ln == c->prev_hit_line) atomicOr(&c->overflow, 128u);
          a.hit_start[k] = 0xFFFFFFFFu;
          continue;
       }
-      if (!a.nh[k]) continue;                             /* k_stream already found the start of the line */
+      if (!(a.nh[k] & 1u)) continue;                      /* k_stream already found the start of the line */
       const uint64_t hp = a.seg_base + a.hit_start[k];   /* a byte of the line (inside the segment); never '\n' */
       if (hp >= a.nbytes || hp < segb || hp >= segb + a.seg_len) {       /* cannot be: an entry the scan kernel never wrote -- fail loudly, touch nothing */
          atomicOr(&c->overflow, 64u);
