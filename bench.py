@@ -469,6 +469,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-memory end-to-end measurement")
     ap.add_argument("--no-per-call", action="store_true", help="skip the seeqStringMatch per-call measurement")
+    ap.add_argument("--no-packed", action="store_true", help="skip the packed-batch scan of the same reads")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI wall-clock measurement (timed region iii)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--check-lines", type=int, default=1_000_000,
@@ -667,6 +668,73 @@ def main():
             out["end_to_end_pinned_host"] = {"lines": ne, "seconds": best, "lines_per_s": ne / best,
                                              "gb_per_s": ne * (READ_LEN + 1) / best / 1e9,
                                              "note": "H2D over PCIe + scan + D2H records; best of 3"}
+        if world == 1 and not args.no_packed and READ_LEN <= 256:
+            # The same reads as a PACKED batch (2 bits per base + an N mask: seeq_amd.h seeqdev_packed_t; SURVEY 8d allows a scan-only
+            # figure on pre-packed data beside the headline): packed on the device here, scanned from HBM, every count and every record
+            # compared with the ASCII run's; then timed region (ii) again with the packed bytes coming from page-locked host memory.
+            try:
+                stride, nstride = (READ_LEN + 3) // 4, (READ_LEN + 7) // 8
+                pb = torch.empty(n * stride, dtype=torch.uint8, device=device)
+                pn = torch.empty(n * nstride, dtype=torch.uint8, device=device)
+                dev.pack_reads_device(text.data_ptr(), n, READ_LEN, pb.data_ptr(), pn.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                scp = dev.Scanner(stream)
+                scp.reserve(0, 0, max(n // 6 + 1024, 8192 * 64), rec_cap)
+                scp.set_profiling(True)
+                for _ in range(2):
+                    scp.run_packed(pat, pb.data_ptr(), pn.data_ptr(), n, READ_LEN, options=opt, want=want)
+                    pc = scp.fetch()
+                torch.cuda.synchronize()
+                tp0 = time.perf_counter()
+                psteps = max(3, args.steps // 2)
+                pfwd = 0.0
+                plaunch = 0
+                for _ in range(psteps):
+                    scp.run_packed(pat, pb.data_ptr(), pn.data_ptr(), n, READ_LEN, options=opt, want=want)
+                    pc = scp.fetch()
+                    tm = scp.last_times_ms()
+                    pfwd += tm["forward"]
+                    plaunch += tm["forward_launches"]
+                torch.cuda.synchronize()
+                pel = (time.perf_counter() - tp0) / psteps
+                same = all(pc[k] == local[k] for k in ("nlines", "nmatchlines", "nhits", "nrecords"))
+                if want == dev.WANT_RECORDS and same:
+                    same = bool(np.array_equal(scp.records(pc["nrecords"]), sc.records(local["nrecords"])))
+                pbytes = n * (stride + nstride)
+                out["packed_scan"] = {"lines_per_s": n / pel, "ms_per_step": pel * 1e3, "bytes_per_read": stride + nstride,
+                                      "packed_gb_per_s": pbytes / pel / 1e9, "ascii_equivalent_gb_per_s": n * (READ_LEN + 1) / pel / 1e9,
+                                      "scan_kernel_ms_per_launch": pfwd / max(1, plaunch), "scan_kernel_launches_per_step": plaunch / psteps,
+                                      "scan_kernel_hbm_frac": (pbytes / (plaunch / psteps)) / (pfwd / max(1, plaunch) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "identical_to_ascii_run": same,
+                                      "note": "2 bits per base + 1 bit per base N mask, one read per lane, no warm-up (seeq_packed.h); scan-only figure on "
+                                              "pre-packed data, beside the headline (SURVEY 8d)"}
+                if not args.no_e2e:
+                    ne = min(n, 10_000_000)
+                    hb = pb[:ne * stride].cpu().pin_memory()
+                    hn = pn[:ne * nstride].cpu().pin_memory()
+                    db = torch.empty_like(pb[:ne * stride])
+                    dn = torch.empty_like(pn[:ne * nstride])
+                    sc3 = dev.Scanner(stream)
+                    best = None
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        db.copy_(hb, non_blocking=True)
+                        dn.copy_(hn, non_blocking=True)
+                        sc3.run_packed(pat, db.data_ptr(), dn.data_ptr(), ne, READ_LEN, options=opt, want=want)
+                        c3 = sc3.fetch()
+                        if want == dev.WANT_RECORDS:
+                            sc3.records(c3["nrecords"])
+                        dt = time.perf_counter() - t1
+                        best = dt if best is None else min(best, dt)
+                    out["end_to_end_pinned_host_packed"] = {"lines": ne, "seconds": best, "lines_per_s": ne / best,
+                                                            "packed_gb_per_s": ne * (stride + nstride) / best / 1e9,
+                                                            "note": "packed bases + N mask from page-locked host memory: H2D + scan + D2H records; best of 3"}
+                    sc3.close()
+                scp.close()
+                del pb, pn
+            except Exception as e:                      # (a pattern without a pair automaton: ENOTSUP)
+                out["packed_scan"] = {"error": str(e)}
         if world == 1 and not args.no_per_call:
             out["per_call"] = per_call_rates(PATTERN, TAU, READ_LEN)
         if not args.no_cpu_baseline and world == 1:
@@ -679,6 +747,10 @@ def main():
             est = out["cpu_baseline"].get("whole_socket_estimate_lines_per_s") or cpu
             regions = {"device_resident": {"lines_per_s": value, "gpu_over_cpu": value / cpu, "meets_10x": value / cpu >= 10.0,
                                            "over_whole_socket_estimate": value / est}}
+            if "end_to_end_pinned_host_packed" in out:
+                e = out["end_to_end_pinned_host_packed"]["lines_per_s"]
+                regions["end_to_end_pinned_host_packed"] = {"lines_per_s": e, "gpu_over_cpu": e / cpu, "meets_10x": e / cpu >= 10.0, "over_whole_socket_estimate": e / est,
+                                                            "note": "region (ii) with the reads handed over packed (57 instead of 151 bytes per read over the link)"}
             if "end_to_end_pinned_host" in out:
                 e = out["end_to_end_pinned_host"]["lines_per_s"]
                 regions["end_to_end_pinned_host"] = {"lines_per_s": e, "gpu_over_cpu": e / cpu, "meets_10x": e / cpu >= 10.0, "over_whole_socket_estimate": e / est,

@@ -100,7 +100,10 @@ int seeqdevScanSetLineHint(seeqdev_scan_t * scan, double avg_bytes_per_line);
 /* Which device path served the last run: 1 = generic (newline index + k_forward<W>),
  * 3 = one-pass per-line bit-vector kernel, text in registers (k_direct),
  * 5 = one-pass table-driven line-agnostic kernel (k_stream: every lane walks a fixed chunk of the text
- *     through the pattern's Levenshtein automaton held in LDS).
+ *     through the pattern's Levenshtein automaton held in LDS),
+ * 6 = the same walk, two text bytes per table step, over the pattern's pair automaton (k_pair: candidates, verified),
+ * 7 = the same frame with the bit-vector column instead of a table (k_stream's Myers mode: patterns without an automaton on
+ *     long lines), 8 = a packed read batch (seeqdevScanPacked).
  * The one-pass kernels serve patterns <= 62 positions in ONE pass over the text. */
 int seeqdevScanLastPath(const seeqdev_scan_t * scan);
 /* 1 when the last run's k_stream walked a partition FILTER automaton (candidates verified by the exact pass)
@@ -158,6 +161,36 @@ int seeqdevScanRunMulti(seeqdev_scan_t * scan, const seeqdev_pattern_t * const *
 int seeqdevScanHostMulti(seeqdev_scan_t * scan, const seeqdev_pattern_t * const * pats, int npat, const char * host_text, size_t nbytes,
                          int options, int want, seeqdev_counts_t * counts);
 int seeqdevScanMultiRecords(const seeqdev_scan_t * scan, int k, const seeqdev_hit_t ** rec, size_t * nrec);
+
+/* PACKED READ BATCHES -- 2 bits per base instead of a byte: a quarter of the HBM (and PCIe) traffic of the ASCII scan for
+ * read sets that are kept packed anyway (BAM, .2bit, a sequencer's own format).  Layout, all device pointers:
+ *   bases : four bases per byte, the FIRST base of a byte in its bits 7-6; code = (ASCII >> 1) & 3, i.e. A 0, C 1, T/U 2, G 3;
+ *           read r starts at bases + r * stride (stride >= ceil(read_len / 4); padding bits are ignored);
+ *   nmask : optional (NULL: no N anywhere): one bit per base, first base of a byte in bit 7, set where the base is N (the
+ *           2-bit code of such a base is ignored); read r at nmask + r * nstride (nstride >= ceil(read_len / 8));
+ *   every read has read_len bases (1 .. 256).
+ * The result is that of seeqdevScanRun over the same reads as ASCII text, one read per line ('line' of a record = read
+ * index + 1), for every match option and every `want` -- the scan kernel walks the packed bytes (one read per lane, no warm-
+ * up, seeq_packed.h), candidate reads are unpacked and verified by the exact pass.  Asynchronous: seeqdevScanFetch waits.
+ * Patterns of up to 62 positions that have a pair automaton (else -1, errno ENOTSUP: scan the text).
+ * What replaces what: the reference has no packed input; this is the boundary's batch entry for callers that do. */
+typedef struct {
+   const void * bases;
+   const void * nmask;
+   uint64_t     nreads;
+   uint32_t     read_len;
+   uint32_t     stride;
+   uint32_t     nstride;
+} seeqdev_packed_t;
+int  seeqdevScanPacked(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const seeqdev_packed_t * batch, int options, int want);
+/* Host helper: ASCII reads (one per line, each exactly read_len bases of A C G T U N in either case) -> that layout, into
+ * caller-provided host buffers (nmask_out may be NULL when the text holds no N: an N is then an error).  Returns the number
+ * of reads, or -1 (errno EINVAL: another byte, a line of another length). */
+long seeqdevPackReads(const char * text, size_t nbytes, uint32_t read_len, void * bases_out, void * nmask_out, uint32_t stride, uint32_t nstride);
+/* The same device to device: d_text holds nreads lines of read_len bases + '\n' in HBM (a byte that is no base counts as N with
+ * a mask, as A without).  Asynchronous on hip_stream (a hipStream_t; NULL = the null stream). */
+int  seeqdevPackReadsDevice(const void * d_text, uint64_t nreads, uint32_t read_len, void * d_bases, void * d_nmask, uint32_t stride, uint32_t nstride,
+                            void * hip_stream);
 
 /* Time (ms) of that H2D copy for the last fetched scan (profiling on), from HIP events on the context's stream. */
 int seeqdevScanLastCopyMs(const seeqdev_scan_t * scan, float * h2d_ms);

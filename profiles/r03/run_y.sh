@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, GPU call y: behind k_pair, a line with one candidate is scanned over that candidate's window only (A/B: SEEQ_NO_WINDOW=1).
 set -u
-O=gpurun_out/r03ac; mkdir -p $O
+O=gpurun_out/r03ad; mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "pair or fuzz or chunk or edge or shard or config1" > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log
 tail -6 $O/pytest.log

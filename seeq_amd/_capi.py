@@ -35,6 +35,11 @@ class seeq_t(C.Structure):
                 ("dfa", C.c_void_p), ("rdfa", C.c_void_p)]
 
 
+class seeqdev_packed_t(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("nmask", C.c_void_p), ("nreads", C.c_uint64), ("read_len", C.c_uint32),
+                ("stride", C.c_uint32), ("nstride", C.c_uint32)]
+
+
 class seeqfile_t(C.Structure):
     _fields_ = [("flags", C.c_int), ("line", C.c_size_t), ("info", C.c_char_p), ("fdi", C.c_void_p)]
 
@@ -62,7 +67,7 @@ EXPORTS = [
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
     "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
-    "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords",
+    "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
 ]
 
 
@@ -176,6 +181,12 @@ def lib():
     L.seeqdevScanHostMulti.restype = C.c_int
     L.seeqdevScanMultiRecords.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.seeqdevScanMultiRecords.restype = C.c_int
+    L.seeqdevScanPacked.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(seeqdev_packed_t), C.c_int, C.c_int]
+    L.seeqdevScanPacked.restype = C.c_int
+    L.seeqdevPackReads.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.seeqdevPackReads.restype = C.c_long
+    L.seeqdevPackReadsDevice.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.seeqdevPackReadsDevice.restype = C.c_int
     L.seeqdevHostAlloc.argtypes = [C.c_size_t]
     L.seeqdevHostAlloc.restype = C.c_void_p
     L.seeqdevHostFree.argtypes = [C.c_void_p]

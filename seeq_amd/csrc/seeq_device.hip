@@ -137,6 +137,7 @@ struct ScanArgs {
    uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
    uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
    uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: m + tau - 1 */
+   const uint32_t *hit_last;    /* packed read batches: per hit line the column of its LAST candidate (else NULL: the repeats in the hit list say) */
    uint32_t       window_ok;    /* k_pair: every candidate the walk dropped is announced (nh[] bit 1 of the kept one) and repeats of a line
                                    follow it in the hit list -- a line with ONE candidate is scanned over that candidate's window only */
    Counters      *cnt;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(WG) void k_nl_write(ScanArgs a)
 
 /* ========================================================================== */
 /* Generic two-level exclusive scan over u32 items with a device-side length   */
-/*   XF 0: in = u32[];  XF 1: in = u64[], item = popcount                     */
+/*   XF 0: in = u32[];  XF 1: in = u64[], item = popcount;  XF 2: u32 != 0     */
 /*   n = (*n_ptr + add) >> shift                                              */
 /* ========================================================================== */
 static constexpr int SCAN_ITEMS = 8;                     /* per thread */
@@ -276,6 +277,7 @@ template <int XF>
 __device__ __forceinline__ uint32_t scan_item(const void *in, uint32_t i)
 {
    if (XF == 0) return reinterpret_cast<const uint32_t *>(in)[i];
+   if (XF == 2) return reinterpret_cast<const uint32_t *>(in)[i] != 0u ? 1u : 0u;
    return (uint32_t)__popcll(reinterpret_cast<const uint64_t *>(in)[i]);
 }
 
@@ -553,6 +555,7 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_exact1.h"
 #include "seeq_stream.h"
 #include "seeq_pair.h"
+#include "seeq_packed.h"
 static_assert(STREAM_NW == STREAM_NW_HOST, "waves per k_stream workgroup");
 extern "C" {
 #include "seeq_dfa.h"
@@ -843,6 +846,11 @@ struct seeqdev_scan {
    /* seeqdevScanRunMulti: per pattern of the last multi scan its counts and (host copy) its records */
    seeqdev_counts_t *multi_cnt; size_t *multi_first; int multi_n, cap_multi_n;
    seeqdev_hit_t *multi_rec; size_t cap_multi_rec, multi_nrec;
+   /* packed read batches (seeqdevScanPacked) */
+   uint32_t *pk_cand, *pk_coff; size_t cap_pk_reads;      /* per read of a segment: candidate columns / rank among the candidates */
+   uint8_t  *pk_stage; size_t cap_pk_stage;               /* ASCII lines of the candidate reads */
+   uint32_t *pk_last; size_t cap_pk_last;                 /* per candidate: column of its last candidate */
+   bool      is_packed; seeqdev_packed_t packed;          /* the last run was a packed one (re-run on overflow) */
    /* last run (for the transparent re-run on overflow) */
    const seeqdev_pattern *pat; const void *text; size_t nbytes; int options, want;
    bool ran;
@@ -940,6 +948,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
       void *ob[] = {s->ow.tile_cl, s->ow.tile_hits, s->ow.tile_dirty, s->ow.tile_dmask, s->ow.tmp, s->ow.wg_hits, s->ow.wg_part, s->ow.wg_lastnl};
       for (void *b : ob) if (b) (void)hipFree(b);
    }
+   { void *pk[] = {s->pk_cand, s->pk_coff, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
@@ -1528,8 +1537,160 @@ static int run_segments(seeqdev_scan *s)
    return 0;
 }
 
+/* ========================================================================== */
+/* Packed read batches (seeq_packed.h)                                        */
+/* ========================================================================== */
+static constexpr size_t PACKED_SEG_READS = (size_t)1 << 24;      /* reads per segment: 16 Mi */
+
+static int run_packed(seeqdev_scan *s)
+{
+   const seeqdev_pattern *pat = s->pat;
+   const seeqdev_packed_t &b = s->packed;
+   const int options = s->options, want = s->want;
+   const int match_opt = options & 3;
+   const bool nh_is_count = want == SEEQDEV_WANT_COUNTMATCH || (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   const int fw = pat->wlen <= FUSED_MAX_WLEN ? 1 : 2;
+   Counters *c = s->d_cnt;
+   hipStream_t st = s->stream;
+   const uint32_t L = b.read_len;
+   /* workspace: per read of a segment, per candidate */
+   const size_t seg_reads = b.nreads < PACKED_SEG_READS ? (size_t)b.nreads : PACKED_SEG_READS;
+   if (seg_reads > s->cap_pk_reads) {
+      if (ws_alloc((void **)&s->pk_cand, seg_reads * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->pk_coff, seg_reads * sizeof(uint32_t))) return -1;
+      s->cap_pk_reads = seg_reads;
+   }
+   if (s->cap_hitlines * (size_t)(L + 1) > s->cap_pk_stage) {
+      if (ws_alloc((void **)&s->pk_stage, s->cap_hitlines * (size_t)(L + 1) + 64)) return -1;
+      s->cap_pk_stage = s->cap_hitlines * (size_t)(L + 1);
+   }
+   if (s->cap_hitlines > s->cap_pk_last) {
+      if (ws_alloc((void **)&s->pk_last, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      s->cap_pk_last = s->cap_hitlines;
+   }
+   {  /* block sums of the scans over per-read arrays */
+      const size_t nb = seg_reads / SCAN_BLOCK + 2;
+      if (nb > s->cap_scan_ws) { if (ws_alloc((void **)&s->scan_ws, nb * sizeof(uint32_t))) return -1; s->cap_scan_ws = nb; }
+   }
+   if (s->cap_hitlines * (uint64_t)(L + 1) > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
+   /* EQ tables of the exact pass (as run_segments makes them) */
+   if (s->eq_pat_id != pat->id || s->eq_options != options) {
+      const int Wp = pat->words;
+      for (int dir = 0; dir < 2; dir++)
+         for (int bb = 0; bb < 256; bb++) {
+            const uint8_t cls = sq_class_of((uint32_t)bb, options);
+            uint64_t v;
+            if (cls < 5) {
+               const uint32_t *q = pat->h_peq + (dir * 5 + cls) * Wp;
+               const uint64_t col = (uint64_t)q[0] | (Wp > 1 ? (uint64_t)q[1] << 32 : 0);
+               v = col << (32 * fw - pat->wlen);
+            } else {
+               v = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
+            }
+            uint32_t *dst = s->h_eqtab + (size_t)(dir * 256 + bb) * fw;
+            dst[0] = (uint32_t)v;
+            if (fw == 2) dst[1] = (uint32_t)(v >> 32);
+         }
+      memcpy(s->h_eqtab + (size_t)512 * fw, s->h_eqtab, (size_t)256 * fw * sizeof(uint32_t));
+      s->h_eqtab[(size_t)512 * fw + (size_t)'\n' * fw] |= 3u;
+      HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)768 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, st), EIO);
+      HIP_TRY(hipStreamSynchronize(st), EIO);
+      s->eq_pat_id = pat->id;
+      s->eq_options = options;
+   }
+   HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), st), EIO);
+   const size_t dfa_lds = (size_t)pat->pair_units * 16;
+   int per_cu = occupancy_of(s, (const void *)k_packed_walk, 64 * STREAM_NW, dfa_lds);
+   if (per_cu < 0) return -1;
+   const unsigned wgrid = (unsigned)(s->ncu * per_cu);
+   const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
+   unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 16 ? hit_blocks : (size_t)s->ncu * 16);
+   if (grid_hits == 0) grid_hits = 1;
+   const size_t nseg = (size_t)((b.nreads + PACKED_SEG_READS - 1) / PACKED_SEG_READS);
+   s->prof_segs = 0;
+   if (s->prof && nseg > s->nev_seg) {
+      hipEvent_t *g = (hipEvent_t *)realloc(s->ev, 4 * nseg * sizeof(hipEvent_t));
+      if (!g) { seeqerr = 0; errno = ENOMEM; return -1; }
+      s->ev = g;
+      for (size_t i = 4 * s->nev_seg; i < 4 * nseg; i++) HIP_TRY(hipEventCreate(&s->ev[i]), EIO);
+      s->nev_seg = nseg;
+   }
+   if (s->prof) s->prof_segs = nseg;
+   for (size_t sg = 0; sg < nseg; sg++) {
+      hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
+      PackedArgs p;
+      memset(&p, 0, sizeof p);
+      p.bases = (const uint8_t *)b.bases; p.nmask = (const uint8_t *)b.nmask;
+      p.first = (uint64_t)sg * PACKED_SEG_READS;
+      p.nreads = (uint32_t)(b.nreads - p.first < PACKED_SEG_READS ? b.nreads - p.first : PACKED_SEG_READS);
+      p.read_len = L; p.stride = b.stride; p.nstride = b.nstride;
+      p.total_bytes = b.nreads * (uint64_t)b.stride;
+      p.dfa = pat->d_pair; p.dfa_units = pat->pair_units;
+      p.cand = s->pk_cand; p.coff = s->pk_coff; p.stage = s->pk_stage;
+      p.hit_start = s->hit_start; p.hit_line = s->hit_line; p.hit_col = s->hit_col; p.hit_last = s->pk_last; p.nh = s->nh;
+      p.cap = (uint32_t)s->cap_hitlines;
+      p.line_base = p.first;
+      p.cnt = c;
+      if (ev) { HIP_TRY(hipEventRecord(ev[0], st), EIO); HIP_TRY(hipEventRecord(ev[1], st), EIO); }
+      {
+         void *kargs[] = {&p};
+         HIP_TRY(hipLaunchKernel((const void *)k_packed_walk, dim3(wgrid), dim3(64 * STREAM_NW), kargs, dfa_lds, st), EIO);
+      }
+      if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
+      /* rank of every candidate read, their number */
+      {
+         const unsigned nb = (unsigned)(((size_t)p.nreads + SCAN_BLOCK - 1) / SCAN_BLOCK);
+         hipLaunchKernelGGL(k_scan_reduce<2>, dim3(nb), dim3(WG), 0, st, (const void *)p.cand, s->scan_ws, (const uint32_t *)nullptr, p.nreads, 0u);
+         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WG), 0, st, s->scan_ws, (const uint32_t *)nullptr, p.nreads, 0u, &c->seg_nhitlines);
+         hipLaunchKernelGGL(k_scan_apply<2>, dim3(nb), dim3(WG), 0, st, (const void *)p.cand, s->pk_coff, (const uint32_t *)s->scan_ws,
+                            (const uint32_t *)nullptr, p.nreads, 0u);
+      }
+      hipLaunchKernelGGL(k_packed_counts, dim3(1), dim3(1), 0, st, p);
+      hipLaunchKernelGGL(k_packed_list, dim3((unsigned)(s->ncu * 16)), dim3(256), 0, st, p);
+      hipLaunchKernelGGL(k_packed_stage, dim3((unsigned)(s->ncu * 8)), dim3(256), 0, st, p);
+      /* from here: the exact pass over the staging text, as behind k_pair */
+      ScanArgs a;
+      memset(&a, 0, sizeof a);
+      a.text = s->pk_stage;
+      a.nbytes = s->cap_hitlines * (uint64_t)(L + 1);
+      a.seg_base = 0; a.seg_len = (uint32_t)a.nbytes; a.first_seg = sg == 0;
+      a.peq = pat->d_peq;
+      a.m = pat->wlen; a.tau = pat->tau; a.options = options & ~(MASK_NONDNA | MASK_INPUT); a.want = want;
+      a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = (uint32_t)s->cap_hitlines; a.nh = s->nh;
+      a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
+      a.use_nh = 3u; a.filter = 1u;
+      a.skip_back = (uint32_t)(pat->wlen + pat->tau);
+      a.hit_last = s->pk_last;
+      a.window_ok = 1u;
+      a.cnt = c;
+      const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
+      const uint32_t *hcol = s->hit_col;
+      uint4 *ecache = want == SEEQDEV_WANT_RECORDS ? s->ow.tmp : nullptr;
+      if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+      else hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+      if (nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
+      launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
+      if (want == SEEQDEV_WANT_RECORDS) {
+         hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);
+         const int mo = match_opt == SQ_COUNT ? SQ_FIRST : match_opt;
+         if (fw == 2) { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+                        else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
+         else { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+                else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
+      }
+      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 1 | (!nh_is_count ? 2 : 0));
+      if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
+      HIP_TRY(hipGetLastError(), EIO);
+   }
+   HIP_TRY(hipMemcpyAsync(s->h_cnt, c, sizeof(Counters), hipMemcpyDeviceToHost, st), EIO);
+   s->last_path = 8;
+   s->last_filter = true;
+   return 0;
+}
+
 static int dispatch_run(seeqdev_scan *s)
 {
+   if (s->is_packed) return run_packed(s);
    const int W = s->pat->words;
    if (W <= 1) return run_segments<1>(s);
    if (W <= 2) return run_segments<2>(s);
@@ -1551,6 +1712,7 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
    if (use_device(s->device)) return -1;
    s->pat = pat; s->text = d_text; s->nbytes = nbytes; s->options = options; s->want = want;
    s->ran = false;
+   s->is_packed = false;
    if ((s->no_stream || s->no_stream_nd || s->force_ll || s->no_window) && --s->fallback_ttl <= 0) s->no_stream = s->no_stream_nd = s->force_ll = s->no_window = false;
    /* Optimistic default workspace: lines average >= 32 bytes, one line in 8 hits, 1 record per hit line.
       A too-small workspace is detected on the device and fixed by one re-run in seeqdevScanFetch. */
@@ -1658,6 +1820,83 @@ extern "C" int seeqdevScanCopyRecords(seeqdev_scan_t *s, seeqdev_hit_t *host_out
            EIO);
    HIP_TRY(hipStreamSynchronize(s->stream), EIO);
    return 0;
+}
+
+/* A packed read batch resident in HBM (seeq_amd.h: seeqdev_packed_t, seeq_packed.h): asynchronous, seeqdevScanFetch waits. */
+extern "C" int seeqdevScanPacked(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const seeqdev_packed_t *batch, int options, int want)
+{
+   seeqerr = 0;
+   if (!s || !pat || !batch || want < 0 || want > 2 || (batch->nreads && !batch->bases)) { errno = EINVAL; return -1; }
+   if (batch->read_len < 1 || batch->read_len > 256 || batch->stride < (batch->read_len + 3) / 4 ||
+       (batch->nmask && batch->nstride < (batch->read_len + 7) / 8) || (options & (MASK_INPUT | SEEQDEV_FASTA | SEEQDEV_SINGLELINE))) { errno = EINVAL; return -1; }
+   if (pat->device != s->device) { errno = EINVAL; return -1; }
+   if (use_device(s->device)) return -1;
+   seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
+   if (pat->wlen > FUSED_MAX_WLEN2) { snprintf(g_last_error, sizeof g_last_error, "packed batches: patterns of up to %d positions", FUSED_MAX_WLEN2); errno = ENOTSUP; return -1; }
+   if (__atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
+   if (mp->pair_state != 1) { snprintf(g_last_error, sizeof g_last_error, "packed batches: the pattern has no pair automaton"); errno = ENOTSUP; return -1; }
+   s->pat = pat; s->text = NULL; s->nbytes = 0; s->options = options; s->want = want;
+   s->ran = false;
+   s->is_packed = true;
+   s->packed = *batch;
+   /* optimistic workspace: one read in eight is a candidate (grown by the re-run of seeqdevScanFetch when it is not) */
+   const size_t seg = batch->nreads < PACKED_SEG_READS ? (size_t)batch->nreads : PACKED_SEG_READS;
+   size_t want_hl = s->cap_hitlines, want_rec = s->cap_records;
+   if (!s->user_reserved) {
+      if (seg / 8 + 1024 > want_hl) want_hl = seg / 8 + 1024;
+      if (want_hl > want_rec) want_rec = want_hl;
+   }
+   if (reserve_impl(s, 1, 0, want_hl, want_rec)) return -1;
+   if (dispatch_run(s)) return -1;
+   s->ran = true;
+   return 0;
+}
+
+/* The same for ASCII reads resident in HBM (one per line, each read_len bases + '\n'): device to device, asynchronous on `hip_stream`. */
+extern "C" int seeqdevPackReadsDevice(const void *d_text, uint64_t nreads, uint32_t read_len, void *d_bases, void *d_nmask, uint32_t stride, uint32_t nstride,
+                                      void *hip_stream)
+{
+   seeqerr = 0;
+   if ((!d_text || !d_bases) && nreads) { errno = EINVAL; return -1; }
+   if (read_len < 1 || read_len > 256 || stride < (read_len + 3) / 4 || (d_nmask && nstride < (read_len + 7) / 8)) { errno = EINVAL; return -1; }
+   if (nreads == 0) return 0;
+   const uint64_t blocks = (nreads + 255) / 256;
+   if (blocks > 0x7FFFFFFFull) { errno = E2BIG; return -1; }
+   hipLaunchKernelGGL(k_pack_ascii, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, (const uint8_t *)d_text, nreads, read_len,
+                      (uint8_t *)d_bases, (uint8_t *)d_nmask, stride, nstride);
+   HIP_TRY(hipGetLastError(), EIO);
+   return 0;
+}
+
+/* ASCII reads, one per line, every line exactly read_len bases -> the packed layout (host helper for callers that hold text:
+ * a caller that holds packed reads already -- BAM, .2bit -- fills seeqdev_packed_t itself).  A C G T U N in either case; any
+ * other byte, or a line of another length: -1, errno = EINVAL.  Returns the number of reads. */
+extern "C" long seeqdevPackReads(const char *text, size_t nbytes, uint32_t read_len, void *bases_out, void *nmask_out, uint32_t stride, uint32_t nstride)
+{
+   seeqerr = 0;
+   if (!text || !bases_out || read_len < 1 || read_len > 256 || stride < (read_len + 3) / 4 || (nmask_out && nstride < (read_len + 7) / 8)) { errno = EINVAL; return -1; }
+   uint8_t *bo = (uint8_t *)bases_out, *no = (uint8_t *)nmask_out;
+   long r = 0;
+   size_t p = 0;
+   while (p < nbytes) {
+      if (p + read_len > nbytes) { errno = EINVAL; return -1; }
+      uint8_t *b = bo + (size_t)r * stride, *n = no ? no + (size_t)r * nstride : NULL;
+      memset(b, 0, stride);
+      if (n) memset(n, 0, nstride);
+      for (uint32_t i = 0; i < read_len; i++) {
+         const unsigned char ch = (unsigned char)text[p + i];
+         const unsigned char up = ch & 0xDF;
+         unsigned code;
+         if (up == 'A' || up == 'C' || up == 'G' || up == 'T' || up == 'U') code = (ch >> 1) & 3u;
+         else if (up == 'N') { code = 0; if (!n) { errno = EINVAL; return -1; } n[i >> 3] |= (uint8_t)(0x80u >> (i & 7)); }
+         else { errno = EINVAL; return -1; }
+         b[i >> 2] |= (uint8_t)(code << (6 - 2 * (i & 3)));
+      }
+      p += read_len;
+      if (p < nbytes) { if (text[p] != '\n') { errno = EINVAL; return -1; } p++; }
+      r++;
+   }
+   return r;
 }
 
 /* Page-locked host memory for staging buffers (H2D at link speed instead of through a bounce buffer). */

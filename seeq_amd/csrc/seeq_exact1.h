@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
             /* the line's further candidates are the repeats behind this entry (a third of the hit lines has one: an occurrence
                near the end of a chain is seen by the next chain's warm-up, which then reports its own first pair): the scan
                runs from before the first candidate to behind the last one */
-            uint32_t lastcol = col, unbounded = a.nh[k] & 2u;
+            uint32_t lastcol = a.hit_last ? a.hit_last[k] : col, unbounded = a.nh[k] & 2u;      /* (hit_last: packed read batches -- the candidates of a read come as one entry) */
             for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) { lastcol = hit_col[j] - hs; unbounded |= a.nh[j] & 2u; }
             if (!unbounded) stop_at = lastcol + m + tau1 + 1u;
          }

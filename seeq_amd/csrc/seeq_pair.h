@@ -264,11 +264,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          }
       }
       /* A chain that flags one line several times (the walk restarts when it accepts: every part of a partition filter
-         reports on its own) keeps the first flag per line only: of the flags before the chain's first newline and of those
-         behind its last one, the first; between two newlines (short lines) all of them.  Only the first candidate of a
-         line matters to the exact pass; every further one is a hit-list entry with nothing to do.  Wave-uniform, rare on
+         reports on its own) keeps the FIRST and the LAST flag per line only: of the flags before the chain's first newline
+         and of those behind its last one; between two newlines (short lines) all of them.  The exact pass scans a line
+         from before its first candidate to behind its last one: what is dropped lies in between.  Wave-uniform, rare on
          read-length lines with a prefix automaton, the rule with a partition filter. */
-      uint32_t more = 0;                                  /* bit x: chain x dropped candidates here (the kept ones say so to the exact pass) */
       if (__ballot(((hm[0] & (hm[0] - 1u)) | (hm[1] & (hm[1] - 1u))) != 0)) {
 #pragma unroll
          for (int x = 0; x < 2; x++) {
@@ -281,8 +280,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
             const uint32_t ma = na >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> na);
             const uint32_t mc = sc >= 32u ? 0u : 0xFFFFFFFFu >> sc;
             const uint32_t ha = h & ma, hc = h & mc & ~ma;
-            hm[x] = (h & ~ma & ~mc) | (ha ? 0x80000000u >> (uint32_t)__builtin_clz(ha) : 0u) | (hc ? 0x80000000u >> (uint32_t)__builtin_clz(hc) : 0u);
-            more |= hm[x] != h ? 1u << x : 0u;
+            hm[x] = (h & ~ma & ~mc) | (ha ? (0x80000000u >> (uint32_t)__builtin_clz(ha)) | (ha & (0u - ha)) : 0u)
+                                    | (hc ? (0x80000000u >> (uint32_t)__builtin_clz(hc)) | (hc & (0u - hc)) : 0u);
          }
       }
       uint32_t lane_nl = 0;
@@ -345,8 +344,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
                      const uint32_t st1 = nlt ? (uint32_t)lane * CH + 32u * r + lz - (uint32_t)__builtin_ctz(nlt) + 1u : before;
                      const uint32_t hp = (uint32_t)lane * CH + 32u * r + lz;           /* the candidate, tile-relative */
                      const uint32_t pos = st1 ? st1 - 1u : hp;
-                     /* {tile | unresolved, rank | column of the candidate << 13 | "its chain dropped candidates" << 31, line start (or candidate) position, line rank} */
-                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord | ((hp - pos) << 13) | (((more >> (r >> 1)) & 1u) << 31),
+                     /* {tile | unresolved, rank | column of the candidate << 13, line start (or candidate) position, line rank} */
+                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord | ((hp - pos) << 13),
                                                          tile * TB + pos + a.pos_bias, nlb + nb);
                      ord++;
                   }

@@ -23,6 +23,25 @@ def _check(rc):
         raise SeeqDeviceError(_capi.error_text())
 
 
+def pack_reads(text, read_len, with_nmask=True):
+    """ASCII reads (bytes, one per line, each exactly read_len bases) -> (bases, nmask, nreads): numpy uint8 arrays in the
+    packed layout of seeq_amd.h (stride ceil(read_len / 4), nstride ceil(read_len / 8)); nmask is None without with_nmask."""
+    stride, nstride = (read_len + 3) // 4, (read_len + 7) // 8
+    nmax = len(text) // read_len + 1
+    bases = np.zeros(nmax * stride, dtype=np.uint8)
+    nmask = np.zeros(nmax * nstride, dtype=np.uint8) if with_nmask else None
+    n = _capi.lib().seeqdevPackReads(text, len(text), read_len, bases.ctypes.data, nmask.ctypes.data if with_nmask else None, stride, nstride)
+    if n < 0:
+        raise SeeqDeviceError("seeqdevPackReads: a line of another length, or a byte that is not A C G T U N")
+    return bases[:n * stride], (nmask[:n * nstride] if with_nmask else None), int(n)
+
+
+def pack_reads_device(text_ptr, nreads, read_len, bases_ptr, nmask_ptr=None, stream=None):
+    """ASCII reads in HBM (nreads lines of read_len bases + newline) -> the packed layout in HBM (device pointers)."""
+    _check(_capi.lib().seeqdevPackReadsDevice(C.c_void_p(text_ptr), nreads, read_len, C.c_void_p(bases_ptr), C.c_void_p(nmask_ptr) if nmask_ptr else None,
+                                              (read_len + 3) // 4, (read_len + 7) // 8, C.c_void_p(stream) if stream else None))
+
+
 def device_count():
     return _capi.lib().seeqdevDeviceCount()
 
@@ -97,10 +116,10 @@ class Scanner:
         _check(self._lib.seeqdevScanSetLineHint(self._h, float(avg_bytes_per_line)))
 
     def last_path(self):
-        return {1: "generic", 3: "fused", 5: "fused", 6: "fused", 7: "fused"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "generic", 3: "fused", 5: "fused", 6: "fused", 7: "fused", 8: "packed"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
     def last_kernel(self):
-        return {1: "k_forward", 3: "k_direct", 5: "k_stream", 6: "k_pair", 7: "k_myers"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
+        return {1: "k_forward", 3: "k_direct", 5: "k_stream", 6: "k_pair", 7: "k_myers", 8: "k_packed"}.get(self._lib.seeqdevScanLastPath(self._h), "none")
 
     def last_filter(self):
         """True when the last k_stream run walked a partition filter automaton (candidates verified by the exact pass)."""
@@ -145,6 +164,12 @@ class Scanner:
         """t: torch uint8 CUDA tensor (contiguous).  Runs and fetches."""
         self.run(pattern, t.data_ptr(), t.numel(), options, want)
         return self.fetch()
+
+    def run_packed(self, pattern, bases_ptr, nmask_ptr, nreads, read_len, stride=None, nstride=None, options=0, want=WANT_COUNTLINES):
+        """Enqueue the scan of a packed read batch resident in HBM (seeq_amd.h: seeqdev_packed_t); fetch() waits."""
+        b = _capi.seeqdev_packed_t(bases_ptr, nmask_ptr or None, nreads, read_len, stride or (read_len + 3) // 4,
+                                   nstride or (read_len + 7) // 8)
+        _check(self._lib.seeqdevScanPacked(self._h, pattern.handle, C.byref(b), options, want))
 
     def scan_host(self, pattern, data, options=0, want=WANT_COUNTLINES):
         """data: bytes.  H2D + scan + fetch (+ records when want == WANT_RECORDS)."""
