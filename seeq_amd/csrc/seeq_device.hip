@@ -847,7 +847,7 @@ struct seeqdev_scan {
    seeqdev_counts_t *multi_cnt; size_t *multi_first; int multi_n, cap_multi_n;
    seeqdev_hit_t *multi_rec; size_t cap_multi_rec, multi_nrec;
    /* packed read batches (seeqdevScanPacked) */
-   uint32_t *pk_cand, *pk_coff; size_t cap_pk_reads;      /* per read of a segment: candidate columns / rank among the candidates */
+   uint32_t *pk_cand, *pk_coff; uint64_t *pk_bmask; size_t cap_pk_reads;      /* candidate columns per read of a segment; per block of 64 reads: candidates before it, their mask */
    uint8_t  *pk_stage; size_t cap_pk_stage;               /* ASCII lines of the candidate reads */
    uint32_t *pk_last; size_t cap_pk_last;                 /* per candidate: column of its last candidate */
    bool      is_packed; seeqdev_packed_t packed;          /* the last run was a packed one (re-run on overflow) */
@@ -948,7 +948,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
       void *ob[] = {s->ow.tile_cl, s->ow.tile_hits, s->ow.tile_dirty, s->ow.tile_dmask, s->ow.tmp, s->ow.wg_hits, s->ow.wg_part, s->ow.wg_lastnl};
       for (void *b : ob) if (b) (void)hipFree(b);
    }
-   { void *pk[] = {s->pk_cand, s->pk_coff, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
+   { void *pk[] = {s->pk_cand, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
@@ -1557,7 +1557,8 @@ static int run_packed(seeqdev_scan *s)
    const size_t seg_reads = b.nreads < PACKED_SEG_READS ? (size_t)b.nreads : PACKED_SEG_READS;
    if (seg_reads > s->cap_pk_reads) {
       if (ws_alloc((void **)&s->pk_cand, seg_reads * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&s->pk_coff, seg_reads * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->pk_coff, (seg_reads / 64 + 1) * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->pk_bmask, (seg_reads / 64 + 1) * sizeof(uint64_t))) return -1;
       s->cap_pk_reads = seg_reads;
    }
    if (s->cap_hitlines * (size_t)(L + 1) > s->cap_pk_stage) {
@@ -1626,7 +1627,7 @@ static int run_packed(seeqdev_scan *s)
       p.read_len = L; p.stride = b.stride; p.nstride = b.nstride;
       p.total_bytes = b.nreads * (uint64_t)b.stride;
       p.dfa = pat->d_pair; p.dfa_units = pat->pair_units;
-      p.cand = s->pk_cand; p.coff = s->pk_coff; p.stage = s->pk_stage;
+      p.cand = s->pk_cand; p.boff = s->pk_coff; p.bmask = s->pk_bmask; p.stage = s->pk_stage;
       p.hit_start = s->hit_start; p.hit_line = s->hit_line; p.hit_col = s->hit_col; p.hit_last = s->pk_last; p.nh = s->nh;
       p.cap = (uint32_t)s->cap_hitlines;
       p.line_base = p.first;
@@ -1637,17 +1638,11 @@ static int run_packed(seeqdev_scan *s)
          HIP_TRY(hipLaunchKernel((const void *)k_packed_walk, dim3(wgrid), dim3(64 * STREAM_NW), kargs, dfa_lds, st), EIO);
       }
       if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
-      /* rank of every candidate read, their number */
-      {
-         const unsigned nb = (unsigned)(((size_t)p.nreads + SCAN_BLOCK - 1) / SCAN_BLOCK);
-         hipLaunchKernelGGL(k_scan_reduce<2>, dim3(nb), dim3(WG), 0, st, (const void *)p.cand, s->scan_ws, (const uint32_t *)nullptr, p.nreads, 0u);
-         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WG), 0, st, s->scan_ws, (const uint32_t *)nullptr, p.nreads, 0u, &c->seg_nhitlines);
-         hipLaunchKernelGGL(k_scan_apply<2>, dim3(nb), dim3(WG), 0, st, (const void *)p.cand, s->pk_coff, (const uint32_t *)s->scan_ws,
-                            (const uint32_t *)nullptr, p.nreads, 0u);
-      }
+      /* candidates before every block of 64 reads, their number */
+      launch_scanset(s, st, s->pk_coff, nullptr, nullptr, (p.nreads + 63u) >> 6, &c->seg_nhitlines, nullptr, nullptr);
       hipLaunchKernelGGL(k_packed_counts, dim3(1), dim3(1), 0, st, p);
       hipLaunchKernelGGL(k_packed_list, dim3((unsigned)(s->ncu * 16)), dim3(256), 0, st, p);
-      hipLaunchKernelGGL(k_packed_stage, dim3((unsigned)(s->ncu * 8)), dim3(256), 0, st, p);
+      hipLaunchKernelGGL(k_packed_stage, dim3((unsigned)(s->ncu * 32)), dim3(256), 0, st, p);
       /* from here: the exact pass over the staging text, as behind k_pair */
       ScanArgs a;
       memset(&a, 0, sizeof a);

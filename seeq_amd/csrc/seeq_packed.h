@@ -7,7 +7,8 @@
  *                   loads) and walks k_pair's pair automaton over it straight from the root -- a read begins where its
  *                   line begins, so there is no warm-up, no newline, no alphabet check, and a nibble of the packed byte IS
  *                   the pair index: per text word two VALU instructions prepare eight steps (k_pair: two).  Per pair: the
- *                   SDWA v_xor, the gather, one v_alignbit.  Output: cand[r] = {first, last candidate column} + 1 or 0.
+ *                   SDWA v_xor, the gather, one v_alignbit.  Output: per block of 64 reads the mask of candidate reads and
+ *                   their number, per candidate read cand[r] = {first, last candidate column}.
  *                   A base that is N is stored as some code and flagged in the optional N mask: an alias, as in k_pair.
  *   k_packed_stage  the candidate reads (5 % of a read set with planted hits) are written out as ASCII lines, N restored,
  *                   into a staging text of one line per candidate, with the hit-list arrays the exact pass reads:
@@ -27,8 +28,9 @@ struct PackedArgs {
    uint64_t       total_bytes;  /* of `bases`: reads of the whole batch x stride */
    const uint16_t *dfa;         /* pair table (seeq_dfa.h section 3) */
    uint32_t       dfa_units;    /* 16-byte units of it */
-   uint32_t      *cand;         /* [nreads] */
-   const uint32_t *coff;        /* [nreads] exclusive prefix of (cand != 0) */
+   uint32_t      *cand;         /* [nreads], written for candidate reads only */
+   uint64_t      *bmask;        /* [ceil(nreads / 64)] candidate reads of every block of 64 reads, read r = bit r & 63 */
+   uint32_t      *boff;         /* [ceil(nreads / 64)] their number; after the scan: candidates before the block */
    uint8_t       *stage;        /* [cap * (read_len + 1)] ASCII lines of the candidates */
    uint32_t      *hit_start, *hit_line, *hit_col, *hit_last, *nh;
    uint32_t       cap;          /* candidates the staging text and the hit list hold */
@@ -75,7 +77,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
       for (uint32_t j = 0; j < nwords; j += 4) {
          const fused_v4u v = dfa_load16(a.bases, roff + 4 * j, a.total_bytes);      /* (bounds-checked: the batch's last read ends the allocation) */
          uint32_t hm = 0;
-         packed_word(v.x, st, hm); packed_word(v.y, st, hm); packed_word(v.z, st, hm); packed_word(v.w, st, hm);
+         packed_word(v.x, st, hm); packed_word(v.y, st, hm);
+         if (j + 2 < nwords) { packed_word(v.z, st, hm); packed_word(v.w, st, hm); }      /* (150 bp: ten words, the third load's last two are the next read) */
+         else hm >>= 16;                                   /* (the first pair belongs in bit 0 before the reversal) */
          hm = __builtin_bitreverse32(hm);                  /* first pair of the 32 in bit 31 */
          const uint32_t lo = j * 8;                        /* pair index of bit 31 */
          const uint32_t keep = npairs <= lo ? 0u : (npairs - lo >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (npairs - lo)));
@@ -86,55 +90,83 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
             last = l;
          }
       }
-      if (live) {
+      const bool is_cand = live && first != 0xFFFFFFFFu;
+      const uint64_t mask = __ballot(is_cand);
+      if (lane == 0) { a.bmask[blk] = mask; a.boff[blk] = (uint32_t)__popcll(mask); }
+      if (is_cand) {
          /* candidate columns: the second base of the flagged pairs (the read's last base when it has no second) */
          uint32_t fc = 2u * first + 1u, lc = 2u * last + 1u;
          fc = fc < a.read_len ? fc : a.read_len - 1u;
          lc = lc < a.read_len ? lc : a.read_len - 1u;
-         a.cand[r] = first == 0xFFFFFFFFu ? 0u : ((fc << 16) | lc) + 1u;
+         a.cand[r] = (fc << 16) | lc;
       }
    }
 }
 
-/* The hit list of the candidate reads (one lane per read of the segment: a load, and for one read in twenty five stores). */
+/* The hit list of the candidate reads: one lane per read, a wave per block of 64 (two loads per wave; for one read in twenty a
+   load and five stores). */
 __global__ __launch_bounds__(256) void k_packed_list(PackedArgs a)
 {
    const uint32_t stride = gridDim.x * 256;
    const uint32_t L = a.read_len;
-   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < a.nreads; r += stride) {
-      const uint32_t cd = a.cand[r];
-      if (!cd) continue;
-      const uint32_t k = a.coff[r];
+   const uint32_t nr = (a.nreads + 63u) & ~63u;
+   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nr; r += stride) {
+      const uint64_t mask = a.bmask[r >> 6];
+      const uint32_t lane = r & 63u;
+      if (!((mask >> lane) & 1u)) continue;
+      const uint32_t k = a.boff[r >> 6] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       if (k >= a.cap) continue;                            /* (the overflow is reported by k_packed_counts) */
+      const uint32_t cd = a.cand[r];
       a.hit_start[k] = k * (L + 1);
       a.hit_line[k] = (uint32_t)(a.line_base + r + 1u);
-      a.hit_col[k] = (cd - 1u) >> 16;
-      a.hit_last[k] = (cd - 1u) & 0xFFFFu;
+      a.hit_col[k] = cd >> 16;
+      a.hit_last[k] = cd & 0xFFFFu;
       a.nh[k] = 0u;
    }
 }
 
-/* Candidate reads -> ASCII lines of the staging text, N restored (one lane per CANDIDATE: run per read, the 151 byte stores of
-   one candidate in a wave of 64 reads held the whole wave -- 5.8 ms per 100 M reads). */
+/* Candidate reads -> ASCII lines of the staging text, N restored: SIXTEEN lanes per candidate, a lane per word of the read
+   (16 bases): one load of the packed bases and one of the N bits per lane, four v_perm look-ups, four word stores.
+   (A lane per read held its wave for the 151 byte stores of one candidate in twenty: 5.8 ms per 100 M reads; a lane per
+   candidate stored to 64 cache lines per instruction: 2.5 ms per 16 M reads; a lane per 16 bytes of the staging text
+   loaded every byte of the read by itself: 0.33 ms per 16 M reads, 0.24 of them the byte loads.) */
+typedef uint32_t packed_u32_unaligned __attribute__((aligned(1)));
+
 __global__ __launch_bounds__(256) void k_packed_stage(PackedArgs a)
 {
    const uint32_t n = a.cnt->seg_nhitlines;
-   const uint32_t stride = gridDim.x * 256;
-   const uint32_t L = a.read_len;
-   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+   const uint32_t L = a.read_len, L1 = L + 1u;
+   const uint32_t i = threadIdx.x & 15u;                   /* word of the read */
+   const uint32_t groups = gridDim.x * 16u;
+   for (uint32_t k = blockIdx.x * 16u + (threadIdx.x >> 4); k < n; k += groups) {
       const uint64_t r = (uint64_t)a.hit_line[k] - 1u;     /* read index in the batch (line numbers are read indices + 1) */
-      const uint8_t *p = a.bases + r * (uint64_t)a.stride;
-      const uint8_t *nm = a.nmask ? a.nmask + r * (uint64_t)a.nstride : nullptr;
-      uint8_t *out = a.stage + (uint64_t)k * (L + 1);
-      for (uint32_t i = 0; i < L; i += 4) {
-         const uint32_t b = p[i >> 2];
-         const uint32_t nbits = nm ? (uint32_t)nm[i >> 3] >> (4u - (i & 4u)) : 0u;      /* the four N bits of these bases, first base in bit 3 */
-         for (uint32_t q = 0; q < 4 && i + q < L; q++) {
-            const uint32_t code = (b >> (6 - 2 * q)) & 3u;
-            out[i + q] = ((nbits >> (3 - q)) & 1u) ? (uint8_t)'N' : (uint8_t)("ACTG"[code]);
-         }
+      uint8_t *out = a.stage + (uint64_t)k * L1;
+      if (i == 0) out[L] = '\n';
+      if (16u * i >= L) continue;
+      const uint8_t *pb = a.bases + r * (uint64_t)a.stride + 4u * i;
+      uint32_t w = 0, nb = 0;
+      if (4u * i + 4u <= a.stride) w = *reinterpret_cast<const packed_u32_unaligned *>(pb);
+      else for (uint32_t b = 4u * i; b < a.stride; b++) w |= (uint32_t)pb[b - 4u * i] << (8u * (b - 4u * i));
+      if (a.nmask) {
+         const uint8_t *pn = a.nmask + r * (uint64_t)a.nstride;
+         nb = (uint32_t)pn[2u * i] << 8;
+         if (2u * i + 1u < a.nstride) nb |= pn[2u * i + 1u];
       }
-      out[L] = '\n';
+      uint32_t word[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+         const uint32_t b = (w >> (8 * j)) & 0xFFu;
+         const uint32_t sel = (b >> 6) | ((b & 0x30u) << 4) | ((b & 0x0Cu) << 14) | ((b & 3u) << 24);      /* the four codes, first base in byte 0 */
+         const uint32_t n4 = (nb >> (12 - 4 * j)) & 0xFu;                                                 /* their N bits, first base in bit 3 */
+         const uint32_t nm = (((n4 >> 3) & 1u) | ((n4 & 4u) << 6) | ((n4 & 2u) << 15) | ((n4 & 1u) << 24)) * 0xFFu;
+         word[j] = (__builtin_amdgcn_perm(0u, 0x47544341u, sel) & ~nm) | (0x4E4E4E4Eu & nm);              /* "ACTG"[code] or 'N' */
+      }
+      if (16u * i + 16u <= L) {
+#pragma unroll
+         for (int j = 0; j < 4; j++) *reinterpret_cast<packed_u32_unaligned *>(out + 16u * i + 4u * j) = word[j];
+      } else {
+         for (uint32_t c = 16u * i; c < L; c++) out[c] = (uint8_t)(word[(c >> 2) & 3u] >> (8u * (c & 3u)));
+      }
    }
 }
 
