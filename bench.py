@@ -562,7 +562,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_rows = None
     if world > 1:
+        # per rank, for the line: its own clock, its read range, what it counted there (the step's value uses the MAX clock)
+        mine = torch.tensor([elapsed, float(first), float(n), float(local["nlines"]), float(local["nmatchlines"]),
+                             fwd_ms / max(1, args.steps), ex_ms / max(1, args.steps)], dtype=torch.float64, device=red_device)
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        rank_rows = [{"rank": r, "ms_per_step": 1e3 * float(x[0]) / args.steps, "first_read": int(x[1]), "reads": int(x[2]),
+                      "lines": int(x[3]), "matching_lines": int(x[4]), "forward_scan_ms": float(x[5]),
+                      "compaction_exact_records_ms": float(x[6])} for r, x in enumerate(rows)]
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -651,6 +660,8 @@ def main():
                          / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
                          "note": notes.get(kern, "see DESIGN.md")},
         }
+        if rank_rows is not None:
+            out["ranks"] = rank_rows
         if world == 1 and not args.no_e2e:
             # Timed region (ii) of SURVEY 8d: same path fed from page-locked HOST memory (H2D + scan + D2H of the
             # records), on a 10 M-line sample.  PCIe-bound; reported beside, never as, `value`.

@@ -57,13 +57,19 @@ static inline void seeq_dfa_free(seeq_dfa_t *d) { if (d) { free(d->table); free(
  * (reference libseeq.c:767-786 per column).  On success returns the number of states n (state 0 = root, state 1 =
  * the absorbing accepting state) and *next_out = n * 5 transitions (classes A C G T N), to be free()d.
  * Returns 0 when the automaton has more than SEEQ_DFA_MAX_STATES states (or on allocation failure). */
-static inline uint32_t seeq_dfa_bfs_parts(const char *keys, const int *cut, int nparts, int t, uint32_t **next_out)
+/* The general form: a threshold per part (tp[p]), up to SEEQ_MULTI_MAX_PARTS parts (several PATTERNS advanced together:
+ * section 4), `cap` states at most; absorb = 1: as above (the first acceptance of any part leads to the absorbing state 1);
+ * absorb = 0: the walk goes on after an acceptance -- there is no state 1 then (state numbers are 0 .. n - 1, all real),
+ * and *mask_out (n words, to be free()d) holds per state the set of parts whose column ends at or below its threshold there. */
+#define SEEQ_MULTI_MAX_PARTS 32
+static inline uint32_t seeq_dfa_bfs_parts_ex(const char *keys, const int *cut, int nparts, const int *tp, int absorb, int cap,
+                                             uint32_t **next_out, uint32_t **mask_out)
 {
    *next_out = NULL;
+   if (mask_out) *mask_out = NULL;
    const int m = cut[nparts];
-   if (nparts < 1 || nparts > SEEQ_DFA_MAX_PARTS || m < 1 || m > 62 || t < 0) return 0;
-   for (int p = 0; p < nparts; p++) if (cut[p + 1] - cut[p] <= t) return 0;       /* a part must be longer than its threshold */
-   const int cap = SEEQ_DFA_MAX_STATES;
+   if (nparts < 1 || nparts > SEEQ_MULTI_MAX_PARTS || m < 1 || m > 2048 || cap < 4) return 0;
+   for (int p = 0; p < nparts; p++) if (tp[p] < 0 || cut[p + 1] - cut[p] <= tp[p]) return 0;       /* a part must be longer than its threshold */
    const size_t colsz = (size_t)m + (size_t)nparts;                /* every part has its own row 0 */
    uint8_t *cols = (uint8_t *)malloc((size_t)(cap + 1) * colsz);          /* state -> columns, concatenated */
    uint32_t *next = (uint32_t *)malloc((size_t)(cap + 1) * 5 * sizeof(uint32_t));
@@ -71,34 +77,37 @@ static inline uint32_t seeq_dfa_bfs_parts(const char *keys, const int *cut, int 
    while (HSZ < 4u * (uint32_t)cap) HSZ <<= 1;
    int32_t *hash = (int32_t *)malloc(HSZ * sizeof(int32_t));
    uint8_t *tmp = (uint8_t *)malloc(colsz);
-   uint32_t n = 2;
+   uint32_t *mask = (!absorb && mask_out) ? (uint32_t *)calloc((size_t)cap + 1, sizeof(uint32_t)) : NULL;
+   uint32_t n = absorb ? 2 : 1;
    bool ok = false;
-   if (!cols || !next || !hash || !tmp) goto done;
+   if (!cols || !next || !hash || !tmp || (!absorb && mask_out && !mask)) goto done;
    memset(hash, 0xFF, HSZ * sizeof(int32_t));
    /* state 0 = root columns min(i, t+1) (reference libseeq.c:681-682); state 1 = ACC (absorbing) */
    {
       size_t o = 0;
       for (int p = 0; p < nparts; p++)
-         for (int i = 0; i <= cut[p + 1] - cut[p]; i++) cols[o++] = (uint8_t)(i <= t ? i : t + 1);
+         for (int i = 0; i <= cut[p + 1] - cut[p]; i++) cols[o++] = (uint8_t)(i <= tp[p] ? i : tp[p] + 1);
    }
-   memset(cols + colsz, 0xFF, colsz);
+   if (absorb) memset(cols + colsz, 0xFF, colsz);
    {
       uint32_t h = 2166136261u;
       for (size_t i = 0; i < colsz; i++) h = (h ^ cols[i]) * 16777619u;
       hash[h & (HSZ - 1)] = 0;
    }
-   for (int c = 0; c < 5; c++) next[5 + c] = 1;                 /* ACC stays ACC */
+   if (absorb) for (int c = 0; c < 5; c++) next[5 + c] = 1;     /* ACC stays ACC */
    for (uint32_t s = 0; s < n; s++) {
-      if (s == 1) continue;
+      if (absorb && s == 1) continue;
       const uint8_t *col = cols + (size_t)s * colsz;
       for (int c = 0; c < 5; c++) {
          /* one column of the saturated matrix per part: reference libseeq.c:767-786 */
          const int bit = 1 << c;
          bool acc = false;
+         uint32_t accmask = 0;
          size_t o = 0;
          for (int p = 0; p < nparts; p++) {
             const int len = cut[p + 1] - cut[p];
             const char *pk = keys + cut[p];
+            const int t = tp[p];
             int diag = col[o], up = 0;
             tmp[o] = 0;
             for (int i = 1; i <= len; i++) {
@@ -111,11 +120,11 @@ static inline uint32_t seeq_dfa_bfs_parts(const char *keys, const int *cut, int 
                up = v;
                diag = left;
             }
-            if (tmp[o + len] <= t) acc = true;
+            if (tmp[o + len] <= t) { acc = true; accmask |= 1u << p; }
             o += (size_t)len + 1;
          }
          uint32_t tgt;
-         if (acc) {
+         if (acc && absorb) {
             tgt = 1;                                             /* accepting: absorbed */
          } else {
             uint32_t h = 2166136261u;
@@ -127,6 +136,7 @@ static inline uint32_t seeq_dfa_bfs_parts(const char *keys, const int *cut, int 
                   if ((int)n >= cap) goto done;                  /* too large for the LDS table */
                   memcpy(cols + (size_t)n * colsz, tmp, colsz);
                   hash[slot] = (int32_t)n;
+                  if (mask) mask[n] = accmask;                   /* (a function of the columns: the same for every way into the state) */
                   tgt = n++;
                   break;
                }
@@ -140,9 +150,19 @@ static inline uint32_t seeq_dfa_bfs_parts(const char *keys, const int *cut, int 
    ok = true;
 done:
    free(cols); free(hash); free(tmp);
-   if (!ok) { free(next); return 0; }
+   if (!ok) { free(next); free(mask); return 0; }
    *next_out = next;
+   if (mask_out) *mask_out = mask; else free(mask);
    return n;
+}
+
+static inline uint32_t seeq_dfa_bfs_parts(const char *keys, const int *cut, int nparts, int t, uint32_t **next_out)
+{
+   int tp[SEEQ_DFA_MAX_PARTS];
+   *next_out = NULL;
+   if (nparts < 1 || nparts > SEEQ_DFA_MAX_PARTS || cut[nparts] > 62 || t < 0) return 0;
+   for (int p = 0; p < nparts; p++) tp[p] = t;
+   return seeq_dfa_bfs_parts_ex(keys, cut, nparts, tp, 1, SEEQ_DFA_MAX_STATES, next_out, NULL);
 }
 
 static inline uint32_t seeq_dfa_bfs(const char *keys, int m, int tau, uint32_t **next_out)
@@ -489,6 +509,105 @@ static inline seeq_pair_t *seeq_pair_plan(const char *keys, int m, int tau)
       else seeq_pair_free(d);
    }
    return best;
+}
+
+/* ==========================================================================================================================
+ * (4) SEVERAL PATTERNS, ONE WALK (barcode sets; reference doc/response.tex:358-360 names the multi-pattern search as the
+ *     place where parallel work exists).  Two automata over the same prefixes lp[p] <= m[p] of the patterns:
+ *
+ *   pair    the UNION walk of k_pair: all prefixes advanced together (parts = patterns, each with its own threshold),
+ *           restart at the root when ANY of them accepts, minimised, two bases per step.  Superset per pattern as in
+ *           seeq_pair.h: every occurrence of pattern p (<= tau[p] errors) holds an occurrence [s, j] of its prefix, the
+ *           chain flags j unless it restarted (for whatever pattern) at j1 in [s, j) -- then j1 is flagged.  So every
+ *           occurrence of every pattern has a candidate inside it or on the byte after it, the first candidate c of a
+ *           line is <= start + maxspan for every occurrence, the last one l >= start + 1: every occurrence of every
+ *           pattern lies in [c - maxspan, l + maxspan], maxspan = max(m + tau).
+ *   res     the same prefixes advanced together WITHOUT restart or absorption, byte by byte (classes A C G T N): per state
+ *           the set of patterns whose prefix has an alignment within its threshold ending there.  Walked from the root
+ *           over the window above it sees every such alignment of the window -- the union of the masks is a superset of
+ *           the patterns that occur in the line, and (prefix = pattern) exactly that set.
+ *
+ * The exact pass then verifies (line, pattern) pairs only.  NULL when a pattern is shorter than tau + 2, the union does not
+ * fit the pair table with prefixes of at least min(m, tau + 5) positions, or `res` needs more than 65 535 states.
+ * ========================================================================================================================== */
+typedef struct {
+   int          npat;
+   int          m[SEEQ_MULTI_MAX_PARTS], tau[SEEQ_MULTI_MAX_PARTS], lp[SEEQ_MULTI_MAX_PARTS];
+   int          maxspan;        /* max over patterns of m + tau */
+   seeq_pair_t *pair;           /* mp = longest prefix, warm = max(lp + tau - 1) */
+   uint32_t     res_states;
+   uint16_t    *res_next;       /* res_states * 8: classes A C G T N, then three unused entries (a 16-byte row) */
+   uint32_t    *res_mask;       /* res_states */
+   int          res_exact;      /* every prefix is its whole pattern */
+} seeq_multi_t;
+
+static inline void seeq_multi_free(seeq_multi_t *d)
+{
+   if (d) { seeq_pair_free(d->pair); free(d->res_next); free(d->res_mask); free(d); }
+}
+
+/* keys[p]: m[p] key bytes of pattern p (bit0 A .. bit3 T, N = 0x1F). */
+static inline seeq_multi_t *seeq_multi_build(const char *const *keys, const int *m, const int *tau, int npat)
+{
+   if (npat < 1 || npat > SEEQ_MULTI_MAX_PARTS) return NULL;
+   int maxm = 0, total = 0;
+   for (int p = 0; p < npat; p++) {
+      if (m[p] < tau[p] + 2 || m[p] > 62 || tau[p] < 0) return NULL;
+      if (m[p] > maxm) maxm = m[p];
+      total += m[p];
+   }
+   seeq_multi_t *d = (seeq_multi_t *)calloc(1, sizeof *d);
+   char *cat = (char *)malloc((size_t)total);
+   int cut[SEEQ_MULTI_MAX_PARTS + 1];
+   if (!d || !cat) { free(d); free(cat); return NULL; }
+   d->npat = npat;
+   for (int p = 0; p < npat; p++) { d->m[p] = m[p]; d->tau[p] = tau[p]; if (m[p] + tau[p] > d->maxspan) d->maxspan = m[p] + tau[p]; }
+   for (int cap_len = maxm; cap_len >= 3 && !d->pair; cap_len--) {
+      int o = 0, warm = 0, longest = 0, ok = 1;
+      for (int p = 0; p < npat; p++) {
+         int lp = m[p] < cap_len ? m[p] : cap_len;
+         const int least = m[p] < tau[p] + 5 ? m[p] : tau[p] + 5;       /* shorter prefixes flag most of a random text */
+         if (lp < least) lp = least;
+         if (lp < tau[p] + 2) ok = 0;
+         d->lp[p] = lp;
+         cut[p] = o;
+         memcpy(cat + o, keys[p], (size_t)lp);
+         o += lp;
+         if (lp + tau[p] - 1 > warm) warm = lp + tau[p] - 1;
+         if (lp > longest) longest = lp;
+      }
+      cut[npat] = o;
+      if (!ok) break;
+      if (warm <= 32) {
+         uint32_t *next = NULL;
+         const uint32_t n = seeq_dfa_bfs_parts_ex(cat, cut, npat, tau, 1, 24000, &next, NULL);
+         if (n) {
+            seeq_pair_t *pr = seeq_pair_from_next(next, n, 4 * longest + 64);      /* (consumes next) */
+            if (pr) { pr->mp = longest; pr->nparts = npat; pr->warm = warm; d->pair = pr; }
+         }
+      }
+      /* every prefix at its floor already: shorter caps change nothing */
+      int at_floor = 1;
+      for (int p = 0; p < npat; p++) { const int least = m[p] < tau[p] + 5 ? m[p] : tau[p] + 5; if (d->lp[p] > least) at_floor = 0; }
+      if (!d->pair && at_floor) break;
+   }
+   if (d->pair) {
+      uint32_t *next = NULL, *mask = NULL;
+      const uint32_t n = seeq_dfa_bfs_parts_ex(cat, cut, npat, tau, 0, 65535, &next, &mask);
+      if (n) {
+         d->res_next = (uint16_t *)calloc((size_t)n * 8, sizeof(uint16_t));
+         if (d->res_next) {
+            for (uint32_t q = 0; q < n; q++) for (int c = 0; c < 5; c++) d->res_next[(size_t)q * 8 + c] = (uint16_t)next[(size_t)q * 5 + c];
+            d->res_states = n; d->res_mask = mask; mask = NULL;
+            d->res_exact = 1;
+            for (int p = 0; p < npat; p++) if (d->lp[p] != m[p]) d->res_exact = 0;
+         }
+      }
+      free(next); free(mask);
+   }
+   free(cat);
+   if (!d->pair || !d->res_next) { seeq_multi_free(d); return NULL; }
+   return d;
 }
 
 #endif

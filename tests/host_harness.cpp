@@ -219,3 +219,69 @@ extern "C" long harness_pair_walk(const uint8_t *text, size_t n, const char *key
    seeq_pair_free(d);
    return (long)ne;
 }
+
+// ---- several patterns, one walk (seeq_dfa.h section 4) ----
+// keys: the patterns' key bytes concatenated (m[p] each).  harness_multi_walk: the union pair automaton walked as
+// harness_pair_walk walks a single one (chains of `chain` bytes, warm-up, restart, made-up candidates) -> candidate positions.
+// info[0..5] = pair states, raw states, longest prefix, warm-up bytes, resolve states, resolve exact.
+static seeq_multi_t *harness_multi_make(const char *keys, const int *m, const int *tau, int npat)
+{
+   const char *kp[SEEQ_MULTI_MAX_PARTS];
+   if (npat < 1 || npat > SEEQ_MULTI_MAX_PARTS) return nullptr;
+   int o = 0;
+   for (int p = 0; p < npat; p++) { kp[p] = keys + o; o += m[p]; }
+   return seeq_multi_build(kp, m, tau, npat);
+}
+
+extern "C" long harness_multi_walk(const uint8_t *text, size_t n, const char *keys, const int *m, const int *tau, int npat, int chain,
+                                   uint64_t *out, size_t cap, uint32_t *info)
+{
+   seeq_multi_t *d = harness_multi_make(keys, m, tau, npat);
+   if (!d) return -1;
+   if (info) { info[0] = d->pair->nstates; info[1] = d->pair->nstates_raw; info[2] = (uint32_t)d->pair->mp; info[3] = (uint32_t)d->pair->warm;
+               info[4] = d->res_states; info[5] = (uint32_t)d->res_exact; info[6] = (uint32_t)d->maxspan; }
+   const long long W = 4 * ((d->pair->warm + 3) / 4) < 16 ? 16 : 4 * ((d->pair->warm + 3) / 4);
+   size_t ne = 0;
+   for (size_t c0 = 0; c0 < n; c0 += (size_t)chain) {
+      uint32_t state = 0;
+      bool warm_flag = false;
+      for (long long p = (long long)c0 - W; p < (long long)c0 + chain && p < (long long)n; p += 2) {
+         const uint8_t b1 = p < 0 ? (uint8_t)'\n' : text[p];
+         const uint8_t b2 = (p + 1 < 0 || p + 1 >= (long long)n) ? (uint8_t)'\n' : text[p + 1];
+         uint16_t nxt;
+         memcpy(&nxt, d->pair->table + state + 2u * (uint32_t)(((b1 >> 1) & 3) * 4 + ((b2 >> 1) & 3)), 2);
+         state = nxt;
+         const bool flagged = (state & 1u) != 0;
+         if (p < (long long)c0) { warm_flag |= flagged; continue; }
+         if (flagged || (p == (long long)c0 && warm_flag)) {
+            const uint64_t pos = (uint64_t)(p + 1 < (long long)n ? p + 1 : (long long)n - 1);
+            if (ne < cap) out[ne] = pos;
+            ne++;
+         }
+      }
+   }
+   seeq_multi_free(d);
+   return (long)ne;
+}
+
+// The resolve automaton walked from the root over text[lo, hi) (a byte outside A C G T N, either case, ends the walk):
+// the union of the masks of the states it visits.  nwin windows at once (lo[i], hi[i]) -> masks[i].
+extern "C" int harness_multi_resolve(const uint8_t *text, const char *keys, const int *m, const int *tau, int npat,
+                                     const uint64_t *lo, const uint64_t *hi, size_t nwin, uint32_t *masks)
+{
+   seeq_multi_t *d = harness_multi_make(keys, m, tau, npat);
+   if (!d) return -1;
+   for (size_t i = 0; i < nwin; i++) {
+      uint32_t q = 0, acc = 0;
+      for (uint64_t p = lo[i]; p < hi[i]; p++) {
+         const uint8_t b = text[p] & 0xDFu;
+         const int c = b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : (b == 'T' || b == 'U') ? 3 : b == 'N' ? 4 : -1;
+         if (c < 0) break;
+         q = d->res_next[(size_t)q * 8 + c];
+         acc |= d->res_mask[q];
+      }
+      masks[i] = acc;
+   }
+   seeq_multi_free(d);
+   return 0;
+}

@@ -313,3 +313,88 @@ def test_pair_automaton_is_a_superset_and_its_first_candidate_bounds_the_scan(ha
         if (pat, tau) == ("GATGTAGCGCGATTAGCCTG", 3):
             assert info[2] == 17 and info[1] == 1839, info
     assert nwalked >= 40
+
+
+def test_multi_pattern_automata_cover_every_pattern_of_every_line(harness, oracle):
+    """Host side of the one-pass multi-pattern scan (seeq_dfa.h section 4): the UNION pair automaton of a barcode set walked
+    in 64-byte chains as k_pair walks it, then the resolve automaton over each candidate line's window
+    [first candidate - maxspan, last candidate + maxspan + 2):
+      (1) every line in which the oracle finds ANY of the patterns gets a candidate;
+      (2) the window's pattern mask holds every pattern the oracle finds in the line (exactly those when the automata carry
+          the whole patterns);
+      (3) each such pattern scanned over the window alone gives the line's own records (SQ_ALL, hence every option)."""
+    import ctypes as C
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(77)
+    harness.harness_multi_walk.restype = C.c_long
+    harness.harness_multi_walk.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    harness.harness_multi_resolve.restype = C.c_int
+    harness.harness_multi_resolve.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_size_t, C.c_void_p]
+    sets = [(["ACGTTGCA", "TTGACCGA", "GGCATTAC", "CAGTGTCA", "ATATCGCG", "GATTACAG"], [1, 1, 1, 1, 0, 1]),
+            (["".join(rng.choice("ACGT") for _ in range(10)) for _ in range(16)], [1] * 16),
+            (["".join(rng.choice("ACGT") for _ in range(rng.choice([8, 9, 11, 12]))) for _ in range(16)], [rng.choice([0, 1]) for _ in range(16)]),
+            (["ACGTTGCA", "TG[AC]CANNGT", "GATGTAGCGCGATTAGCCTG", "AAAAAAAA"], [1, 1, 3, 2]),
+            (["ACACACAC", "CACACACA", "ACACACACAC"], [1, 1, 2])]
+    nsets = 0
+    for pats, taus in sets:
+        keysl = [oracle.parse(p)[0] for p in pats]
+        ms = [len(k) for k in keysl]
+        cat = bytes(b for k in keysl for b in k)
+        npat = len(pats)
+        cm = (C.c_int * npat)(*ms); ct = (C.c_int * npat)(*taus)
+        lines = []
+        for i in range(700):
+            n = rng.choice([0, 5, 30, 60, 150, 151, 300])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            for _ in range(rng.choice([0, 1, 1, 2, 3])):
+                k = rng.randrange(npat)
+                cp = mutate(rng, plain(pats[k]).replace("N", "A"), rng.randint(0, taus[k] + 1))
+                if n >= len(cp):
+                    q = rng.choice([0, n - len(cp), rng.randrange(n - len(cp) + 1)])
+                    t[q:q + len(cp)] = list(cp)
+            if i % 19 == 0 and n:
+                t[rng.randrange(n)] = "N"
+            t = "".join(t)[:n]
+            lines.append(t.lower() if i % 31 == 0 else t)
+        if len(set("".join(pats))) <= 2:
+            lines += ["AC" * rng.randint(2, 9) + "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 20))) for _ in range(300)]
+        buf = ("\n".join(lines) + "\n").encode()
+        starts = np.cumsum([0] + [len(x) + 1 for x in lines])
+        out = np.zeros(1 << 18, dtype=np.uint64)
+        info = (C.c_uint32 * 8)()
+        ne = harness.harness_multi_walk(buf, len(buf), cat, cm, ct, npat, 64, out.ctypes.data, out.size, info)
+        assert ne >= 0, pats
+        nsets += 1
+        maxspan = int(info[6])
+        assert maxspan == max(m + t for m, t in zip(ms, taus)) and info[0] + 5 <= 2047 and info[3] <= 32
+        first, last = {}, {}
+        for p in out[:ne]:
+            p = int(p)
+            ln = int(np.searchsorted(starts, p, side="right"))
+            first.setdefault(ln, p - int(starts[ln - 1]))
+            last[ln] = p - int(starts[ln - 1])
+        want = [{} for _ in pats]
+        for k, (pt, tau) in enumerate(zip(pats, taus)):
+            for ln, st, en, di in oracle.buffer_scan(pt, tau, buf, SQ_ALL)["records"]:
+                want[k].setdefault(int(ln), []).append((int(st), int(en), int(di)))
+        hit_lines = set().union(*[set(w) for w in want])
+        assert not (hit_lines - set(first)), (pats, sorted(hit_lines - set(first))[:5])
+        cand = sorted(first)
+        lo = np.array([starts[ln - 1] + max(0, first[ln] - maxspan) for ln in cand], dtype=np.uint64)
+        hi = np.array([starts[ln - 1] + min(len(lines[ln - 1]), last[ln] + maxspan + 2) for ln in cand], dtype=np.uint64)
+        masks = np.zeros(len(cand), dtype=np.uint32)
+        assert harness.harness_multi_resolve(buf, cat, cm, ct, npat, lo.ctypes.data, hi.ctypes.data, len(cand), masks.ctypes.data) == 0
+        for ln, a, b, mk in zip(cand, lo, hi, masks):
+            truth = sum(1 << k for k in range(npat) if ln in want[k])
+            assert (int(mk) & truth) == truth, (pats, ln, bin(int(mk)), bin(truth))
+            if info[5] and "N" not in lines[ln - 1].upper():
+                assert int(mk) == truth, (pats, ln, bin(int(mk)), bin(truth))
+            a, b = int(a - starts[ln - 1]), int(b - starts[ln - 1])
+            for k in range(npat):
+                if truth >> k & 1:
+                    sub = oracle.string_match(pats[k], taus[k], lines[ln - 1][a:b], SQ_ALL)[::-1]
+                    assert [(s + a, e + a, d) for s, e, d in sub] == want[k][ln], (pats[k], ln, a, b)
+    assert nsets == len(sets)

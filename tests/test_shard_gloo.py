@@ -183,6 +183,14 @@ def test_bench_launches_its_own_ranks(gpu):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["results"]["lines"] == 600000
     assert line["results"]["oracle_lines_checked"] >= 100000
+    # both ranks in the line: disjoint contiguous read ranges, their own clocks, their counts adding up to the total
+    rows = line["ranks"]
+    assert [r["rank"] for r in rows] == [0, 1]
+    assert rows[0]["first_read"] == 0 and rows[1]["first_read"] == rows[0]["reads"] == 300000
+    assert all(r["lines"] == 300000 and r["ms_per_step"] > 0 and r["forward_scan_ms"] > 0 for r in rows)
+    assert sum(r["matching_lines"] for r in rows) == line["results"]["matching_lines"]
+    assert rows[0]["matching_lines"] != rows[1]["matching_lines"] or rows[0]["matching_lines"] > 0     # (different reads: the generator is indexed by the read number)
+    assert line["ms_per_step"] >= max(r["ms_per_step"] for r in rows) * 0.999                          # the step is the slowest rank's
 
 
 @pytest.mark.gpu
