@@ -151,16 +151,22 @@ int seeqdevStringMatch(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, con
  * that fills the next chunk meanwhile, and one context per GPU, is how seeqFileMatch pipelines its ingest. */
 int seeqdevScanHostBegin(seeqdev_scan_t * scan, const seeqdev_pattern_t * pat, const char * host_text, size_t nbytes,
                          int options, int want);
-/* Several patterns over ONE text (barcode demultiplexing, reference doc/response.tex:358-360): the text is staged once
- * (seeqdevScanHostMulti) or is already resident (seeqdevScanRunMulti), then every pattern gets its own scan over it, back
- * to back on the context's stream.  counts[k] (may be NULL) = pattern k's counts; with SEEQDEV_WANT_RECORDS pattern k's
- * ordered records are kept on the host (seeqdevScanMultiRecords: context-owned, valid until the next multi scan).
- * All patterns must live on the context's device.  Results per pattern are those of a seeqdevScanRun of its own. */
+/* SEVERAL PATTERNS, ONE TEXT (barcode demultiplexing; the reference names the multi-pattern search as the place where its
+ * algorithm has parallel work, doc/response.tex:358-360, and runs one pattern per scan, seeq.c:307-437).  The text is staged
+ * once (seeqdevScanHostMulti) or is already resident (seeqdevScanRunMulti).  A set of 2 .. 32 patterns that has a union
+ * automaton (seeq_multi.h: barcodes of 8 .. 12 positions at distance <= 1 do, sixteen at a time) is scanned in ONE walk over
+ * the text -- read-length lines, SQ_FAIL or SQ_CONVERT -- that finds the candidate (line, pattern) pairs; the exact pass
+ * verifies each pair.  Every other set / text / option, and any set under SEEQ_MULTI=sequential, gets a scan per pattern over
+ * the resident text, back to back on the context's stream (seeqdevScanLastMulti tells which it was).  Synchronous.
+ * counts[k] (may be NULL) = pattern k's counts; with SEEQDEV_WANT_RECORDS pattern k's ordered records are kept on the host
+ * (seeqdevScanMultiRecords: context-owned, valid until the next multi scan).  All patterns must live on the context's
+ * device.  Results per pattern are those of a seeqdevScanRun of its own -- whichever way the set was scanned. */
 int seeqdevScanRunMulti(seeqdev_scan_t * scan, const seeqdev_pattern_t * const * pats, int npat, const void * d_text, size_t nbytes,
                         int options, int want, seeqdev_counts_t * counts);
 int seeqdevScanHostMulti(seeqdev_scan_t * scan, const seeqdev_pattern_t * const * pats, int npat, const char * host_text, size_t nbytes,
                          int options, int want, seeqdev_counts_t * counts);
 int seeqdevScanMultiRecords(const seeqdev_scan_t * scan, int k, const seeqdev_hit_t ** rec, size_t * nrec);
+int seeqdevScanLastMulti(const seeqdev_scan_t * scan);     /* 1: one walk for all patterns; 0: a scan per pattern */
 
 /* PACKED READ BATCHES -- 2 bits per base instead of a byte: a quarter of the HBM (and PCIe) traffic of the ASCII scan for
  * read sets that are kept packed anyway (BAM, .2bit, a sequencer's own format).  Layout, all device pointers:

@@ -67,7 +67,7 @@ EXPORTS = [
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
     "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
-    "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
+    "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanLastMulti", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
 ]
 
 
@@ -181,6 +181,8 @@ def lib():
     L.seeqdevScanHostMulti.restype = C.c_int
     L.seeqdevScanMultiRecords.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.seeqdevScanMultiRecords.restype = C.c_int
+    L.seeqdevScanLastMulti.argtypes = [C.c_void_p]
+    L.seeqdevScanLastMulti.restype = C.c_int
     L.seeqdevScanPacked.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(seeqdev_packed_t), C.c_int, C.c_int]
     L.seeqdevScanPacked.restype = C.c_int
     L.seeqdevPackReads.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]

@@ -556,6 +556,7 @@ __global__ void k_single_line(ScanArgs a)
 #include "seeq_stream.h"
 #include "seeq_pair.h"
 #include "seeq_packed.h"
+#include "seeq_multi.h"
 static_assert(STREAM_NW == STREAM_NW_HOST, "waves per k_stream workgroup");
 extern "C" {
 #include "seeq_dfa.h"
@@ -781,6 +782,96 @@ static void pattern_plan_pair(seeqdev_pattern *mp)
    pthread_mutex_unlock(&mp->plan_lock);
 }
 
+/* ---- one-pass multi-pattern scans: the automata of a pattern SET (seeq_dfa.h section 4, seeq_multi.h) ---- */
+struct MultiPlan {
+   int            npat;
+   unsigned long  ids[SEEQ_MULTI_MAX];      /* generation ids of the patterns it was built for */
+   int            state;                    /* 1 usable, -1 no union automaton for this set: a scan per pattern */
+   seeqdev_pattern upat;                    /* the union as a pattern: what run_segments walks (wlen = maxspan, tau = 0: skip_back = maxspan) */
+   uint16_t      *d_res_next;
+   uint32_t      *d_res_mask;
+   uint32_t       res_states;
+   int            maxspan;
+   int            m[SEEQ_MULTI_MAX], tau[SEEQ_MULTI_MAX], fw[SEEQ_MULTI_MAX];
+   uint32_t      *d_eq;                     /* [npat][768 * 2] the patterns' EQ tables of the exact pass */
+   int            eq_options;               /* the option bits d_eq was made for (-1: none yet) */
+   uint32_t       pair_states, raw_states;
+   int            lp_min, exact;
+};
+
+static void multi_plan_free(MultiPlan *mp)
+{
+   if (!mp) return;
+   if (mp->d_res_next) (void)hipFree(mp->d_res_next);
+   if (mp->d_res_mask) (void)hipFree(mp->d_res_mask);
+   if (mp->d_eq) (void)hipFree(mp->d_eq);
+   if (mp->upat.d_pair) (void)hipFree(mp->upat.d_pair);
+   if (mp->upat.d_peq) (void)hipFree(mp->upat.d_peq);
+   free(mp->upat.h_peq);
+   free(mp);
+}
+
+/* The plan for this set (built once per set and context; a context keeps the plan of its last set). */
+static MultiPlan *multi_plan_for(MultiPlan **slot, const seeqdev_pattern_t *const *pats, int npat)
+{
+   MultiPlan *mp = *slot;
+   if (mp && mp->npat == npat) {
+      bool same = true;
+      for (int k = 0; k < npat; k++) same = same && mp->ids[k] == pats[k]->id;
+      if (same) return mp;
+   }
+   multi_plan_free(mp);
+   *slot = mp = (MultiPlan *)calloc(1, sizeof *mp);
+   if (!mp) return NULL;
+   mp->npat = npat;
+   mp->state = -1;
+   mp->eq_options = -1;
+   for (int k = 0; k < npat; k++) mp->ids[k] = pats[k]->id;
+   if (npat < 2 || npat > SEEQ_MULTI_MAX) return mp;
+   const char *keys[SEEQ_MULTI_MAX];
+   for (int k = 0; k < npat; k++) {
+      if (!pats[k]->keys || pats[k]->wlen > FUSED_MAX_WLEN2) return mp;
+      keys[k] = pats[k]->keys; mp->m[k] = pats[k]->wlen; mp->tau[k] = pats[k]->tau;
+      mp->fw[k] = pats[k]->wlen <= FUSED_MAX_WLEN ? 1 : 2;
+   }
+   seeq_multi_t *d = seeq_multi_build(keys, mp->m, mp->tau, npat);
+   if (!d) return mp;
+   if (d->maxspan <= FUSED_MAX_WLEN2) {
+      seeqdev_pattern &u = mp->upat;
+      u.id = __atomic_add_fetch(&g_pattern_ids, 1ul, __ATOMIC_RELAXED);
+      u.wlen = d->maxspan; u.tau = 0; u.words = seeq_words_for(d->maxspan);
+      u.device = pats[0]->device;
+      u.sdfa_state = -1;
+      u.h_peq = (uint32_t *)calloc((size_t)10 * u.words, sizeof(uint32_t));
+      bool ok = u.h_peq != NULL;
+      ok = ok && hipMalloc((void **)&u.d_peq, (size_t)10 * u.words * sizeof(uint32_t)) == hipSuccess;
+      ok = ok && hipMemset(u.d_peq, 0, (size_t)10 * u.words * sizeof(uint32_t)) == hipSuccess;
+      ok = ok && hipMalloc((void **)&u.d_pair, d->pair->table_bytes) == hipSuccess;
+      ok = ok && hipMemcpy(u.d_pair, d->pair->table, d->pair->table_bytes, hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMalloc((void **)&mp->d_res_next, (size_t)d->res_states * 16) == hipSuccess;
+      ok = ok && hipMemcpy(mp->d_res_next, d->res_next, (size_t)d->res_states * 16, hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMalloc((void **)&mp->d_res_mask, (size_t)d->res_states * 4) == hipSuccess;
+      ok = ok && hipMemcpy(mp->d_res_mask, d->res_mask, (size_t)d->res_states * 4, hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMalloc((void **)&mp->d_eq, (size_t)npat * 1536 * sizeof(uint32_t)) == hipSuccess;
+      if (ok) {
+         u.pair_state = 1;
+         u.pair_units = d->pair->table_bytes / 16;
+         u.pair_states = d->pair->nstates;
+         u.pair_parts = npat; u.pair_mp = d->pair->mp; u.pair_warm = d->pair->warm;
+         u.pair_pacc = d->pair->p_accept;
+         mp->res_states = d->res_states;
+         mp->maxspan = d->maxspan;
+         mp->pair_states = d->pair->nstates; mp->raw_states = d->pair->nstates_raw;
+         mp->exact = d->res_exact;
+         mp->lp_min = d->lp[0];
+         for (int k = 1; k < npat; k++) if (d->lp[k] < mp->lp_min) mp->lp_min = d->lp[k];
+         mp->state = 1;
+      }
+   }
+   seeq_multi_free(d);
+   return mp;
+}
+
 /* ========================================================================== */
 /* Scan context                                                               */
 /* ========================================================================== */
@@ -846,6 +937,15 @@ struct seeqdev_scan {
    /* seeqdevScanRunMulti: per pattern of the last multi scan its counts and (host copy) its records */
    seeqdev_counts_t *multi_cnt; size_t *multi_first; int multi_n, cap_multi_n;
    seeqdev_hit_t *multi_rec; size_t cap_multi_rec, multi_nrec;
+   /* one-pass multi-pattern scans (seeq_multi.h): the plan of the last pattern set, per-pattern workspace */
+   struct MultiPlan *mplan;                               /* owned */
+   bool      multi_active;                                /* run_segments: stop after the candidate list, hand over to multi_post */
+   int       multi_rc;                                    /* multi_post's verdict inside run_segments */
+   uint32_t *ml_mask, *ml_first, *ml_last; size_t cap_ml;            /* per candidate line */
+   uint32_t *mp_start, *mp_line, *mp_col, *mp_last, *mp_nh; size_t cap_mp;      /* npat regions of cap_mp / npat entries */
+   uint32_t *m_bsum; size_t cap_m_bsum;
+   Counters *d_mcnt, *h_mcnt;                             /* [SEEQ_MULTI_MAX], h_ pinned */
+   int       last_multi;                                  /* the last multi scan: 1 = one walk for all patterns, 0 = a scan per pattern */
    /* packed read batches (seeqdevScanPacked) */
    uint32_t *pk_cand, *pk_coff; uint64_t *pk_bmask; size_t cap_pk_reads;      /* candidate columns per read of a segment; per block of 64 reads: candidates before it, their mask */
    uint8_t  *pk_stage; size_t cap_pk_stage;               /* ASCII lines of the candidate reads */
@@ -949,6 +1049,9 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
       for (void *b : ob) if (b) (void)hipFree(b);
    }
    { void *pk[] = {s->pk_cand, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
+   { void *mw[] = {s->ml_mask, s->ml_first, s->ml_last, s->mp_start, s->mp_line, s->mp_col, s->mp_last, s->mp_nh, s->m_bsum, s->d_mcnt}; for (void *b : mw) if (b) (void)hipFree(b); }
+   if (s->h_mcnt) (void)hipHostFree(s->h_mcnt);
+   multi_plan_free(s->mplan);
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
                    s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
@@ -1188,6 +1291,8 @@ static int occupancy_of(seeqdev_scan *s, const void *fn, int threads, size_t lds
    return per_cu;
 }
 
+static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st);
+
 template <int W>
 static int run_segments(seeqdev_scan *s)
 {
@@ -1252,9 +1357,10 @@ static int run_segments(seeqdev_scan *s)
           (kn.kernel == 0 || kn.kernel == 3) && s->seg_bytes % (64u * 128u) == 0) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (__atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
-         use_pair = mp->pair_state == 1 && (kn.kernel == 3 || mp->pair_pacc * s->avg_line <= 0.25);
+         use_pair = mp->pair_state == 1 && (kn.kernel == 3 || s->multi_active || mp->pair_pacc * s->avg_line <= 0.25);
       }
       if (use_pair) { use_stream = true; can_sub = false; }
+      if (s->multi_active && !use_pair) return -2;       /* this text / these options are not k_pair's: a scan per pattern */
    }
    /* k_stream's Myers mode: no automaton fits (or only a filter, which serves read-length lines), the lines are too long for
       the per-line kernels -- the same line-agnostic chunks, the bit-vector column instead of the table (seeq_stream.h) */
@@ -1487,6 +1593,14 @@ static int run_segments(seeqdev_scan *s)
          if (grid_hits == 0) grid_hits = 1;
          if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col,
                                             (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
+         if (s->multi_active) {
+            /* several patterns: the candidate list is the union's -- pattern sets per line, a list per pattern, the exact pass per pattern */
+            if (multi_post(s, a, st)) return -1;
+            hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 3);
+            if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
+            HIP_TRY(hipGetLastError(), EIO);
+            continue;
+         }
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
          uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? ow.tmp : nullptr;   /* COUNT -> EMIT */
          /* (Tried behind k_pair: a lane-queue kernel -- a wave owns 256 .. 512 hit-list entries staged in LDS and a lane that has
@@ -1683,6 +1797,111 @@ static int run_packed(seeqdev_scan *s)
    return 0;
 }
 
+/* ========================================================================== */
+/* Several patterns, one walk (seeq_multi.h)                                    */
+/* ========================================================================== */
+static int multi_ws_ensure(seeqdev_scan *s, int npat)
+{
+   if (!s->d_mcnt) {
+      HIP_TRY(hipMalloc((void **)&s->d_mcnt, SEEQ_MULTI_MAX * sizeof(Counters)), ENOMEM);
+      HIP_TRY(hipHostMalloc((void **)&s->h_mcnt, SEEQ_MULTI_MAX * sizeof(Counters), hipHostMallocDefault), ENOMEM);
+   }
+   if (s->cap_hitlines > s->cap_ml) {
+      if (ws_alloc((void **)&s->ml_mask, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->ml_first, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->ml_last, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      s->cap_ml = s->cap_hitlines;
+   }
+   if (s->cap_hitlines > s->cap_mp) {
+      if (ws_alloc((void **)&s->mp_start, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->mp_line, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->mp_col, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->mp_last, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->mp_nh, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      s->cap_mp = s->cap_hitlines;
+   }
+   const size_t nb = s->cap_hitlines / MULTI_BLOCK + 2;
+   if ((size_t)npat * nb > s->cap_m_bsum) {
+      if (ws_alloc((void **)&s->m_bsum, (size_t)npat * nb * sizeof(uint32_t))) return -1;
+      s->cap_m_bsum = (size_t)npat * nb;
+   }
+   return 0;
+}
+
+/* The part of a segment behind the union walk: `ua` = the union scan's arguments (hit list made, bounds done). */
+static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
+{
+   const MultiPlan *mp = s->mplan;
+   const int npat = mp->npat;
+   const int options = s->options, want = s->want;
+   const int match_opt = options & 3;
+   const bool nh_is_count = want == SEEQDEV_WANT_COUNTMATCH || (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   const uint32_t capP = (uint32_t)(s->cap_hitlines / (size_t)npat);
+   const uint64_t capR = s->cap_records / (uint64_t)npat;
+   MultiArgs m;
+   memset(&m, 0, sizeof m);
+   m.text = ua.text; m.nbytes = ua.nbytes; m.seg_base = ua.seg_base;
+   m.hit_start = s->hit_start; m.hit_line = s->hit_line; m.hit_col = s->hit_col; m.nh = s->nh;
+   m.ucnt = s->d_cnt;
+   m.res_next = mp->d_res_next; m.res_mask = mp->d_res_mask; m.res_states = mp->res_states;
+   m.maxspan = (uint32_t)mp->maxspan;
+   m.window_ok = ua.window_ok;
+   m.options = options;
+   m.lmask = s->ml_mask; m.lfirst = s->ml_first; m.llast = s->ml_last;
+   m.npat = (uint32_t)npat; m.capP = capP;
+   m.p_start = s->mp_start; m.p_line = s->mp_line; m.p_col = s->mp_col; m.p_last = s->mp_last; m.p_nh = s->mp_nh;
+   m.pcnt = s->d_mcnt;
+   m.bsum = s->m_bsum;
+   m.nb = (uint32_t)(s->cap_hitlines / MULTI_BLOCK + 2);
+   for (int k = 0; k < npat; k++) m.span[k] = (uint32_t)(mp->m[k] + mp->tau[k]);
+   {
+      const size_t blocks = (s->cap_hitlines + 255) / 256;
+      const unsigned grid = (unsigned)(blocks < (size_t)s->ncu * 16 ? blocks : (size_t)s->ncu * 16);
+      const size_t lds = (size_t)mp->res_states * 20;
+      if (lds <= 65536) hipLaunchKernelGGL(k_multi_resolve<true>, dim3(grid ? grid : 1), dim3(256), lds, st, m);
+      else hipLaunchKernelGGL(k_multi_resolve<false>, dim3(grid ? grid : 1), dim3(256), 0, st, m);
+      hipLaunchKernelGGL(k_multi_reduce, dim3(m.nb, (unsigned)npat), dim3(256), 0, st, m);
+      hipLaunchKernelGGL(k_multi_top, dim3((unsigned)npat), dim3(256), 0, st, m);
+      hipLaunchKernelGGL(k_multi_apply, dim3(m.nb, (unsigned)npat), dim3(256), 0, st, m);
+   }
+   const size_t hit_blocks = ((size_t)capP + WG - 1) / WG;
+   unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 16 ? hit_blocks : (size_t)s->ncu * 16);
+   if (grid_hits == 0) grid_hits = 1;
+   for (int k = 0; k < npat; k++) {
+      Counters *pc = s->d_mcnt + k;
+      ScanArgs a = ua;
+      a.m = mp->m[k]; a.tau = mp->tau[k];
+      a.hit_start = s->mp_start + (size_t)k * capP; a.hit_line = s->mp_line + (size_t)k * capP; a.cap_hitlines = capP;
+      a.nh = s->mp_nh + (size_t)k * capP;
+      a.records = s->records + (uint64_t)k * capR; a.cap_records = capR; a.rec_off = s->rec_off + (uint64_t)k * capR;
+      a.use_nh = 3u; a.filter = 1u;
+      a.skip_back = (uint32_t)mp->maxspan;
+      a.hit_last = s->mp_last + (size_t)k * capP;
+      a.window_ok = 1u;
+      a.tile_dirty = nullptr; a.tile_dmask = nullptr; a.stream_ntiles = 0; a.stream_ch = 0;
+      a.cnt = pc;
+      const int fw = mp->fw[k];
+      const uint32_t *eqp = mp->d_eq + (size_t)k * 1536;
+      const uint32_t *hcol = s->mp_col + (size_t)k * capP;
+      uint4 *ecache = want == SEEQDEV_WANT_RECORDS ? s->ow.tmp + (size_t)k * capP : nullptr;
+      if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+      else hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+      if (nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
+      launch_scan<0>(s, st, a.nh, a.nh, capP, &pc->seg_nhitlines, 0u, 0u, &pc->seg_nrec);
+      if (want == SEEQDEV_WANT_RECORDS) {
+         hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);
+         const int mo = match_opt == SQ_COUNT ? SQ_FIRST : match_opt;
+         if (fw == 2) { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+                        else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
+         else { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+                else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
+      }
+      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 1 | (!nh_is_count ? 2 : 0));
+   }
+   HIP_TRY(hipGetLastError(), EIO);
+   return 0;
+}
+
 static int dispatch_run(seeqdev_scan *s)
 {
    if (s->is_packed) return run_packed(s);
@@ -1694,8 +1913,20 @@ static int dispatch_run(seeqdev_scan *s)
    return run_segments<16>(s);
 }
 
+static int scan_setup(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const void *d_text, size_t nbytes, int options, int want, int hl_div);
+
 extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const void *d_text, size_t nbytes,
                               int options, int want)
+{
+   if (scan_setup(s, pat, d_text, nbytes, options, want, 8)) return -1;
+   if (dispatch_run(s)) return -1;
+   s->ran = true;
+   return 0;
+}
+
+/* Everything of a run before its launches: arguments, fall-back flags, the optimistic workspace (hit lines: one line in
+   `hl_div`), the line-length sample. */
+static int scan_setup(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const void *d_text, size_t nbytes, int options, int want, int hl_div)
 {
    seeqerr = 0;
    if (!s || !pat || (!d_text && nbytes) || want < 0 || want > 2) { errno = EINVAL; return -1; }
@@ -1716,7 +1947,7 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
    if (!s->user_reserved) {
       const size_t guess = (options & SEEQDEV_SINGLELINE) ? 1 : seg / 32 + 1024;
       if (guess > want_lines) want_lines = guess;
-      if (want_lines / 8 + 1024 > want_hl) want_hl = want_lines / 8 + 1024;
+      if (want_lines / (size_t)hl_div + 1024 > want_hl) want_hl = want_lines / (size_t)hl_div + 1024;
       /* the one-pass kernels cut the hit-line workspace into one slice per wave (<= 8 192 of them): room for 64
          entries each, or the first scan with a hit always costs a second pass */
       if (!(options & SEEQDEV_SINGLELINE) && want_hl < (size_t)8192 * 64) want_hl = (size_t)8192 * 64;
@@ -1737,8 +1968,6 @@ extern "C" int seeqdevScanRun(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, c
       s->avg_text = d_text;
       s->avg_nbytes = nbytes;
    }
-   if (dispatch_run(s)) return -1;
-   s->ran = true;
    return 0;
 }
 
@@ -1964,16 +2193,128 @@ extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, 
 /* ========================================================================== */
 /* Several patterns, one text (barcode demultiplexing: reference doc/response.tex:358-360)  */
 /* ========================================================================== */
-/* The text is staged / resident ONCE; every pattern then gets its own scan over it, back to back on the context's
- * stream (the scan kernels are bound by their own per-character work, not by reading the text -- DESIGN.md -- so a
- * shared pass over the bytes would not be faster than this; what is shared is what costs: the ingest, the H2D copy
- * over the link, the workspace, the line-length sample).  Per pattern: counts, and for SEEQDEV_WANT_RECORDS its
- * ordered records, kept on the host until the next multi scan. */
+/* Several patterns over one text.  ONE walk for all of them when the set has a union automaton and the text is k_pair's
+ * (read-length lines, SQ_FAIL / SQ_CONVERT; seeq_multi.h) -- else, and under SEEQ_MULTI=sequential, a scan per pattern over
+ * the resident text, back to back on the context's stream.  Per pattern: counts, and for SEEQDEV_WANT_RECORDS its ordered
+ * records, kept on the host until the next multi scan.  Either way the results are those of a scan of each pattern alone. */
+static int multi_grow_host(seeqdev_scan_t *s, size_t n)
+{
+   if (s->multi_nrec + n > s->cap_multi_rec) {
+      const size_t cap = (s->multi_nrec + n) + ((s->multi_nrec + n) >> 1) + 1024;
+      seeqdev_hit_t *g = (seeqdev_hit_t *)realloc(s->multi_rec, cap * sizeof *g);
+      if (!g) { errno = ENOMEM; return -1; }
+      s->multi_rec = g;
+      s->cap_multi_rec = cap;
+   }
+   return 0;
+}
+
+/* 0: done; 1: not for this set / text / options (the caller scans pattern by pattern); -1: error */
+static int multi_one_pass(seeqdev_scan_t *s, const seeqdev_pattern_t *const *pats, int npat, const void *d_text, size_t nbytes,
+                          int options, int want, seeqdev_counts_t *counts)
+{
+   const char *env = getenv("SEEQ_MULTI");
+   if (env && !strcmp(env, "sequential")) return 1;
+   if (npat < 2 || npat > SEEQ_MULTI_MAX || nbytes == 0) return 1;
+   const int nd = options & MASK_NONDNA;
+   if ((options & (MASK_INPUT | SEEQDEV_SINGLELINE)) || !(nd == SQ_FAIL || nd == SQ_CONVERT)) return 1;
+   for (int k = 0; k < npat; k++) if (!pats[k] || pats[k]->device != s->device) return 1;
+   if (use_device(s->device)) return -1;
+   MultiPlan *mp = multi_plan_for(&s->mplan, pats, npat);
+   if (!mp) { errno = ENOMEM; return -1; }
+   if (mp->state != 1) return 1;
+   /* the patterns' EQ tables of the exact pass (as run_segments makes the one of a single pattern) */
+   if (mp->eq_options != options) {
+      uint32_t *h = (uint32_t *)calloc((size_t)npat * 1536, sizeof(uint32_t));
+      if (!h) { errno = ENOMEM; return -1; }
+      for (int k = 0; k < npat; k++) {
+         const seeqdev_pattern *pat = pats[k];
+         const int Wp = pat->words, fw = mp->fw[k];
+         uint32_t *tab = h + (size_t)k * 1536;
+         for (int dir = 0; dir < 2; dir++)
+            for (int b = 0; b < 256; b++) {
+               const uint8_t cls = sq_class_of((uint32_t)b, options);
+               uint64_t v;
+               if (cls < 5) {
+                  const uint32_t *q = pat->h_peq + (dir * 5 + cls) * Wp;
+                  const uint64_t col = (uint64_t)q[0] | (Wp > 1 ? (uint64_t)q[1] << 32 : 0);
+                  v = col << (32 * fw - pat->wlen);
+               } else {
+                  v = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
+               }
+               uint32_t *dst = tab + (size_t)(dir * 256 + b) * fw;
+               dst[0] = (uint32_t)v;
+               if (fw == 2) dst[1] = (uint32_t)(v >> 32);
+            }
+      }
+      const hipError_t e = hipMemcpy(mp->d_eq, h, (size_t)npat * 1536 * sizeof(uint32_t), hipMemcpyHostToDevice);
+      free(h);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpy(EQ tables)", EIO);
+      mp->eq_options = options;
+   }
+   if (scan_setup(s, &mp->upat, d_text, nbytes, options, want, 2)) return -1;
+   s->multi_active = true;
+   int rc = -1;
+   for (int attempt = 0; attempt < 8; attempt++) {
+      if (multi_ws_ensure(s, npat)) break;
+      if (hipMemsetAsync(s->d_mcnt, 0, SEEQ_MULTI_MAX * sizeof(Counters), s->stream) != hipSuccess) { errno = EIO; break; }
+      const int r = dispatch_run(s);
+      if (r == -2) { rc = 1; break; }
+      if (r) break;
+      if (hipMemcpyAsync(s->h_mcnt, s->d_mcnt, (size_t)npat * sizeof(Counters), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+          hipStreamSynchronize(s->stream) != hipSuccess) { errno = EIO; break; }
+      const Counters u = *s->h_cnt;
+      uint32_t povf = 0, need_hl = 0;
+      uint64_t need_rec = 0;
+      for (int k = 0; k < npat; k++) {
+         povf |= s->h_mcnt[k].overflow;
+         if (s->h_mcnt[k].need_hitlines > need_hl) need_hl = s->h_mcnt[k].need_hitlines;
+         if (s->h_mcnt[k].need_records > need_rec) need_rec = s->h_mcnt[k].need_records;
+      }
+      if (u.overflow & 64u) { snprintf(g_last_error, sizeof g_last_error, "internal inconsistency in the hit list (k_stream_bounds)"); errno = EIO; break; }
+      if (u.overflow & (8u | 16u | 32u)) { rc = 1; break; }          /* not k_pair's text after all: a scan per pattern */
+      if (!u.overflow && !povf) {
+         /* results: counts, then every pattern's records from its region */
+         const uint64_t capR = s->cap_records / (uint64_t)npat;
+         s->multi_nrec = 0;
+         rc = 0;
+         for (int k = 0; k < npat && rc == 0; k++) {
+            const Counters &h = s->h_mcnt[k];
+            seeqdev_counts_t &o = s->multi_cnt[k];
+            o.nlines = h.lines; o.nmatchlines = h.matchlines; o.nhits = h.hits; o.nrecords = h.records; o.nheaders = h.headers;
+            s->multi_first[k] = s->multi_nrec;
+            const size_t n = want == SEEQDEV_WANT_RECORDS ? (size_t)h.records : 0;
+            if (n) {
+               if (multi_grow_host(s, n)) { rc = -1; break; }
+               if (hipMemcpyAsync(s->multi_rec + s->multi_nrec, s->records + (uint64_t)k * capR, n * sizeof(seeqdev_hit_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) { errno = EIO; rc = -1; break; }
+               s->multi_nrec += n;
+            }
+            if (counts) counts[k] = o;
+         }
+         if (rc == 0 && hipStreamSynchronize(s->stream) != hipSuccess) { errno = EIO; rc = -1; }
+         if (rc == 0) { s->multi_first[npat] = s->multi_nrec; s->multi_n = npat; s->last_multi = 1; }
+         break;
+      }
+      size_t nl = s->cap_lines, nhl = s->cap_hitlines, nrec = s->cap_records;
+      if (u.overflow & 1u) nl = (size_t)u.need_lines + (u.need_lines >> 3) + 64;
+      if (u.overflow & 2u) nhl = (size_t)u.need_hitlines + (u.need_hitlines >> 3) + 64;
+      if (u.overflow & 128u) { s->no_window = true; s->fallback_ttl = 32; }
+      if (povf & 2u) { const size_t w = ((size_t)need_hl + (need_hl >> 3) + 64) * (size_t)npat; if (w > nhl) nhl = w; }
+      if (povf & 4u) { const size_t w = ((size_t)need_rec + (size_t)(need_rec >> 3) + 64) * (size_t)npat; if (w > nrec) nrec = w; }
+      if ((u.overflow & 1u) && nhl < nl / 2) nhl = nl / 2 + 64;
+      if (attempt == 7) { snprintf(g_last_error, sizeof g_last_error, "workspace did not converge"); errno = ENOMEM; break; }
+      if (reserve_impl(s, s->nbytes, nl, nhl, nrec)) break;
+   }
+   s->multi_active = false;
+   s->ran = false;                                         /* (seeqdevScanFetch has nothing to fetch: the multi scan is complete) */
+   return rc;
+}
+
 extern "C" int seeqdevScanRunMulti(seeqdev_scan_t *s, const seeqdev_pattern_t *const *pats, int npat, const void *d_text, size_t nbytes,
                                    int options, int want, seeqdev_counts_t *counts)
 {
    seeqerr = 0;
-   if (!s || !pats || npat < 1 || (!d_text && nbytes)) { errno = EINVAL; return -1; }
+   if (!s || !pats || npat < 1 || (!d_text && nbytes) || want < 0 || want > 2) { errno = EINVAL; return -1; }
    if (npat > s->cap_multi_n) {
       seeqdev_counts_t *c = (seeqdev_counts_t *)realloc(s->multi_cnt, (size_t)npat * sizeof *c);
       if (c) s->multi_cnt = c;
@@ -1984,19 +2325,19 @@ extern "C" int seeqdevScanRunMulti(seeqdev_scan_t *s, const seeqdev_pattern_t *c
    }
    s->multi_n = 0;
    s->multi_nrec = 0;
+   s->last_multi = 0;
+   {
+      const int r = multi_one_pass(s, pats, npat, d_text, nbytes, options, want, counts);
+      if (r <= 0) return r;
+   }
+   s->multi_nrec = 0;
    for (int k = 0; k < npat; k++) {
       if (seeqdevScanRun(s, pats[k], d_text, nbytes, options, want)) return -1;
       if (seeqdevScanFetch(s, &s->multi_cnt[k])) return -1;
       s->multi_first[k] = s->multi_nrec;
       const size_t n = want == SEEQDEV_WANT_RECORDS ? (size_t)s->multi_cnt[k].nrecords : 0;
       if (n) {
-         if (s->multi_nrec + n > s->cap_multi_rec) {
-            const size_t cap = (s->multi_nrec + n) + ((s->multi_nrec + n) >> 1) + 1024;
-            seeqdev_hit_t *g = (seeqdev_hit_t *)realloc(s->multi_rec, cap * sizeof *g);
-            if (!g) { errno = ENOMEM; return -1; }
-            s->multi_rec = g;
-            s->cap_multi_rec = cap;
-         }
+         if (multi_grow_host(s, n)) return -1;
          if (seeqdevScanCopyRecords(s, s->multi_rec + s->multi_nrec, 0, n)) return -1;
          s->multi_nrec += n;
       }
@@ -2006,6 +2347,9 @@ extern "C" int seeqdevScanRunMulti(seeqdev_scan_t *s, const seeqdev_pattern_t *c
    s->multi_n = npat;
    return 0;
 }
+
+/* 1: the last multi scan walked the text once for all its patterns; 0: a scan per pattern. */
+extern "C" int seeqdevScanLastMulti(const seeqdev_scan_t *s) { return s ? s->last_multi : 0; }
 
 extern "C" int seeqdevScanHostMulti(seeqdev_scan_t *s, const seeqdev_pattern_t *const *pats, int npat, const char *host_text, size_t nbytes,
                                     int options, int want, seeqdev_counts_t *counts)

@@ -202,6 +202,10 @@ class Scanner:
             out.append(res)
         return out
 
+    def last_multi_one_pass(self):
+        """True when the last multi-pattern scan walked the text once for all its patterns (seeq_multi.h)."""
+        return bool(self._lib.seeqdevScanLastMulti(self._h))
+
     def scan_host_multi(self, patterns, data, options=0, want=WANT_COUNTLINES):
         """data: bytes, staged ONCE; every pattern gets its own scan over it.  -> one result dict per pattern."""
         return self._multi(patterns, lambda arr, n, cnts: self._lib.seeqdevScanHostMulti(self._h, arr, n, data, len(data), options, want, cnts), want)

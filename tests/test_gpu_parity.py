@@ -389,6 +389,7 @@ def test_multi_pattern_scan_vs_independent_oracle_scans(gpu, capi, oracle):
     sc = dev.Scanner()
     for opt in (SQ_BEST, SQ_ALL):
         got = sc.scan_host_multi(pats, buf, opt, dev.WANT_RECORDS)
+        assert sc.last_multi_one_pass()                     # the set has a union automaton: one walk for all eight (seeq_multi.h)
         exp = [oracle.buffer_scan(b, t, buf, opt) for b, t in zip(barcodes, taus)]
         for k in range(len(pats)):
             assert got[k]["nlines"] == exp[k]["nlines"] == len(lines)
@@ -1251,3 +1252,66 @@ def test_all_mode_many_records_per_line(gpu, capi, oracle):
                 exp = oracle.buffer_scan(pattern, tau, fa, SQ_ALL, fasta=True)
                 got = _scan(capi, pattern, tau, fa, SQ_ALL, dev.WANT_RECORDS, True)
                 assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, dense, "fasta")
+
+
+MULTI16 = r"""
+import os, sys, random, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from oracle.pyoracle import Oracle, SQ_ALL, SQ_BEST, SQ_FIRST
+from seeq_amd import device as dev
+from test_gpu_parity import _mutate
+o = Oracle()
+rng = random.Random(%(seed)d)
+lens = %(lens)r
+barcodes = ["".join(rng.choice("ACGT") for _ in range(rng.choice(lens))) for _ in range(16)]
+taus = [rng.choice(%(taus)r) for _ in range(16)]
+lines = []
+for i in range(%(nlines)d):
+    n = rng.choice([150, 150, 150, 151, 100, 36, 0, 12])
+    t = [rng.choice("ACGT") for _ in range(n)]
+    for _ in range(rng.choice([0, 1, 1, 1, 2])):
+        k = rng.randrange(16)
+        c = _mutate(rng, barcodes[k], rng.randint(0, taus[k] + 1))
+        if n >= len(c):
+            q = rng.choice([0, 0, n - len(c), rng.randrange(n - len(c) + 1)])
+            t[q:q + len(c)] = list(c)
+    if rng.random() < 0.02 and n: t[rng.randrange(n)] = "N"
+    if rng.random() < 0.01 and n: t = [x.lower() for x in t]
+    if %(foreign)r and rng.random() < 0.01 and n: t[rng.randrange(n)] = rng.choice("!*XZ-.")
+    lines.append("".join(t)[:n])
+buf = ("\n".join(lines) + "\n").encode()
+pats = [dev.Pattern(b, t) for b, t in zip(barcodes, taus)]
+sc = dev.Scanner()
+nd = %(nd)d
+for opt, want in ((SQ_BEST, dev.WANT_RECORDS), (SQ_ALL, dev.WANT_RECORDS), (SQ_FIRST, dev.WANT_RECORDS), (0, dev.WANT_COUNTLINES), (0, dev.WANT_COUNTMATCH)):
+    os.environ.pop("SEEQ_MULTI", None)
+    one = sc.scan_host_multi(pats, buf, opt | nd, want)
+    assert sc.last_multi_one_pass(), "the one-pass path did not run"
+    os.environ["SEEQ_MULTI"] = "sequential"
+    seq = sc.scan_host_multi(pats, buf, opt | nd, want)
+    assert not sc.last_multi_one_pass()
+    for k in range(16):
+        for f in ("nlines", "nmatchlines", "nhits", "nrecords"):
+            assert one[k][f] == seq[k][f], (k, f, opt, want, one[k], seq[k])
+        if want == dev.WANT_RECORDS:
+            assert np.array_equal(one[k]["records"], seq[k]["records"]), (k, opt)
+    if want == dev.WANT_RECORDS:
+        for k in (0, 5, 11, 15):
+            exp = o.buffer_scan(barcodes[k], taus[k], buf, opt | nd)
+            assert one[k]["nmatchlines"] == exp["nmatchlines"] and np.array_equal(one[k]["records"].astype(np.uint64), exp["records"]), (k, opt)
+print("MULTI OK", sum(r["nmatchlines"] for r in one))
+"""
+
+
+@pytest.mark.parametrize("case", [dict(seed=5, lens=[10], taus=[1], nlines=60000, foreign=False, nd=0, env={}),
+                                  dict(seed=6, lens=[8, 9, 11, 12], taus=[0, 1], nlines=60000, foreign=True, nd=0, env={}),
+                                  dict(seed=7, lens=[8, 10, 12], taus=[1], nlines=40000, foreign=True, nd=4, env={}),
+                                  dict(seed=8, lens=[9, 10], taus=[1], nlines=40000, foreign=False, nd=0, env={"SEEQ_SEGMENT_BYTES": "65536"})],
+                         ids=["10mers", "mixed-foreign", "convert", "small-segments"])
+def test_multi_pattern_one_pass_equals_sequential(gpu, capi, oracle, case):
+    """Sixteen barcodes over one text (seeq_multi.h): the one walk for all of them against a scan per pattern
+    (SEEQ_MULTI=sequential) -- counts and records of every pattern, every match option and `want` -- and four of the patterns
+    against the oracle; reads with planted barcodes at either end, N, lower case, foreign bytes, SQ_CONVERT, 64 KiB segments."""
+    code = MULTI16 % dict(root=ROOT, **{k: v for k, v in case.items() if k != "env"})
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **case["env"]), timeout=900)
+    assert r.returncode == 0 and "MULTI OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
