@@ -1,0 +1,31 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r03as; mkdir -p $O
+export TMPDIR=/tmp; REPO=$PWD; cd /tmp
+cat > /tmp/mb.py <<'PY'
+import os, sys, time
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "profiles"))
+import numpy as np, torch
+from seeq_amd import device as dev
+import multi_bench as mb
+torch.cuda.set_device(0)
+rng = np.random.default_rng(3)
+barcodes = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=10)) for _ in range(16)]
+text = mb.make_reads(10_000_000, 150, barcodes, 0.9, 17)
+pats = [dev.Pattern(b, 1) for b in barcodes]
+sc = dev.Scanner(torch.cuda.current_stream().cuda_stream)
+for it in range(3):
+    t0 = time.perf_counter(); got = sc.scan_tensor_multi(pats, text, dev.SQ_BEST, dev.WANT_COUNTLINES); print(time.perf_counter() - t0, sc.last_multi_one_pass(), sum(g["nmatchlines"] for g in got))
+PY
+for e in 0 1 2; do
+SEEQ_MULTI_EXP=$e REPO=$REPO timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/trace_$e -- python3 /tmp/mb.py > $REPO/$O/trace_$e.log 2>&1 || break
+done
+cd $REPO
+python3 - <<'PY'
+import csv, glob
+for w in (0, 1, 2):
+  for f in glob.glob("gpurun_out/r03as/trace_%d/**/*kernel_stats.csv" % w, recursive=True):
+    for r in list(csv.DictReader(open(f))):
+        if "resolve" in r["Name"]: print(w, "%-50s calls %5s avg_us %10.2f" % (r["Name"][:50], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+grep -v "^[EW]20" $O/trace_0.log | tail -4

@@ -138,6 +138,7 @@ struct ScanArgs {
    uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
    uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: m + tau - 1 */
    const uint32_t *hit_last;    /* packed read batches: per hit line the column of its LAST candidate (else NULL: the repeats in the hit list say) */
+   const uint32_t *hit_idx;     /* several patterns, one walk: this pattern's list holds indices into the shared per-line arrays (else NULL) */
    uint32_t       window_ok;    /* k_pair: every candidate the walk dropped is announced (nh[] bit 1 of the kept one) and repeats of a line
                                    follow it in the hit list -- a line with ONE candidate is scanned over that candidate's window only */
    Counters      *cnt;
@@ -942,7 +943,7 @@ struct seeqdev_scan {
    bool      multi_active;                                /* run_segments: stop after the candidate list, hand over to multi_post */
    int       multi_rc;                                    /* multi_post's verdict inside run_segments */
    uint32_t *ml_mask, *ml_first, *ml_last; size_t cap_ml;            /* per candidate line */
-   uint32_t *mp_start, *mp_line, *mp_col, *mp_last, *mp_nh; size_t cap_mp;      /* npat regions of cap_mp / npat entries */
+   uint32_t *mp_idx, *mp_nh; size_t cap_mp;               /* npat regions of cap_mp / npat entries: index into the per-line arrays, hits */
    uint32_t *m_bsum; size_t cap_m_bsum;
    Counters *d_mcnt, *h_mcnt;                             /* [SEEQ_MULTI_MAX], h_ pinned */
    int       last_multi;                                  /* the last multi scan: 1 = one walk for all patterns, 0 = a scan per pattern */
@@ -1049,7 +1050,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
       for (void *b : ob) if (b) (void)hipFree(b);
    }
    { void *pk[] = {s->pk_cand, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
-   { void *mw[] = {s->ml_mask, s->ml_first, s->ml_last, s->mp_start, s->mp_line, s->mp_col, s->mp_last, s->mp_nh, s->m_bsum, s->d_mcnt}; for (void *b : mw) if (b) (void)hipFree(b); }
+   { void *mw[] = {s->ml_mask, s->ml_first, s->ml_last, s->mp_idx, s->mp_nh, s->m_bsum, s->d_mcnt}; for (void *b : mw) if (b) (void)hipFree(b); }
    if (s->h_mcnt) (void)hipHostFree(s->h_mcnt);
    multi_plan_free(s->mplan);
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
@@ -1063,7 +1064,8 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    if (s->h_strout) (void)hipHostFree(s->h_strout);
    for (size_t i = 0; i < 4 * s->nev_seg; i++) (void)hipEventDestroy(s->ev[i]);
    free(s->ev);
-   free(s->multi_cnt); free(s->multi_first); free(s->multi_rec);
+   free(s->multi_cnt); free(s->multi_first);
+   if (s->multi_rec) (void)hipHostFree(s->multi_rec);
    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
    free(s);
 }
@@ -1813,10 +1815,7 @@ static int multi_ws_ensure(seeqdev_scan *s, int npat)
       s->cap_ml = s->cap_hitlines;
    }
    if (s->cap_hitlines > s->cap_mp) {
-      if (ws_alloc((void **)&s->mp_start, s->cap_hitlines * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&s->mp_line, s->cap_hitlines * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&s->mp_col, s->cap_hitlines * sizeof(uint32_t))) return -1;
-      if (ws_alloc((void **)&s->mp_last, s->cap_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->mp_idx, s->cap_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->mp_nh, s->cap_hitlines * sizeof(uint32_t))) return -1;
       s->cap_mp = s->cap_hitlines;
    }
@@ -1847,22 +1846,25 @@ static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
    m.maxspan = (uint32_t)mp->maxspan;
    m.window_ok = ua.window_ok;
    m.options = options;
+   /* whole patterns in the resolve automaton: its sets are exact -- counting lines needs no exact pass (as behind k_stream's complete automata) */
+   const bool trust = mp->exact && want == SEEQDEV_WANT_COUNTLINES;
+   m.trust = trust ? 1u : 0u;
    m.lmask = s->ml_mask; m.lfirst = s->ml_first; m.llast = s->ml_last;
    m.npat = (uint32_t)npat; m.capP = capP;
-   m.p_start = s->mp_start; m.p_line = s->mp_line; m.p_col = s->mp_col; m.p_last = s->mp_last; m.p_nh = s->mp_nh;
+   m.p_idx = s->mp_idx;
    m.pcnt = s->d_mcnt;
    m.bsum = s->m_bsum;
    m.nb = (uint32_t)(s->cap_hitlines / MULTI_BLOCK + 2);
-   for (int k = 0; k < npat; k++) m.span[k] = (uint32_t)(mp->m[k] + mp->tau[k]);
    {
-      const size_t blocks = (s->cap_hitlines + 255) / 256;
-      const unsigned grid = (unsigned)(blocks < (size_t)s->ncu * 16 ? blocks : (size_t)s->ncu * 16);
+      const size_t blocks = (s->cap_hitlines + MULTI_RESOLVE_WG - 1) / MULTI_RESOLVE_WG;
+      const unsigned grid = (unsigned)(blocks < (size_t)s->ncu * 2 ? blocks : (size_t)s->ncu * 2);      /* persistent: the table is staged once per workgroup */
       const size_t lds = (size_t)mp->res_states * 20;
-      if (lds <= 65536) hipLaunchKernelGGL(k_multi_resolve<true>, dim3(grid ? grid : 1), dim3(256), lds, st, m);
-      else hipLaunchKernelGGL(k_multi_resolve<false>, dim3(grid ? grid : 1), dim3(256), 0, st, m);
-      hipLaunchKernelGGL(k_multi_reduce, dim3(m.nb, (unsigned)npat), dim3(256), 0, st, m);
+      if (lds <= 65536) hipLaunchKernelGGL(k_multi_resolve<true>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds, st, m);
+      else hipLaunchKernelGGL(k_multi_resolve<false>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), 0, st, m);
+      hipLaunchKernelGGL(k_multi_reduce, dim3(m.nb), dim3(256), 0, st, m);
       hipLaunchKernelGGL(k_multi_top, dim3((unsigned)npat), dim3(256), 0, st, m);
-      hipLaunchKernelGGL(k_multi_apply, dim3(m.nb, (unsigned)npat), dim3(256), 0, st, m);
+      if (trust) { HIP_TRY(hipGetLastError(), EIO); return 0; }
+      hipLaunchKernelGGL(k_multi_apply, dim3(m.nb), dim3(256), 0, st, m);
    }
    const size_t hit_blocks = ((size_t)capP + WG - 1) / WG;
    unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 16 ? hit_blocks : (size_t)s->ncu * 16);
@@ -1871,18 +1873,19 @@ static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
       Counters *pc = s->d_mcnt + k;
       ScanArgs a = ua;
       a.m = mp->m[k]; a.tau = mp->tau[k];
-      a.hit_start = s->mp_start + (size_t)k * capP; a.hit_line = s->mp_line + (size_t)k * capP; a.cap_hitlines = capP;
+      a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = capP;      /* the union's lines, through this pattern's index list */
+      a.hit_idx = s->mp_idx + (size_t)k * capP;
       a.nh = s->mp_nh + (size_t)k * capP;
       a.records = s->records + (uint64_t)k * capR; a.cap_records = capR; a.rec_off = s->rec_off + (uint64_t)k * capR;
       a.use_nh = 3u; a.filter = 1u;
       a.skip_back = (uint32_t)mp->maxspan;
-      a.hit_last = s->mp_last + (size_t)k * capP;
+      a.hit_last = s->ml_last;
       a.window_ok = 1u;
       a.tile_dirty = nullptr; a.tile_dmask = nullptr; a.stream_ntiles = 0; a.stream_ch = 0;
       a.cnt = pc;
       const int fw = mp->fw[k];
       const uint32_t *eqp = mp->d_eq + (size_t)k * 1536;
-      const uint32_t *hcol = s->mp_col + (size_t)k * capP;
+      const uint32_t *hcol = s->ml_first;
       uint4 *ecache = want == SEEQDEV_WANT_RECORDS ? s->ow.tmp + (size_t)k * capP : nullptr;
       if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
       else hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
@@ -2199,10 +2202,15 @@ extern "C" int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, 
  * records, kept on the host until the next multi scan.  Either way the results are those of a scan of each pattern alone. */
 static int multi_grow_host(seeqdev_scan_t *s, size_t n)
 {
-   if (s->multi_nrec + n > s->cap_multi_rec) {
+   if (s->multi_nrec + n > s->cap_multi_rec) {             /* page-locked: the records of a barcode set are hundreds of MB, and a pageable copy runs at a fifth of the link */
       const size_t cap = (s->multi_nrec + n) + ((s->multi_nrec + n) >> 1) + 1024;
-      seeqdev_hit_t *g = (seeqdev_hit_t *)realloc(s->multi_rec, cap * sizeof *g);
-      if (!g) { errno = ENOMEM; return -1; }
+      seeqdev_hit_t *g = nullptr;
+      if (hipHostMalloc((void **)&g, cap * sizeof *g, hipHostMallocDefault) != hipSuccess || !g) { errno = ENOMEM; return -1; }
+      if (s->multi_rec) {
+         if (hipStreamSynchronize(s->stream) != hipSuccess) { (void)hipHostFree(g); errno = EIO; return -1; }      /* (copies into the old buffer may be in flight) */
+         if (s->multi_nrec) memcpy(g, s->multi_rec, s->multi_nrec * sizeof *g);
+         (void)hipHostFree(s->multi_rec);
+      }
       s->multi_rec = g;
       s->cap_multi_rec = cap;
    }
@@ -2278,6 +2286,11 @@ static int multi_one_pass(seeqdev_scan_t *s, const seeqdev_pattern_t *const *pat
          const uint64_t capR = s->cap_records / (uint64_t)npat;
          s->multi_nrec = 0;
          rc = 0;
+         if (want == SEEQDEV_WANT_RECORDS) {
+            size_t total = 0;
+            for (int k = 0; k < npat; k++) total += (size_t)s->h_mcnt[k].records;
+            if (multi_grow_host(s, total)) { rc = -1; break; }
+         }
          for (int k = 0; k < npat && rc == 0; k++) {
             const Counters &h = s->h_mcnt[k];
             seeqdev_counts_t &o = s->multi_cnt[k];

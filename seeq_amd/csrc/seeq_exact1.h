@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
    const uint32_t kmax = (nhl + stride - 1) / stride * stride;
    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < kmax; k += stride) {
       bool done = k >= nhl;
-      const uint32_t hs = done ? 0u : a.hit_start[k];
+      /* hit_idx (several patterns, one walk -- seeq_multi.h): entry k of this pattern's list is entry hit_idx[k] of the shared per-line arrays */
+      const uint32_t kk = (a.hit_idx && !done) ? a.hit_idx[k] : k;
+      const uint32_t hs = done ? 0u : a.hit_start[kk];
       if (hs == 0xFFFFFFFFu) done = true;                  /* k_stream: repeat of the previous entry's line */
       const uint64_t off = done ? a.seg_base : a.seg_base + hs;
       if (MODE == SQ_MODE_COUNT && trusted && count_any) {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       uint32_t stop_at = 0xFFFFFFFFu;
       int32_t lastsub = -0x40000000;                       /* column of the last score <= tau seen */
       if (hit_col && (trusted || walk || a.filter) && !done) {
-         const uint32_t col = hit_col[k];
+         const uint32_t col = hit_col[kk];
          /* nothing ends the line before the first candidate (clean text), so the scan may start just before it: no
             occurrence ends before `col` (a filter: every occurrence contains a part that ends at or after the first
             candidate), and a column started skip_back >= m + tau - 1 bytes earlier has the line's own scores from there */
@@ -217,8 +219,12 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
             /* the line's further candidates are the repeats behind this entry (a third of the hit lines has one: an occurrence
                near the end of a chain is seen by the next chain's warm-up, which then reports its own first pair): the scan
                runs from before the first candidate to behind the last one */
-            uint32_t lastcol = a.hit_last ? a.hit_last[k] : col, unbounded = a.nh[k] & 2u;      /* (hit_last: packed read batches -- the candidates of a read come as one entry) */
-            for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) { lastcol = hit_col[j] - hs; unbounded |= a.nh[j] & 2u; }
+            uint32_t lastcol = a.hit_last ? a.hit_last[kk] : col, unbounded = a.nh[k] & 2u;      /* (hit_last: packed read batches -- the candidates of a read come as one entry) */
+            if (a.hit_idx) {                               /* the line's window is the union's: it ends maxspan (= skip_back) + 2 behind the last candidate; no last candidate: no end */
+               unbounded = lastcol == 0xFFFFFFFFu ? 2u : 0u;
+               lastcol += a.skip_back - (m + tau1 - 1u);
+            }
+            else for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) { lastcol = hit_col[j] - hs; unbounded |= a.nh[j] & 2u; }
             if (!unbounded) stop_at = lastcol + m + tau1 + 1u;
          }
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       uint32_t cstart = 0, chas = 0;                                  /* EMIT: the cached record's start, when COUNT recovered it */
       bool from_cache = false;
       if (MODE == SQ_MODE_EMIT && !done) {
-         line_no = a.hit_line[k];
+         line_no = a.hit_line[kk];
          if (match_opt == SQ_ALL) { out = a.records + c->records + a.nh[k]; out_cap = 0xFFFFFFFFu; }
          else { out = a.records + c->records + (by_nh ? a.nh[k] : k); out_cap = 1; }
          if (cache_ok) {
@@ -456,10 +462,11 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
       const uint32_t novf = ovf[0].x;
       for (uint32_t e = 1u + (threadIdx.x & 63u); e <= novf; e += 64u) {
          const uint4 o = ovf[e];                                    /* {hit-list entry, index in the line, end, dist} */
-         const uint64_t off = a.seg_base + a.hit_start[o.x];
+         const uint32_t ox = a.hit_idx ? a.hit_idx[o.x] : o.x;
+         const uint64_t off = a.seg_base + a.hit_start[ox];
          const uint64_t slot = c->records + a.nh[o.x] + o.y;
          seeqdev_hit_t h;
-         h.line = a.hit_line[o.x];
+         h.line = a.hit_line[ox];
          h.start = exact1_reverse<W>(a.text, off, a.nbytes, o.z, o.w, eqr_base, m, tau1, row);
          h.end = o.z;
          h.dist = o.w;

@@ -36,65 +36,94 @@ struct MultiArgs {
    uint32_t       res_states;
    uint32_t       maxspan;
    uint32_t       window_ok;
+   uint32_t       trust;          /* the sets are exact and only lines are counted: k_multi_top books them, no exact pass */
    int            options;
    /* per candidate line */
    uint32_t      *lmask, *lfirst, *llast;
    /* per pattern: regions of capP entries */
    uint32_t       npat, capP;
-   uint32_t      *p_start, *p_line, *p_col, *p_last, *p_nh;
+   uint32_t      *p_idx;          /* pattern p's list: entries of the union's list whose set holds p */
    Counters      *pcnt;           /* [npat] */
    uint32_t      *bsum;           /* [npat * nb] block sums */
    uint32_t       nb;
-   uint32_t       span[SEEQ_MULTI_MAX];      /* m + tau of every pattern */
 };
 
-static constexpr int MULTI_ITEMS = 8;
-static constexpr int MULTI_BLOCK = 256 * MULTI_ITEMS;
+static constexpr int MULTI_ITEMS = 8;                      /* rounds of 64 lines per wave */
+static constexpr int MULTI_BLOCK = 256 * MULTI_ITEMS;      /* lines per workgroup of the split kernels: wave w owns lines [512 w, 512 w + 512) of them */
+static constexpr int MULTI_RESOLVE_WG = 1024;              /* the table is staged once per workgroup: large workgroups, full occupancy */
 
 /* INLDS: the resolve table and the masks are staged in LDS (res_states * 20 bytes) */
 template <bool INLDS>
-__global__ __launch_bounds__(256) void k_multi_resolve(MultiArgs a)
+__global__ __launch_bounds__(MULTI_RESOLVE_WG) void k_multi_resolve(MultiArgs a)
 {
    extern __shared__ __align__(16) uint8_t ms_tab[];
    __shared__ uint8_t s_cls[256];
-   for (int b = threadIdx.x; b < 256; b += 256) s_cls[b] = sq_class_of((uint32_t)b, a.options);
+   if (threadIdx.x < 256) s_cls[threadIdx.x] = sq_class_of((uint32_t)threadIdx.x, a.options);
    if (INLDS) {                                           /* the table, then the masks */
       const fused_v4u *src = reinterpret_cast<const fused_v4u *>(a.res_next);
-      for (uint32_t i = threadIdx.x; i < a.res_states; i += 256) reinterpret_cast<fused_v4u *>(ms_tab)[i] = src[i];
+      for (uint32_t i = threadIdx.x; i < a.res_states; i += MULTI_RESOLVE_WG) reinterpret_cast<fused_v4u *>(ms_tab)[i] = src[i];
       uint32_t *mk = reinterpret_cast<uint32_t *>(ms_tab + (size_t)a.res_states * 16);
-      for (uint32_t i = threadIdx.x; i < a.res_states; i += 256) mk[i] = a.res_mask[i];
+      for (uint32_t i = threadIdx.x; i < a.res_states; i += MULTI_RESOLVE_WG) mk[i] = a.res_mask[i];
    }
    __syncthreads();
-   const uint16_t *tab = INLDS ? reinterpret_cast<const uint16_t *>(ms_tab) : a.res_next;
-   const uint32_t *masks = INLDS ? reinterpret_cast<const uint32_t *>(ms_tab + (size_t)a.res_states * 16) : a.res_mask;
    const Counters *c = a.ucnt;
    const uint32_t nhl = c->seg_nhitlines;
    const bool whole = !a.window_ok || c->dirty != 0;      /* no windows: every candidate line from its first byte to its end */
-   const uint32_t stride = gridDim.x * 256;
-   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
+   const uint32_t stride = gridDim.x * MULTI_RESOLVE_WG;
+   for (uint32_t k = blockIdx.x * MULTI_RESOLVE_WG + threadIdx.x; k < nhl; k += stride) {
       const uint32_t hs = a.hit_start[k];
       if (hs == 0xFFFFFFFFu) { a.lmask[k] = 0u; continue; }      /* a repeat: its line's first entry speaks for it */
       const uint32_t col = a.hit_col[k];
-      uint32_t lastcol = col, unbounded = a.nh[k] & 2u;
-      for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) { lastcol = a.hit_col[j] - hs; unbounded |= a.nh[j] & 2u; }
-      const bool all = whole || unbounded != 0;
-      const uint32_t from = (all || col <= a.maxspan) ? 0u : col - a.maxspan;
-      const uint32_t to = all ? 0xFFFFFFFFu : lastcol + a.maxspan + 2u;
       const uint64_t off = a.seg_base + hs;
-      uint32_t q = 0, acc = 0;
+      if ((a.options & SEEQDEV_FASTA) && a.text[off] == '>') { a.lmask[k] = 0u; continue; }      /* a candidate inside a FASTA header */
+      /* the line's candidates: this entry and the repeats behind it.  Every occurrence of a pattern lies within maxspan of
+         ITS candidate (seeq_dfa.h section 4), so the walk covers [c - maxspan, c + maxspan + 2) of every candidate c --
+         windows that touch (or lie in one chain of k_pair) are walked through, a gap is jumped with a fresh start at the root.  (One window from the first
+         candidate to the last: a read with a barcode in front and a chance candidate at its end held its whole wave for
+         ten blocks of text instead of two -- 0.85 ms per 10 M reads against 0.4.) */
+      uint32_t lastcol = col, unbounded = a.nh[k] & 2u;
+      uint32_t jn = k + 1;                                 /* next entry of the list to look at */
+      bool all = whole || unbounded != 0;
+      uint32_t pos = (all || col <= a.maxspan) ? 0u : col - a.maxspan;
+      uint32_t to = all ? 0xFFFFFFFFu : col + a.maxspan + 2u;
+      uint32_t q = 0, acc = 0;                             /* q: INLDS the byte offset of the state's row, else the state */
       bool done = false;
-      for (uint32_t pos = from; pos < to && !done; pos += 16) {
+      while (!done) {
+         if (pos >= to) {                                  /* the window is walked: the next candidate of the line */
+            if (!(jn < nhl && a.hit_start[jn] == 0xFFFFFFFFu)) break;
+            const uint32_t c = a.hit_col[jn] - hs;
+            if (a.nh[jn] & 2u) { all = true; pos = 0; to = 0xFFFFFFFFu; q = 0; acc = 0; jn = nhl; continue; }      /* a chain dropped candidates: the whole line */
+            jn++;
+            /* k_pair lists the FIRST and the LAST candidate of a chain (64 bytes of text): two entries of one chain may have
+               unlisted candidates between them -- that stretch is walked through; between two chains there are none */
+            const bool same_chain = ((hs + c) >> 6) == ((hs + lastcol) >> 6);
+            lastcol = c;
+            if (!same_chain && c > pos + a.maxspan) { pos = c - a.maxspan; q = 0; }
+            to = c + a.maxspan + 2u;
+            continue;
+         }
          const fused_v4u v = direct_load16(a.text, off + pos, a.nbytes);       /* (bytes beyond the buffer read as NUL: a terminator) */
          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+         uint32_t cls[16];
+#pragma unroll
+         for (int i = 0; i < 16; i++) cls[i] = s_cls[(w[i >> 2] >> (8 * (i & 3))) & 0xFFu];      /* (off the chain of the walk: all sixteen go out together) */
+         bool stop = false;                                /* this window ends inside the block */
 #pragma unroll
          for (int i = 0; i < 16; i++) {
-            const uint32_t cls = s_cls[(w[i >> 2] >> (8 * (i & 3))) & 0xFFu];
-            done = done || cls >= 5u || pos + (uint32_t)i >= to;                /* (SQC_SKIP cannot occur: SQ_IGNORE is not served) */
-            if (!done) {
-               q = tab[q * 8u + cls];
-               acc |= masks[q];
+            stop = stop || pos + (uint32_t)i >= to;
+            done = done || (!stop && cls[i] >= 5u);                             /* a terminator INSIDE the window ends the line (SQC_SKIP cannot occur: SQ_IGNORE is not served) */
+            const bool off_ = done || stop;
+            if (INLDS) {
+               const uint32_t nq = (uint32_t)*reinterpret_cast<const uint16_t *>(ms_tab + q + 2u * (cls[i] & 7u)) << 4;
+               q = off_ ? q : nq;
+               const uint32_t mk = *reinterpret_cast<const uint32_t *>(ms_tab + (size_t)a.res_states * 16 + (q >> 2));
+               acc |= off_ ? 0u : mk;
+            } else if (!off_) {
+               q = a.res_next[q * 8u + cls[i]];
+               acc |= a.res_mask[q];
             }
          }
+         pos = stop ? to : pos + 16u;
       }
       a.lmask[k] = acc;
       a.lfirst[k] = all ? 0u : col;                       /* (column 0: k_exact1 starts at the line's first byte) */
@@ -102,22 +131,33 @@ __global__ __launch_bounds__(256) void k_multi_resolve(MultiArgs a)
    }
 }
 
-/* bit y of the sets, summed per block of MULTI_BLOCK entries */
+/* A wave's pattern counts over its 512 lines: lane p ends up with the number of lines whose set holds pattern p. */
+__device__ __forceinline__ uint32_t multi_wave_counts(const MultiArgs &a, uint32_t wbase, uint32_t nhl, uint32_t lane)
+{
+   uint32_t mine = 0;
+   for (int r = 0; r < MULTI_ITEMS; r++) {
+      const uint32_t i = wbase + (uint32_t)r * 64u + lane;
+      const uint32_t mk = i < nhl ? a.lmask[i] : 0u;
+      for (uint32_t p = 0; p < a.npat; p++) {
+         const uint32_t n = (uint32_t)__popcll(__ballot((mk >> p) & 1u));
+         mine += lane == p ? n : 0u;
+      }
+   }
+   return mine;
+}
+
+/* per workgroup of 2048 lines: how many of them hold pattern p -> bsum[p][workgroup], every pattern in one pass */
 __global__ __launch_bounds__(256) void k_multi_reduce(MultiArgs a)
 {
-   __shared__ uint32_t s_wave[4];
+   __shared__ uint32_t s_cnt[4][SEEQ_MULTI_MAX];
    const uint32_t nhl = a.ucnt->seg_nhitlines;
-   const uint32_t y = blockIdx.y, base = blockIdx.x * MULTI_BLOCK;
-   if (base >= nhl) return;                                /* (the grid is sized for the workspace; k_multi_top reads the blocks below nhl only) */
-   uint32_t v = 0;
-#pragma unroll
-   for (int k = 0; k < MULTI_ITEMS; k++) {
-      const uint32_t i = base + threadIdx.x * MULTI_ITEMS + k;
-      if (i < nhl) v += (a.lmask[i] >> y) & 1u;
-   }
-   uint32_t tot;
-   block_excl_scan(v, &tot, s_wave);
-   if (threadIdx.x == 0) a.bsum[y * a.nb + blockIdx.x] = tot;
+   const uint32_t base = blockIdx.x * MULTI_BLOCK;
+   if (base >= nhl) return;                                /* (the grid is sized for the workspace; k_multi_top reads the workgroups below nhl only) */
+   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const uint32_t mine = multi_wave_counts(a, base + wave * 64u * MULTI_ITEMS, nhl, lane);
+   if (lane < SEEQ_MULTI_MAX) s_cnt[wave][lane] = mine;
+   __syncthreads();
+   if (threadIdx.x < a.npat) a.bsum[threadIdx.x * a.nb + blockIdx.x] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
 }
 
 /* per pattern (blockIdx.x): exclusive scan of its block sums; its Counters for this segment */
@@ -142,8 +182,8 @@ __global__ __launch_bounds__(256) void k_multi_top(MultiArgs a)
       Counters *pc = a.pcnt + y;
       const Counters *u = a.ucnt;
       uint32_t n = running;
-      if (n > pc->need_hitlines) pc->need_hitlines = n;
-      if (n > a.capP) { pc->overflow |= 2u; n = 0; }
+      if (!a.trust && n > pc->need_hitlines) pc->need_hitlines = n;
+      if (!a.trust && n > a.capP) { pc->overflow |= 2u; n = 0; }
       if (pc->overflow & 2u) n = 0;
       pc->seg_nhitlines = n;
       pc->seg_nlines = u->seg_nlines;
@@ -151,41 +191,48 @@ __global__ __launch_bounds__(256) void k_multi_top(MultiArgs a)
       pc->seg_nrec = 0; pc->seg_nmatch = 0; pc->seg_novf = 0;
       pc->dirty = u->dirty;
       pc->seg_last_nl = u->seg_last_nl;
+      if (a.trust) {                                       /* what k_seg_end books behind an exact pass of 0 / 1 verdicts */
+         pc->lines += u->seg_nlines - u->seg_nheaders;
+         pc->headers += u->seg_nheaders;
+         pc->matchlines += running;
+         pc->hits += running;
+         pc->seg_nhitlines = 0;
+      }
    }
 }
 
-/* the (line, pattern) pairs of pattern y into its region, in line order */
+/* the (line, pattern) pairs into the patterns' regions, in line order: a wave walks its 512 lines 64 at a time; per pattern
+   present in the round one ballot gives the ranks, lane p carries pattern p's running position */
 __global__ __launch_bounds__(256) void k_multi_apply(MultiArgs a)
 {
-   __shared__ uint32_t s_wave[4];
+   __shared__ uint32_t s_cnt[4][SEEQ_MULTI_MAX];
    const uint32_t nhl = a.ucnt->seg_nhitlines;
-   const uint32_t y = blockIdx.y, base = blockIdx.x * MULTI_BLOCK;
-   const Counters *pc = a.pcnt + y;
+   const uint32_t base = blockIdx.x * MULTI_BLOCK;
    if (base >= nhl) return;
-   uint32_t item[MULTI_ITEMS];
-   uint32_t v = 0;
-#pragma unroll
-   for (int k = 0; k < MULTI_ITEMS; k++) {
-      const uint32_t i = base + threadIdx.x * MULTI_ITEMS + k;
-      item[k] = i < nhl ? (a.lmask[i] >> y) & 1u : 0u;
-      v += item[k];
+   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const uint32_t wbase = base + wave * 64u * MULTI_ITEMS;
+   const uint32_t mine = multi_wave_counts(a, wbase, nhl, lane);
+   if (lane < SEEQ_MULTI_MAX) s_cnt[wave][lane] = mine;
+   __syncthreads();
+   uint32_t mybase = 0;                                    /* lane p: position of this wave's next pair of pattern p inside region p */
+   bool room = true;
+   if (lane < a.npat) {
+      mybase = a.bsum[lane * a.nb + blockIdx.x];
+      for (uint32_t w = 0; w < wave; w++) mybase += s_cnt[w][lane];
+      room = !(a.pcnt[lane].overflow & 2u);                /* the region is too small: the scan is run again */
    }
-   uint32_t tot;
-   uint32_t ex = block_excl_scan(v, &tot, s_wave) + a.bsum[y * a.nb + blockIdx.x];
-   if (pc->overflow & 2u) return;                          /* the region is too small: the scan is run again */
-   const size_t r0 = (size_t)y * a.capP;
-#pragma unroll
-   for (int k = 0; k < MULTI_ITEMS; k++) {
-      if (item[k]) {
-         const uint32_t i = base + threadIdx.x * MULTI_ITEMS + k;
-         const uint32_t last = a.llast[i];
-         a.p_start[r0 + ex] = a.hit_start[i];
-         a.p_line[r0 + ex] = a.hit_line[i];
-         a.p_col[r0 + ex] = a.lfirst[i];
-         /* k_exact1 ends the scan at last + m + tau + 2: the union window ends at last candidate + maxspan + 2 */
-         a.p_last[r0 + ex] = last == 0xFFFFFFFFu ? 0u : last + a.maxspan - a.span[y];
-         a.p_nh[r0 + ex] = last == 0xFFFFFFFFu ? 2u : 0u;            /* bit 1: no window end (k_exact1 scans to the end of the line) */
-         ex++;
+   for (int r = 0; r < MULTI_ITEMS; r++) {
+      const uint32_t i = wbase + (uint32_t)r * 64u + lane;
+      const uint32_t mk = i < nhl ? a.lmask[i] : 0u;
+      if (__ballot(mk != 0u) == 0ull) continue;
+      for (uint32_t p = 0; p < a.npat; p++) {
+         const bool has = (mk >> p) & 1u;
+         const uint64_t bal = __ballot(has);
+         if (bal == 0ull) continue;
+         const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)mybase, (int)p);
+         const bool ok = __builtin_amdgcn_readlane((int)(room ? 1 : 0), (int)p) != 0;
+         if (has && ok) a.p_idx[(size_t)p * a.capP + b0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
+         mybase += lane == p ? (uint32_t)__popcll(bal) : 0u;
       }
    }
 }

@@ -183,7 +183,7 @@ class Scanner:
 
 
     # ---- several patterns, one text (include/seeq_amd.h: seeqdevScanRunMulti / seeqdevScanHostMulti) ----
-    def _multi(self, patterns, call, want):
+    def _multi(self, patterns, call, want, copy=True):
         n = len(patterns)
         arr = (C.c_void_p * n)(*[C.cast(p.handle, C.c_void_p) for p in patterns])
         cnts = (_capi.seeqdev_counts_t * n)()
@@ -195,9 +195,15 @@ class Scanner:
             if want == WANT_RECORDS:
                 ptr, m = C.c_void_p(), C.c_size_t()
                 _check(self._lib.seeqdevScanMultiRecords(self._h, k, C.byref(ptr), C.byref(m)))
-                rec = np.zeros((m.value, 4), dtype=np.uint32)
-                if m.value:
-                    C.memmove(rec.ctypes.data, ptr.value, m.value * 16)
+                if copy:
+                    rec = np.zeros((m.value, 4), dtype=np.uint32)
+                    if m.value:
+                        C.memmove(rec.ctypes.data, ptr.value, m.value * 16)
+                elif m.value:
+                    # a view of the context's page-locked buffer: valid until the next multi scan of this Scanner
+                    rec = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(m.value, 4))
+                else:
+                    rec = np.zeros((0, 4), dtype=np.uint32)
                 res["records"] = rec
             out.append(res)
         return out
@@ -206,14 +212,15 @@ class Scanner:
         """True when the last multi-pattern scan walked the text once for all its patterns (seeq_multi.h)."""
         return bool(self._lib.seeqdevScanLastMulti(self._h))
 
-    def scan_host_multi(self, patterns, data, options=0, want=WANT_COUNTLINES):
-        """data: bytes, staged ONCE; every pattern gets its own scan over it.  -> one result dict per pattern."""
-        return self._multi(patterns, lambda arr, n, cnts: self._lib.seeqdevScanHostMulti(self._h, arr, n, data, len(data), options, want, cnts), want)
+    def scan_host_multi(self, patterns, data, options=0, want=WANT_COUNTLINES, copy=True):
+        """data: bytes, staged ONCE.  -> one result dict per pattern (copy=False: records are views of the Scanner's buffer,
+        valid until its next multi scan)."""
+        return self._multi(patterns, lambda arr, n, cnts: self._lib.seeqdevScanHostMulti(self._h, arr, n, data, len(data), options, want, cnts), want, copy)
 
-    def scan_tensor_multi(self, patterns, t, options=0, want=WANT_COUNTLINES):
-        """t: torch uint8 CUDA tensor (contiguous), resident.  -> one result dict per pattern."""
+    def scan_tensor_multi(self, patterns, t, options=0, want=WANT_COUNTLINES, copy=True):
+        """t: torch uint8 CUDA tensor (contiguous), resident.  -> one result dict per pattern (copy: see scan_host_multi)."""
         return self._multi(patterns, lambda arr, n, cnts: self._lib.seeqdevScanRunMulti(self._h, arr, n, C.c_void_p(t.data_ptr()), t.numel(),
-                                                                                     options, want, cnts), want)
+                                                                                     options, want, cnts), want, copy)
 
 
 def assign_best(results, nlines):
