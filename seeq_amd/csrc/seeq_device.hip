@@ -1858,9 +1858,12 @@ static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
    {
       const size_t blocks = (s->cap_hitlines + MULTI_RESOLVE_WG - 1) / MULTI_RESOLVE_WG;
       const unsigned grid = (unsigned)(blocks < (size_t)s->ncu * 2 ? blocks : (size_t)s->ncu * 2);      /* persistent: the table is staged once per workgroup */
-      const size_t lds = (size_t)mp->res_states * 20;
-      if (lds <= 65536) hipLaunchKernelGGL(k_multi_resolve<true>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds, st, m);
-      else hipLaunchKernelGGL(k_multi_resolve<false>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), 0, st, m);
+      HIP_TRY(hipMemsetAsync(s->ml_mask, 0, s->cap_hitlines * sizeof(uint32_t), st), EIO);      /* the lanes of a line's entries OR / MAX into them */
+      HIP_TRY(hipMemsetAsync(s->ml_last, 0, s->cap_hitlines * sizeof(uint32_t), st), EIO);
+      const size_t lds2 = (size_t)mp->res_states * 20, lds1 = (size_t)mp->res_states * 16;
+      if (lds2 <= 65536) hipLaunchKernelGGL(k_multi_resolve<2>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds2, st, m);
+      else if (lds1 <= 65536) hipLaunchKernelGGL(k_multi_resolve<1>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds1, st, m);
+      else hipLaunchKernelGGL(k_multi_resolve<0>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), 0, st, m);
       hipLaunchKernelGGL(k_multi_reduce, dim3(m.nb), dim3(256), 0, st, m);
       hipLaunchKernelGGL(k_multi_top, dim3((unsigned)npat), dim3(256), 0, st, m);
       if (trust) { HIP_TRY(hipGetLastError(), EIO); return 0; }

@@ -592,15 +592,31 @@ static inline seeq_multi_t *seeq_multi_build(const char *const *keys, const int 
       if (!d->pair && at_floor) break;
    }
    if (d->pair) {
+      /* the resolve automaton is not bound by the pair table's 2 047 rows: whole patterns when that stays below 65 536
+         states (its sets are exact then), else the prefixes of the union walk */
       uint32_t *next = NULL, *mask = NULL;
-      const uint32_t n = seeq_dfa_bfs_parts_ex(cat, cut, npat, tau, 0, 65535, &next, &mask);
+      uint32_t n = 0;
+      int whole = 1;
+      for (int p = 0; p < npat; p++) if (d->lp[p] != m[p]) whole = 0;
+      if (!whole) {
+         char *full = (char *)malloc((size_t)total);
+         int fcut[SEEQ_MULTI_MAX_PARTS + 1];
+         if (full) {
+            int o = 0;
+            for (int p = 0; p < npat; p++) { fcut[p] = o; memcpy(full + o, keys[p], (size_t)m[p]); o += m[p]; }
+            fcut[npat] = o;
+            n = seeq_dfa_bfs_parts_ex(full, fcut, npat, tau, 0, 65535, &next, &mask);
+            if (n) whole = 1;
+            free(full);
+         }
+      }
+      if (!n) n = seeq_dfa_bfs_parts_ex(cat, cut, npat, tau, 0, 65535, &next, &mask);
       if (n) {
          d->res_next = (uint16_t *)calloc((size_t)n * 8, sizeof(uint16_t));
          if (d->res_next) {
             for (uint32_t q = 0; q < n; q++) for (int c = 0; c < 5; c++) d->res_next[(size_t)q * 8 + c] = (uint16_t)next[(size_t)q * 5 + c];
             d->res_states = n; d->res_mask = mask; mask = NULL;
-            d->res_exact = 1;
-            for (int p = 0; p < npat; p++) if (d->lp[p] != m[p]) d->res_exact = 0;
+            d->res_exact = whole;
          }
       }
       free(next); free(mask);

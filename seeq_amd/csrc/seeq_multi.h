@@ -52,8 +52,9 @@ static constexpr int MULTI_ITEMS = 8;                      /* rounds of 64 lines
 static constexpr int MULTI_BLOCK = 256 * MULTI_ITEMS;      /* lines per workgroup of the split kernels: wave w owns lines [512 w, 512 w + 512) of them */
 static constexpr int MULTI_RESOLVE_WG = 1024;              /* the table is staged once per workgroup: large workgroups, full occupancy */
 
-/* INLDS: the resolve table and the masks are staged in LDS (res_states * 20 bytes) */
-template <bool INLDS>
+/* INLDS 2: the resolve table and the masks are staged in LDS (res_states * 20 bytes); 1: the table only (* 16 bytes), the
+   masks are read through L2 (off the chain of the walk); 0: both through L2 */
+template <int INLDS>
 __global__ __launch_bounds__(MULTI_RESOLVE_WG) void k_multi_resolve(MultiArgs a)
 {
    extern __shared__ __align__(16) uint8_t ms_tab[];
@@ -62,8 +63,10 @@ __global__ __launch_bounds__(MULTI_RESOLVE_WG) void k_multi_resolve(MultiArgs a)
    if (INLDS) {                                           /* the table, then the masks */
       const fused_v4u *src = reinterpret_cast<const fused_v4u *>(a.res_next);
       for (uint32_t i = threadIdx.x; i < a.res_states; i += MULTI_RESOLVE_WG) reinterpret_cast<fused_v4u *>(ms_tab)[i] = src[i];
-      uint32_t *mk = reinterpret_cast<uint32_t *>(ms_tab + (size_t)a.res_states * 16);
-      for (uint32_t i = threadIdx.x; i < a.res_states; i += MULTI_RESOLVE_WG) mk[i] = a.res_mask[i];
+      if (INLDS == 2) {
+         uint32_t *mk = reinterpret_cast<uint32_t *>(ms_tab + (size_t)a.res_states * 16);
+         for (uint32_t i = threadIdx.x; i < a.res_states; i += MULTI_RESOLVE_WG) mk[i] = a.res_mask[i];
+      }
    }
    __syncthreads();
    const Counters *c = a.ucnt;
@@ -71,63 +74,68 @@ __global__ __launch_bounds__(MULTI_RESOLVE_WG) void k_multi_resolve(MultiArgs a)
    const bool whole = !a.window_ok || c->dirty != 0;      /* no windows: every candidate line from its first byte to its end */
    const uint32_t stride = gridDim.x * MULTI_RESOLVE_WG;
    for (uint32_t k = blockIdx.x * MULTI_RESOLVE_WG + threadIdx.x; k < nhl; k += stride) {
-      const uint32_t hs = a.hit_start[k];
-      if (hs == 0xFFFFFFFFu) { a.lmask[k] = 0u; continue; }      /* a repeat: its line's first entry speaks for it */
-      const uint32_t col = a.hit_col[k];
+      /* One lane per ENTRY of the list -- a line's first candidate or a repeat: every occurrence of a pattern lies within
+         maxspan of ITS candidate (seeq_dfa.h section 4), so each lane walks [c - maxspan, c + maxspan + 2) of its own
+         candidate c from the root and ORs what it finds into the line's set.  k_pair lists the FIRST and the LAST candidate
+         of a chain (64 bytes of text): an entry in the chain of the entry before it starts where that one starts, the
+         stretch between them may hold unlisted candidates.  (A lane per LINE walking from its first candidate to its last
+         held its wave for ten blocks of text where a read had a barcode in front and a chance candidate at its end: 0.85 ms
+         per 10 M reads; a lane per line jumping from window to window: 0.67 ms, the wave still waits for its longest line.) */
+      uint32_t hs = a.hit_start[k];
+      uint32_t f = k;                                      /* the line's first entry */
+      const bool repeat = hs == 0xFFFFFFFFu;
+      if (repeat) {
+         if (whole) continue;                              /* the first entry's lane walks the whole line */
+         while (f > 0 && hs == 0xFFFFFFFFu) hs = a.hit_start[--f];
+         if (hs == 0xFFFFFFFFu) continue;                  /* the line's first candidate belongs to the segment before this one (the run is void: overflow 128) */
+      }
+      const uint32_t c = repeat ? a.hit_col[k] - hs : a.hit_col[k];
       const uint64_t off = a.seg_base + hs;
-      if ((a.options & SEEQDEV_FASTA) && a.text[off] == '>') { a.lmask[k] = 0u; continue; }      /* a candidate inside a FASTA header */
-      /* the line's candidates: this entry and the repeats behind it.  Every occurrence of a pattern lies within maxspan of
-         ITS candidate (seeq_dfa.h section 4), so the walk covers [c - maxspan, c + maxspan + 2) of every candidate c --
-         windows that touch (or lie in one chain of k_pair) are walked through, a gap is jumped with a fresh start at the root.  (One window from the first
-         candidate to the last: a read with a barcode in front and a chance candidate at its end held its whole wave for
-         ten blocks of text instead of two -- 0.85 ms per 10 M reads against 0.4.) */
-      uint32_t lastcol = col, unbounded = a.nh[k] & 2u;
-      uint32_t jn = k + 1;                                 /* next entry of the list to look at */
-      bool all = whole || unbounded != 0;
-      uint32_t pos = (all || col <= a.maxspan) ? 0u : col - a.maxspan;
-      uint32_t to = all ? 0xFFFFFFFFu : col + a.maxspan + 2u;
+      if ((a.options & SEEQDEV_FASTA) && a.text[off] == '>') continue;      /* a candidate inside a FASTA header */
+      bool all = whole;
+      if (!repeat) {
+         a.lfirst[k] = c;
+         uint32_t unbounded = a.nh[k] & 2u;                /* a chain dropped candidates of this line: the whole line */
+         for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) unbounded |= a.nh[j] & 2u;
+         all = all || unbounded != 0;
+         if (all) { a.lfirst[k] = 0u; atomicMax(&a.llast[k], 0xFFFFFFFFu); }      /* (column 0: k_exact1 starts at the line's first byte and scans to its end) */
+      }
+      uint32_t from = c;
+      if (k > f) {                                         /* same chain as the entry before: from its window's start */
+         const uint32_t pc = k - 1 == f ? a.hit_col[f] : a.hit_col[k - 1] - hs;
+         if (((hs + pc) >> 6) == ((hs + c) >> 6)) from = pc;
+      }
+      uint32_t pos = (all || from <= a.maxspan) ? 0u : from - a.maxspan;
+      const uint32_t to = all ? 0xFFFFFFFFu : c + a.maxspan + 2u;
       uint32_t q = 0, acc = 0;                             /* q: INLDS the byte offset of the state's row, else the state */
       bool done = false;
-      while (!done) {
-         if (pos >= to) {                                  /* the window is walked: the next candidate of the line */
-            if (!(jn < nhl && a.hit_start[jn] == 0xFFFFFFFFu)) break;
-            const uint32_t c = a.hit_col[jn] - hs;
-            if (a.nh[jn] & 2u) { all = true; pos = 0; to = 0xFFFFFFFFu; q = 0; acc = 0; jn = nhl; continue; }      /* a chain dropped candidates: the whole line */
-            jn++;
-            /* k_pair lists the FIRST and the LAST candidate of a chain (64 bytes of text): two entries of one chain may have
-               unlisted candidates between them -- that stretch is walked through; between two chains there are none */
-            const bool same_chain = ((hs + c) >> 6) == ((hs + lastcol) >> 6);
-            lastcol = c;
-            if (!same_chain && c > pos + a.maxspan) { pos = c - a.maxspan; q = 0; }
-            to = c + a.maxspan + 2u;
-            continue;
-         }
+      while (!done && pos < to) {
          const fused_v4u v = direct_load16(a.text, off + pos, a.nbytes);       /* (bytes beyond the buffer read as NUL: a terminator) */
          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
          uint32_t cls[16];
 #pragma unroll
          for (int i = 0; i < 16; i++) cls[i] = s_cls[(w[i >> 2] >> (8 * (i & 3))) & 0xFFu];      /* (off the chain of the walk: all sixteen go out together) */
-         bool stop = false;                                /* this window ends inside the block */
 #pragma unroll
          for (int i = 0; i < 16; i++) {
-            stop = stop || pos + (uint32_t)i >= to;
-            done = done || (!stop && cls[i] >= 5u);                             /* a terminator INSIDE the window ends the line (SQC_SKIP cannot occur: SQ_IGNORE is not served) */
-            const bool off_ = done || stop;
+            done = done || cls[i] >= 5u || pos + (uint32_t)i >= to;             /* a terminator ends the line (SQC_SKIP cannot occur: SQ_IGNORE is not served) */
             if (INLDS) {
                const uint32_t nq = (uint32_t)*reinterpret_cast<const uint16_t *>(ms_tab + q + 2u * (cls[i] & 7u)) << 4;
-               q = off_ ? q : nq;
-               const uint32_t mk = *reinterpret_cast<const uint32_t *>(ms_tab + (size_t)a.res_states * 16 + (q >> 2));
-               acc |= off_ ? 0u : mk;
-            } else if (!off_) {
+               q = done ? q : nq;
+               if (INLDS == 2) {
+                  const uint32_t mk = *reinterpret_cast<const uint32_t *>(ms_tab + (size_t)a.res_states * 16 + (q >> 2));
+                  acc |= done ? 0u : mk;
+               } else if (!done) {
+                  acc |= a.res_mask[q >> 4];
+               }
+            } else if (!done) {
                q = a.res_next[q * 8u + cls[i]];
                acc |= a.res_mask[q];
             }
          }
-         pos = stop ? to : pos + 16u;
+         pos += 16u;
       }
-      a.lmask[k] = acc;
-      a.lfirst[k] = all ? 0u : col;                       /* (column 0: k_exact1 starts at the line's first byte) */
-      a.llast[k] = all ? 0xFFFFFFFFu : lastcol;
+      if (acc) atomicOr(&a.lmask[f], acc);                 /* (lmask[] and llast[] are zeroed before the launch) */
+      if (!all) atomicMax(&a.llast[f], c);
    }
 }
 
