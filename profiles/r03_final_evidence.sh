@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round 3, final evidence of the committed build: the four bench lines, rocprofv3 kernel stats + PMC passes of the headline
+# workload and of cfg5, the PMC traffic file bench.py ties to the build, the multi-pattern and packed-batch figures.
+# Usage: bash profiles/r03_final_evidence.sh [bench|profile|pmc|all] (a gpurun call is at most 20 minutes: one part per call).
+# Outputs land under gpurun_out/r03final/ and gpurun_out/prof_r03_final_*; the summaries are copied into profiles/ afterwards.
+set -u
+PART=${1:-all}
+O=gpurun_out/r03final; mkdir -p $O
+export TMPDIR=/tmp
+if [ $PART = all ] || [ $PART = bench ]; then
+timeout -k 10 400 python bench.py > $O/bench_best.json 2> $O/bench_best.err; echo "best exit $?"
+timeout -k 10 200 python bench.py --workload count --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed > $O/bench_count.json 2> $O/bench_count.err; echo "count exit $?"
+timeout -k 10 200 python bench.py --workload all --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed > $O/bench_all.json 2> $O/bench_all.err; echo "all exit $?"
+timeout -k 10 400 python bench.py --workload cfg5 --steps 20 --warmup 3 --no-e2e --no-per-call --no-cli --no-packed > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo "cfg5 exit $?"
+for f in $O/bench_*.json; do python3 - "$f" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+print(sys.argv[1], round(d["value"]/1e9,3), "G lines/s", round(d["ms_per_step"],3), "ms", d["device_ms_per_step"], d["roofline"]["kernel"], round(d["roofline"]["avg_launch_ms"],4), round(d["roofline"]["frac"],3), d["results"].get("oracle_check",{}).get("result"), (d.get("cpu_baseline") or {}).get("value"))
+PY
+done
+timeout -k 10 600 python3 profiles/multi_bench.py 10000000 > $O/multi.jsonl 2> $O/multi.err; echo "multi exit $?"
+fi
+if [ $PART = all ] || [ $PART = profile ]; then
+TEXT_BYTES_TOTAL=60400000000 timeout -k 10 500 bash profiles/gpu_profile.sh r03_final_best --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --check-lines 0 > $O/profile_best.log 2>&1; echo "profile best exit $?"
+TEXT_BYTES_TOTAL=100400000000 timeout -k 10 500 bash profiles/gpu_profile.sh r03_final_cfg5 --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --check-lines 0 > $O/profile_cfg5.log 2>&1; echo "profile cfg5 exit $?"
+find gpurun_out/prof_r03_final_best gpurun_out/prof_r03_final_cfg5 -name "*.csv" -size +2M -delete
+head -30 gpurun_out/prof_r03_final_best/summary.txt
+fi
+if [ $PART = all ] || [ $PART = pmc ]; then
+timeout -k 10 500 bash profiles/pmc_traffic.sh r03final_pmc > $O/pmc_traffic.log 2>&1; echo "pmc traffic exit $?"; tail -30 $O/pmc_traffic.log
+fi

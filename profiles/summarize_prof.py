@@ -33,7 +33,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_sq2"):
             k = r.get("Kernel_Name", "")[:48]
             agg[k][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
 for k in sorted(agg):
-    if not any(s in k for s in ("k_forward", "k_nl_", "k_exact", "k_fused", "k_direct", "k_scan", "k_compact", "k_stream", "k_dfa")):
+    if not any(s in k for s in ("k_forward", "k_nl_", "k_exact", "k_fused", "k_direct", "k_scan", "k_compact", "k_stream", "k_dfa", "k_pair", "k_packed", "k_multi")):
         continue
     print(k)
     for c in sorted(agg[k]):
@@ -45,7 +45,7 @@ for k in sorted(agg):
 # (16 B/lane) streaming read, so it is doubled.  The counters sit on the L2's fabric side, so
 # Infinity-Cache hits are included.
 import json
-scan = [k for k in agg if ("k_direct" in k or "k_fused<" in k or "k_forward" in k or "k_stream<" in k or "k_dfa" in k)
+scan = [k for k in agg if ("k_direct" in k or "k_fused<" in k or "k_forward" in k or "k_stream<" in k or "k_dfa" in k or "k_pair<" in k)
         and "FETCH_SIZE" in agg[k]]
 if scan:
     k = max(scan, key=lambda x: sum(agg[x]["FETCH_SIZE"]))
