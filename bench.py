@@ -631,7 +631,7 @@ def main():
                         "HBM stream time: see DESIGN.md",
             "k_pair": "line-agnostic table walk, TWO text bytes per LDS gather (pair automaton of the pattern's longest prefix that fits / "
                       "a partition filter; every hit line a candidate, verified by the exact pass): 0.66 gathers per text byte; no longer held "
-                      "by the LDS unit (57 % busy) -- without its bookkeeping it runs at 6.2 TB/s, what a plain read sweep reaches here; "
+                      "by the LDS unit (60 % busy, VALU issue 40-60 %) -- without its bookkeeping it runs at 0.645 ms per launch, 7 % above what a plain read sweep of this layout takes (0.60 ms at 6.2 TB/s); the packed walk shows the LDS unit's own floor (0.57 ms); "
                       "PMC tables and the phase experiments: profiles/r03*, DESIGN.md section 5",
             "k_direct": "one-pass per-line scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte) and "
                         "on re-reading lines from L2: see DESIGN.md",
