@@ -121,3 +121,29 @@ def test_match_stack_utilities_vs_reference_vectors(capi):
         assert merged == c["merged"] and left == c["left"], c
         nm += len(merged)
     assert nm > 1000
+
+
+def test_pack_reads_layout_on_the_host(capi):
+    """seeqdevPackReads needs no GPU: the packed layout of include/seeq_amd.h bit by bit -- four bases per byte, the first in
+    bits 7-6, code = (ASCII >> 1) & 3 (A 0, C 1, T/U 2, G 3), N through the mask (first base of a byte = bit 7), either case;
+    the error returns."""
+    import ctypes as C
+    import numpy as np
+    L = C.CDLL(capi.LIB_PATH)
+    L.seeqdevPackReads.restype = C.c_long
+    L.seeqdevPackReads.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    text = b"ACGTN\nacgun\nTTTTT"                       # no newline behind the last read
+    bases = np.zeros(3 * 2, dtype=np.uint8); nmask = np.zeros(3, dtype=np.uint8)
+    assert L.seeqdevPackReads(text, len(text), 5, bases.ctypes.data, nmask.ctypes.data, 2, 1) == 3
+    code = {"A": 0, "C": 1, "T": 2, "U": 2, "G": 3}
+    for r, line in enumerate(["ACGTN", "ACGUN", "TTTTT"]):
+        for i, ch in enumerate(line):
+            got = (int(bases[2 * r + i // 4]) >> (6 - 2 * (i % 4))) & 3
+            isn = (int(nmask[r]) >> (7 - i)) & 1
+            assert isn == (ch == "N"), (r, i)
+            if ch != "N":
+                assert got == code[ch], (r, i)
+    assert L.seeqdevPackReads(b"ACGT\nACG\n", 9, 4, bases.ctypes.data, nmask.ctypes.data, 1, 1) == -1      # a line of another length
+    assert L.seeqdevPackReads(b"ACXT\n", 5, 4, bases.ctypes.data, nmask.ctypes.data, 1, 1) == -1           # not a base
+    assert L.seeqdevPackReads(b"ACNT\n", 5, 4, bases.ctypes.data, None, 1, 0) == -1                        # an N and no mask
+    assert L.seeqdevPackReads(b"", 0, 4, bases.ctypes.data, nmask.ctypes.data, 1, 1) == 0

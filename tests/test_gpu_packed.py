@@ -92,3 +92,76 @@ def test_packed_every_read_a_candidate_and_no_nmask(gpu, capi, oracle):
     with pytest.raises(dev.SeeqDeviceError):
         dev.pack_reads(b"ACGT\nACG\n", 4)                     # a line of another length
     pat.close()
+
+
+def test_pack_on_device_equals_host_packer_and_padded_strides(gpu, capi, oracle):
+    """seeqdevPackReadsDevice against seeqdevPackReads byte for byte; a batch whose strides are larger than they need to be
+    (reads padded to 16 bytes, masks to 8) gives the same records."""
+    import torch
+    from seeq_amd import device as dev
+    rng = random.Random(77)
+    for L in (1, 5, 8, 33, 150, 255):
+        lines = ["".join(rng.choice("ACGTN" if rng.random() < 0.1 else "ACGT") for _ in range(L)) for _ in range(1000)]
+        text = ("\n".join(lines) + "\n").encode()
+        bases, nmask, n = dev.pack_reads(text, L)
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+        db = torch.zeros(n * ((L + 3) // 4), dtype=torch.uint8, device="cuda:0")
+        dn = torch.zeros(n * ((L + 7) // 8), dtype=torch.uint8, device="cuda:0")
+        dev.pack_reads_device(t.data_ptr(), n, L, db.data_ptr(), dn.data_ptr())
+        torch.cuda.synchronize()
+        tail = (1 << (2 * ((4 - L % 4) % 4))) - 1                     # padding bits of a read's last byte are unspecified
+        hb, gb = bases.reshape(n, -1).copy(), db.cpu().numpy().reshape(n, -1).copy()
+        hb[:, -1] &= 0xFF ^ tail; gb[:, -1] &= 0xFF ^ tail
+        assert np.array_equal(hb, gb), L
+        ntail = (1 << ((8 - L % 8) % 8)) - 1
+        hn, gn = nmask.reshape(n, -1).copy(), dn.cpu().numpy().reshape(n, -1).copy()
+        hn[:, -1] &= 0xFF ^ ntail; gn[:, -1] &= 0xFF ^ ntail
+        assert np.array_equal(hn, gn), L
+    # padded strides
+    pattern, tau, L = "GATTAGCCTG", 1, 50
+    lines = []
+    for i in range(5000):
+        t_ = "".join(rng.choice("ACGT") for _ in range(L))
+        if i % 4 == 0:
+            q = rng.randrange(L - len(pattern) + 1); t_ = t_[:q] + pattern + t_[q + len(pattern):]
+        if i % 13 == 0:
+            q = rng.randrange(L); t_ = t_[:q] + "N" + t_[q + 1:]
+        lines.append(t_)
+    text = ("\n".join(lines) + "\n").encode()
+    bases, nmask, n = dev.pack_reads(text, L)
+    stride, nstride = 16, 8
+    pb = np.full((n, stride), 0xA5, dtype=np.uint8); pb[:, :(L + 3) // 4] = bases.reshape(n, -1)
+    pn = np.full((n, nstride), 0x5A, dtype=np.uint8); pn[:, :(L + 7) // 8] = nmask.reshape(n, -1)
+    db, dn = torch.from_numpy(pb.reshape(-1)).cuda(), torch.from_numpy(pn.reshape(-1)).cuda()
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner()
+    sc.run_packed(pat, db.data_ptr(), dn.data_ptr(), n, L, stride=stride, nstride=nstride, options=SQ_ALL, want=dev.WANT_RECORDS)
+    cnt = sc.fetch()
+    exp = oracle.buffer_scan(pattern, tau, text, SQ_ALL)
+    assert cnt["nmatchlines"] == exp["nmatchlines"] and np.array_equal(sc.records(cnt["nrecords"]).astype(np.uint64), exp["records"])
+    sc.close(); pat.close()
+
+
+def test_packed_two_segments_equal_the_ascii_scan(gpu, capi):
+    """More reads than one packed segment holds (16 Mi): 20 M reads of 24 bases, the packed scan against the ASCII scan of the
+    same reads on the GPU (the ASCII path is the one the oracle pins at this size elsewhere) -- counts and every record."""
+    import torch
+    from seeq_amd import device as dev
+    n, L = 20_000_000, 24
+    pattern, tau = "GATTAGCC", 1
+    stream = torch.cuda.current_stream().cuda_stream
+    text = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda:0")
+    dev.synth_reads(text.data_ptr(), 0, n, L, pattern, tau, stream=stream)
+    db = torch.empty(n * 6, dtype=torch.uint8, device="cuda:0"); dn = torch.empty(n * 3, dtype=torch.uint8, device="cuda:0")
+    dev.pack_reads_device(text.data_ptr(), n, L, db.data_ptr(), dn.data_ptr(), stream=stream)
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner(stream)
+    sc.run(pat, text.data_ptr(), text.numel(), SQ_BEST, dev.WANT_RECORDS)
+    a = sc.fetch(); ra = sc.records(a["nrecords"])
+    sc.run_packed(pat, db.data_ptr(), dn.data_ptr(), n, L, options=SQ_BEST, want=dev.WANT_RECORDS)
+    b = sc.fetch(); rb = sc.records(b["nrecords"])
+    assert sc.last_kernel() == "k_packed"
+    assert a == b and a["nlines"] == n and a["nmatchlines"] > n // 50
+    assert np.array_equal(ra, rb)
+    assert int(rb[:, 0].max()) > (1 << 24)                      # records of the second segment are there
+    sc.close(); pat.close()

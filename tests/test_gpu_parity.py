@@ -1315,3 +1315,63 @@ def test_multi_pattern_one_pass_equals_sequential(gpu, capi, oracle, case):
     code = MULTI16 % dict(root=ROOT, **{k: v for k, v in case.items() if k != "env"})
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **case["env"]), timeout=900)
     assert r.returncode == 0 and "MULTI OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_multi_pattern_edges_and_fallbacks(gpu, capi, oracle):
+    """The one-walk multi-pattern scan at its edges -- two patterns, thirty-two, classes and N, FASTA input with candidates in
+    header lines, empty lines, no newline at the end, a text of foreign bytes under SQ_FAIL -- and the sets / options it hands
+    to the per-pattern scans (a pattern shorter than d + 2, SQ_IGNORE, one pattern): always the oracle's results per pattern."""
+    from seeq_amd import device as dev
+    rng = random.Random(404)
+
+    def text_for(barcodes, taus, nlines, fasta=False, foreign=False, trailing=True):
+        lines = []
+        for i in range(nlines):
+            n = rng.choice([0, 0, 20, 80, 150, 151])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            for _ in range(rng.choice([0, 1, 2])):
+                k = rng.randrange(len(barcodes))
+                c = _mutate(rng, dev.plain_pattern(barcodes[k]).replace("N", "A"), rng.randint(0, taus[k] + 1))
+                if n >= len(c):
+                    q = rng.choice([0, n - len(c), rng.randrange(n - len(c) + 1)])
+                    t[q:q + len(c)] = list(c)
+            if foreign and rng.random() < 0.05 and n:
+                t[rng.randrange(n)] = rng.choice("!*XZ-.\t")
+            line = "".join(t)[:n]
+            if fasta and i % 5 == 0:
+                line = ">" + (dev.plain_pattern(barcodes[i % len(barcodes)]).replace("N", "A") + line)[:60]
+            lines.append(line)
+        return ("\n".join(lines) + ("\n" if trailing else "")).encode()
+
+    def check(barcodes, taus, buf, options=0, fasta=False, expect_one_pass=True):
+        pats = [dev.Pattern(b, t) for b, t in zip(barcodes, taus)]
+        sc = dev.Scanner()
+        fl = dev.SEEQDEV_FASTA if fasta else 0
+        for opt, want in ((SQ_BEST, dev.WANT_RECORDS), (SQ_ALL, dev.WANT_RECORDS), (0, dev.WANT_COUNTLINES), (0, dev.WANT_COUNTMATCH)):
+            got = sc.scan_host_multi(pats, buf, opt | options | fl, want)
+            assert sc.last_multi_one_pass() == expect_one_pass, (barcodes, opt, want)
+            for k, (b, t) in enumerate(zip(barcodes, taus)):
+                exp = oracle.buffer_scan(b, t, buf, (opt if want == dev.WANT_RECORDS else SQ_ALL) | options, fasta=fasta)
+                assert got[k]["nlines"] == exp["nlines"] and got[k]["nmatchlines"] == exp["nmatchlines"], (barcodes, k, opt, want)
+                if want == dev.WANT_RECORDS:
+                    assert np.array_equal(got[k]["records"].astype(np.uint64), exp["records"]), (barcodes, k, opt)
+                if want == dev.WANT_COUNTMATCH:
+                    assert got[k]["nhits"] == len(exp["records"]), (barcodes, k)
+        sc.close()
+        for p in pats:
+            p.close()
+
+    two = ["GATTACAGA", "TTGACCGAT"]
+    check(two, [1, 1], text_for(two, [1, 1], 3000))
+    check(two, [1, 1], text_for(two, [1, 1], 3000, trailing=False))
+    thirty_two = ["".join(rng.choice("ACGT") for _ in range(10)) for _ in range(32)]
+    check(thirty_two, [1] * 32, text_for(thirty_two, [1] * 32, 6000))
+    classes = ["AC[GT]TNGCAT", "TTGAC[AC]GANN", "GGCATTAC", "NNCAGTGT"]
+    check(classes, [1, 1, 0, 1], text_for(classes, [1, 1, 0, 1], 4000))
+    check(two, [1, 1], text_for(two, [1, 1], 3000, fasta=True), fasta=True)
+    check(two, [1, 1], text_for(two, [1, 1], 3000, foreign=True))                            # SQ_FAIL: a foreign byte ends its line
+    check(two, [1, 1], text_for(two, [1, 1], 3000, foreign=True), options=dev.SQ_CONVERT)
+    # what the one walk does not take: a scan per pattern, same results
+    check(two, [1, 1], text_for(two, [1, 1], 2000, foreign=True), options=dev.SQ_IGNORE, expect_one_pass=False)
+    check(["ACG", "GATTACAGA"], [2, 1], text_for(["ACG", "GATTACAGA"], [2, 1], 1500), expect_one_pass=False)     # shorter than d + 2
+    check(["GATTACAGA"], [1], text_for(["GATTACAGA"], [1], 1500), expect_one_pass=False)
