@@ -948,7 +948,7 @@ struct seeqdev_scan {
    Counters *d_mcnt, *h_mcnt;                             /* [SEEQ_MULTI_MAX], h_ pinned */
    int       last_multi;                                  /* the last multi scan: 1 = one walk for all patterns, 0 = a scan per pattern */
    /* packed read batches (seeqdevScanPacked) */
-   uint32_t *pk_cand, *pk_coff; uint64_t *pk_bmask; size_t cap_pk_reads;      /* candidate columns per read of a segment; per block of 64 reads: candidates before it, their mask */
+   uint32_t *pk_cand, *pk_slot, *pk_coff; uint64_t *pk_bmask; size_t cap_pk_reads;      /* candidate columns per read of a segment; per block of 64 reads: candidates before it, their mask */
    uint8_t  *pk_stage; size_t cap_pk_stage;               /* ASCII lines of the candidate reads */
    uint32_t *pk_last; size_t cap_pk_last;                 /* per candidate: column of its last candidate */
    bool      is_packed; seeqdev_packed_t packed;          /* the last run was a packed one (re-run on overflow) */
@@ -1049,7 +1049,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
       void *ob[] = {s->ow.tile_cl, s->ow.tile_hits, s->ow.tile_dirty, s->ow.tile_dmask, s->ow.tmp, s->ow.wg_hits, s->ow.wg_part, s->ow.wg_lastnl};
       for (void *b : ob) if (b) (void)hipFree(b);
    }
-   { void *pk[] = {s->pk_cand, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
+   { void *pk[] = {s->pk_cand, s->pk_slot, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
    { void *mw[] = {s->ml_mask, s->ml_first, s->ml_last, s->mp_idx, s->mp_nh, s->m_bsum, s->d_mcnt}; for (void *b : mw) if (b) (void)hipFree(b); }
    if (s->h_mcnt) (void)hipHostFree(s->h_mcnt);
    multi_plan_free(s->mplan);
@@ -1673,13 +1673,15 @@ static int run_packed(seeqdev_scan *s)
    const size_t seg_reads = b.nreads < PACKED_SEG_READS ? (size_t)b.nreads : PACKED_SEG_READS;
    if (seg_reads > s->cap_pk_reads) {
       if (ws_alloc((void **)&s->pk_cand, seg_reads * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->pk_slot, seg_reads * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->pk_coff, (seg_reads / 64 + 1) * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->pk_bmask, (seg_reads / 64 + 1) * sizeof(uint64_t))) return -1;
       s->cap_pk_reads = seg_reads;
    }
-   if (s->cap_hitlines * (size_t)(L + 1) > s->cap_pk_stage) {
-      if (ws_alloc((void **)&s->pk_stage, s->cap_hitlines * (size_t)(L + 1) + 64)) return -1;
-      s->cap_pk_stage = s->cap_hitlines * (size_t)(L + 1);
+   const uint32_t pitch = (L + 1u + 15u) & ~15u;            /* bytes per line of the staging text (L <= 256: the newline's word exists for every lane count up to 17; 16 lanes serve L <= 255, L = 256 below) */
+   if (s->cap_hitlines * (size_t)pitch > s->cap_pk_stage) {
+      if (ws_alloc((void **)&s->pk_stage, s->cap_hitlines * (size_t)pitch + 64)) return -1;
+      s->cap_pk_stage = s->cap_hitlines * (size_t)pitch;
    }
    if (s->cap_hitlines > s->cap_pk_last) {
       if (ws_alloc((void **)&s->pk_last, s->cap_hitlines * sizeof(uint32_t))) return -1;
@@ -1689,7 +1691,7 @@ static int run_packed(seeqdev_scan *s)
       const size_t nb = seg_reads / SCAN_BLOCK + 2;
       if (nb > s->cap_scan_ws) { if (ws_alloc((void **)&s->scan_ws, nb * sizeof(uint32_t))) return -1; s->cap_scan_ws = nb; }
    }
-   if (s->cap_hitlines * (uint64_t)(L + 1) > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
+   if (s->cap_hitlines * (uint64_t)pitch > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
    /* EQ tables of the exact pass (as run_segments makes them) */
    if (s->eq_pat_id != pat->id || s->eq_options != options) {
       const int Wp = pat->words;
@@ -1719,7 +1721,12 @@ static int run_packed(seeqdev_scan *s)
    const size_t dfa_lds = (size_t)pat->pair_units * 16;
    int per_cu = occupancy_of(s, (const void *)k_packed_walk, 64 * STREAM_NW, dfa_lds);
    if (per_cu < 0) return -1;
-   const unsigned wgrid = (unsigned)(s->ncu * per_cu);
+   /* persistent grid, but no more waves than blocks of 64 reads: every wave owns cap / waves lines of the staging text */
+   unsigned wgrid = (unsigned)(s->ncu * per_cu);
+   {
+      const size_t nblocks = (seg_reads + 63) / 64, need = (nblocks + STREAM_NW_HOST - 1) / STREAM_NW_HOST;
+      if (need < wgrid) wgrid = (unsigned)(need ? need : 1);
+   }
    const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
    unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 16 ? hit_blocks : (size_t)s->ncu * 16);
    if (grid_hits == 0) grid_hits = 1;
@@ -1743,7 +1750,9 @@ static int run_packed(seeqdev_scan *s)
       p.read_len = L; p.stride = b.stride; p.nstride = b.nstride;
       p.total_bytes = b.nreads * (uint64_t)b.stride;
       p.dfa = pat->d_pair; p.dfa_units = pat->pair_units;
-      p.cand = s->pk_cand; p.boff = s->pk_coff; p.bmask = s->pk_bmask; p.stage = s->pk_stage;
+      p.cand = s->pk_cand; p.cslot = s->pk_slot; p.boff = s->pk_coff; p.bmask = s->pk_bmask; p.stage = s->pk_stage;
+      p.wave_cap = (uint32_t)(s->cap_hitlines / ((size_t)wgrid * STREAM_NW_HOST));
+      p.pitch = pitch;
       p.hit_start = s->hit_start; p.hit_line = s->hit_line; p.hit_col = s->hit_col; p.hit_last = s->pk_last; p.nh = s->nh;
       p.cap = (uint32_t)s->cap_hitlines;
       p.line_base = p.first;
@@ -1757,13 +1766,12 @@ static int run_packed(seeqdev_scan *s)
       /* candidates before every block of 64 reads, their number */
       launch_scanset(s, st, s->pk_coff, nullptr, nullptr, (p.nreads + 63u) >> 6, &c->seg_nhitlines, nullptr, nullptr);
       hipLaunchKernelGGL(k_packed_counts, dim3(1), dim3(1), 0, st, p);
-      hipLaunchKernelGGL(k_packed_list, dim3((unsigned)(s->ncu * 16)), dim3(256), 0, st, p);
-      hipLaunchKernelGGL(k_packed_stage, dim3((unsigned)(s->ncu * 32)), dim3(256), 0, st, p);
+      hipLaunchKernelGGL(k_packed_list, dim3((unsigned)(((size_t)p.nreads / 64 + 256) / 256)), dim3(256), 0, st, p);
       /* from here: the exact pass over the staging text, as behind k_pair */
       ScanArgs a;
       memset(&a, 0, sizeof a);
       a.text = s->pk_stage;
-      a.nbytes = s->cap_hitlines * (uint64_t)(L + 1);
+      a.nbytes = s->cap_hitlines * (uint64_t)pitch;
       a.seg_base = 0; a.seg_len = (uint32_t)a.nbytes; a.first_seg = sg == 0;
       a.peq = pat->d_peq;
       a.m = pat->wlen; a.tau = pat->tau; a.options = options & ~(MASK_NONDNA | MASK_INPUT); a.want = want;

@@ -10,9 +10,11 @@
  *                   SDWA v_xor, the gather, one v_alignbit.  Output: per block of 64 reads the mask of candidate reads and
  *                   their number, per candidate read cand[r] = {first, last candidate column}.
  *                   A base that is N is stored as some code and flagged in the optional N mask: an alias, as in k_pair.
- *   k_packed_stage  the candidate reads (5 % of a read set with planted hits) are written out as ASCII lines, N restored,
- *                   into a staging text of one line per candidate, with the hit-list arrays the exact pass reads:
- *                   from here on k_exact1 COUNT / EMIT run as behind k_pair -- windows, every match option, bit-exact.
+ *                   The candidate reads of a block (5 % of a read set with planted hits) are unpacked on the spot -- sixteen
+ *                   lanes per candidate, N restored -- into lines of a staging text (every wave fills its own share of it).
+ *   k_packed_list   after a scan over the blocks' candidate counts: the hit-list arrays the exact pass reads, in read order,
+ *                   pointing at those lines: from here on k_exact1 COUNT / EMIT run as behind k_pair -- windows, every
+ *                   match option, bit-exact.
  *
  * Results are those of the ASCII scan of the same reads, one per line (tests/test_gpu_packed.py against the oracle).
  */
@@ -28,7 +30,10 @@ struct PackedArgs {
    uint64_t       total_bytes;  /* of `bases`: reads of the whole batch x stride */
    const uint16_t *dfa;         /* pair table (seeq_dfa.h section 3) */
    uint32_t       dfa_units;    /* 16-byte units of it */
-   uint32_t      *cand;         /* [nreads], written for candidate reads only */
+   uint32_t      *cand;         /* [nreads], written for candidate reads only: {first, last candidate column} */
+   uint32_t      *cslot;        /* [nreads], candidate reads only: the line of the staging text the walk kernel unpacked the read into */
+   uint32_t       wave_cap;     /* lines of the staging text every wave of the walk grid owns */
+   uint32_t       pitch;        /* bytes per line of the staging text: read_len + 1 rounded up to 16 */
    uint64_t      *bmask;        /* [ceil(nreads / 64)] candidate reads of every block of 64 reads, read r = bit r & 63 */
    uint32_t      *boff;         /* [ceil(nreads / 64)] their number; after the scan: candidates before the block */
    uint8_t       *stage;        /* [cap * (read_len + 1)] ASCII lines of the candidates */
@@ -52,6 +57,63 @@ __device__ __forceinline__ void packed_word(uint32_t w, uint32_t &st, uint32_t &
    PACKED_STEP(thi, 2) PACKED_STEP(tlo, 2) PACKED_STEP(thi, 3) PACKED_STEP(tlo, 3)
 }
 
+typedef uint32_t packed_u32_unaligned __attribute__((aligned(1)));
+
+/* Read `r` of the batch -> line `line` of the staging text, N restored: lane i of sixteen handles word i of the read (16
+   bases).  In two halves so that the walk can put a block of text between them: packed_stage_load requests the lane's
+   packed word and N bits, packed_stage_store -- a block later, when they have long arrived -- does the four v_perm look-ups
+   and the four word stores. */
+struct packed_pend_t { uint32_t w, nb, line, live; };
+
+__device__ __forceinline__ packed_pend_t packed_stage_load(const PackedArgs &a, uint64_t r, uint32_t line, uint32_t i)
+{
+   packed_pend_t p = {0u, 0u, line, 0u};
+   if (16u * i > a.read_len) return p;                     /* (lane read_len / 16 writes the newline, with or without bases in front of it) */
+   p.live = 1u;
+   if (16u * i == a.read_len) return p;
+   const uint8_t *pb = a.bases + r * (uint64_t)a.stride + 4u * i;
+   if (4u * i + 4u <= a.stride) p.w = *reinterpret_cast<const packed_u32_unaligned *>(pb);
+   else for (uint32_t b = 4u * i; b < a.stride; b++) p.w |= (uint32_t)pb[b - 4u * i] << (8u * (b - 4u * i));
+   if (a.nmask) {
+      const uint8_t *pn = a.nmask + r * (uint64_t)a.nstride;
+      p.nb = (uint32_t)pn[2u * i] << 8;
+      if (2u * i + 1u < a.nstride) p.nb |= pn[2u * i + 1u];
+   }
+   return p;
+}
+
+/* The staging text has a pitch of a multiple of 16 bytes per line (read_len + 1 rounded up): every lane stores ONE aligned
+   16-byte word -- the line's last word carries the newline and zeros behind it (never read as text: the line ends at the
+   newline).  (Lines at a pitch of read_len + 1: four unaligned 4-byte stores per lane and a byte loop for the last word --
+   the staging cost 0.11 ms per 16 Mi reads inside the walk kernel, as much as in a kernel of its own.) */
+__device__ __forceinline__ void packed_stage_store(const PackedArgs &a, const packed_pend_t &p, uint32_t i)
+{
+   if (!p.live) return;
+   const uint32_t L = a.read_len;
+   uint8_t *out = a.stage + (uint64_t)p.line * a.pitch;
+   uint32_t word[4];
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      const uint32_t b = (p.w >> (8 * j)) & 0xFFu;
+      const uint32_t sel = (b >> 6) | ((b & 0x30u) << 4) | ((b & 0x0Cu) << 14) | ((b & 3u) << 24);      /* the four codes, first base in byte 0 */
+      const uint32_t n4 = (p.nb >> (12 - 4 * j)) & 0xFu;                                               /* their N bits, first base in bit 3 */
+      const uint32_t nm = (((n4 >> 3) & 1u) | ((n4 & 4u) << 6) | ((n4 & 2u) << 15) | ((n4 & 1u) << 24)) * 0xFFu;
+      word[j] = (__builtin_amdgcn_perm(0u, 0x47544341u, sel) & ~nm) | (0x4E4E4E4Eu & nm);              /* "ACTG"[code] or 'N' */
+   }
+   if (16u * i + 16u > L) {                                /* the line's last word: bases, the newline, zeros */
+      const uint32_t keep = L - 16u * i;                   /* 0 .. 15 bases */
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+         const uint32_t lo = 4u * (uint32_t)j;
+         const uint32_t nb_ = keep <= lo ? 0u : (keep - lo >= 4u ? 4u : keep - lo);      /* bases of this word that belong to the read */
+         const uint32_t km = nb_ >= 4u ? 0xFFFFFFFFu : (1u << (8u * nb_)) - 1u;
+         word[j] = (word[j] & km) | ((keep >= lo && keep < lo + 4u) ? 0x0Au << (8u * (keep - lo)) : 0u);
+      }
+   }
+   *reinterpret_cast<fused_v4u *>(out + 16u * i) = fused_v4u{word[0], word[1], word[2], word[3]};
+   if (L == 256u && i == 15u) out[256] = '\n';            /* (the one length whose newline has no lane of its own) */
+}
+
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
 {
    extern __shared__ __align__(16) uint8_t dsmem[];
@@ -66,6 +128,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
    const uint32_t nwords = (nb + 3) >> 2;                  /* <= 16 */
    const uint32_t npairs = (a.read_len + 1) >> 1;
    const uint32_t nblocks = (a.nreads + 63) >> 6;
+   uint32_t wslots = 0;                                    /* wave-uniform: lines of the staging text this wave has filled */
+   bool wave_over = false;
+   packed_pend_t pend = {0u, 0u, 0u, 0u};                  /* a candidate's words on their way: unpacked and stored a block later */
    for (uint32_t blk = gwave; blk < nblocks; blk += nwaves) {
       const uint32_t r = blk * 64 + (uint32_t)lane;
       const bool live = r < a.nreads;
@@ -100,72 +165,59 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
          lc = lc < a.read_len ? lc : a.read_len - 1u;
          a.cand[r] = (fc << 16) | lc;
       }
+      /* The candidates of this block are unpacked right here -- their bytes are in L1, a later kernel would gather 57-byte
+         objects scattered over the batch (0.145 ms per 16 Mi reads) -- into lines of the staging text this WAVE owns (no
+         atomics: a counter per wave, as the hit slices of k_pair); k_packed_list points the hit list at them. */
+      const uint32_t nc = (uint32_t)__popcll(mask);
+      if (nc) {
+         const uint32_t s0 = wslots;
+         wslots += nc;
+         if (wslots <= a.wave_cap) {
+            const uint32_t line0 = gwave * a.wave_cap + s0;
+            if (is_cand) a.cslot[r] = line0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t g = (uint32_t)lane >> 4, i = (uint32_t)lane & 15u;
+            for (uint32_t b0 = 0; b0 < nc; b0 += 4) {       /* sixteen lanes per candidate, four candidates per round */
+               packed_stage_store(a, pend, i);               /* the round before this one (the last round of a block: finished behind the next block's walk) */
+               pend.live = 0u;
+               const uint32_t idx = b0 + g;
+               if (idx >= nc) continue;
+               uint64_t mm = mask;
+               for (uint32_t t = 0; t < idx; t++) mm &= mm - 1ull;
+               const uint32_t src = (uint32_t)__builtin_ctzll(mm);
+               pend = packed_stage_load(a, a.first + (uint64_t)blk * 64u + src, line0 + idx, i);
+            }
+         } else {
+            wave_over = true;
+         }
+      }
+   }
+   packed_stage_store(a, pend, (uint32_t)lane & 15u);
+   if (wave_over && lane == 0) {                           /* the wave's share of the staging text is too small: the scan is run again with more */
+      atomicOr(&a.cnt->overflow, 2u);
+      atomicMax(&a.cnt->need_hitlines, wslots * nwaves);
    }
 }
 
-/* The hit list of the candidate reads: one lane per read, a wave per block of 64 (two loads per wave; for one read in twenty a
-   load and five stores). */
+/* The hit list of the candidate reads: one lane per BLOCK of 64 reads walks the set bits of the block's mask (three of them
+   on a read set with planted hits; a lane per read spent 55 us per 16 Mi reads looking at 95 % empty positions). */
 __global__ __launch_bounds__(256) void k_packed_list(PackedArgs a)
 {
    const uint32_t stride = gridDim.x * 256;
-   const uint32_t L = a.read_len;
-   const uint32_t nr = (a.nreads + 63u) & ~63u;
-   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nr; r += stride) {
-      const uint64_t mask = a.bmask[r >> 6];
-      const uint32_t lane = r & 63u;
-      if (!((mask >> lane) & 1u)) continue;
-      const uint32_t k = a.boff[r >> 6] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      if (k >= a.cap) continue;                            /* (the overflow is reported by k_packed_counts) */
-      const uint32_t cd = a.cand[r];
-      a.hit_start[k] = k * (L + 1);
-      a.hit_line[k] = (uint32_t)(a.line_base + r + 1u);
-      a.hit_col[k] = cd >> 16;
-      a.hit_last[k] = cd & 0xFFFFu;
-      a.nh[k] = 0u;
-   }
-}
-
-/* Candidate reads -> ASCII lines of the staging text, N restored: SIXTEEN lanes per candidate, a lane per word of the read
-   (16 bases): one load of the packed bases and one of the N bits per lane, four v_perm look-ups, four word stores.
-   (A lane per read held its wave for the 151 byte stores of one candidate in twenty: 5.8 ms per 100 M reads; a lane per
-   candidate stored to 64 cache lines per instruction: 2.5 ms per 16 M reads; a lane per 16 bytes of the staging text
-   loaded every byte of the read by itself: 0.33 ms per 16 M reads, 0.24 of them the byte loads.) */
-typedef uint32_t packed_u32_unaligned __attribute__((aligned(1)));
-
-__global__ __launch_bounds__(256) void k_packed_stage(PackedArgs a)
-{
-   const uint32_t n = a.cnt->seg_nhitlines;
-   const uint32_t L = a.read_len, L1 = L + 1u;
-   const uint32_t i = threadIdx.x & 15u;                   /* word of the read */
-   const uint32_t groups = gridDim.x * 16u;
-   for (uint32_t k = blockIdx.x * 16u + (threadIdx.x >> 4); k < n; k += groups) {
-      const uint64_t r = (uint64_t)a.hit_line[k] - 1u;     /* read index in the batch (line numbers are read indices + 1) */
-      uint8_t *out = a.stage + (uint64_t)k * L1;
-      if (i == 0) out[L] = '\n';
-      if (16u * i >= L) continue;
-      const uint8_t *pb = a.bases + r * (uint64_t)a.stride + 4u * i;
-      uint32_t w = 0, nb = 0;
-      if (4u * i + 4u <= a.stride) w = *reinterpret_cast<const packed_u32_unaligned *>(pb);
-      else for (uint32_t b = 4u * i; b < a.stride; b++) w |= (uint32_t)pb[b - 4u * i] << (8u * (b - 4u * i));
-      if (a.nmask) {
-         const uint8_t *pn = a.nmask + r * (uint64_t)a.nstride;
-         nb = (uint32_t)pn[2u * i] << 8;
-         if (2u * i + 1u < a.nstride) nb |= pn[2u * i + 1u];
-      }
-      uint32_t word[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-         const uint32_t b = (w >> (8 * j)) & 0xFFu;
-         const uint32_t sel = (b >> 6) | ((b & 0x30u) << 4) | ((b & 0x0Cu) << 14) | ((b & 3u) << 24);      /* the four codes, first base in byte 0 */
-         const uint32_t n4 = (nb >> (12 - 4 * j)) & 0xFu;                                                 /* their N bits, first base in bit 3 */
-         const uint32_t nm = (((n4 >> 3) & 1u) | ((n4 & 4u) << 6) | ((n4 & 2u) << 15) | ((n4 & 1u) << 24)) * 0xFFu;
-         word[j] = (__builtin_amdgcn_perm(0u, 0x47544341u, sel) & ~nm) | (0x4E4E4E4Eu & nm);              /* "ACTG"[code] or 'N' */
-      }
-      if (16u * i + 16u <= L) {
-#pragma unroll
-         for (int j = 0; j < 4; j++) *reinterpret_cast<packed_u32_unaligned *>(out + 16u * i + 4u * j) = word[j];
-      } else {
-         for (uint32_t c = 16u * i; c < L; c++) out[c] = (uint8_t)(word[(c >> 2) & 3u] >> (8u * (c & 3u)));
+   const uint32_t nblocks = (a.nreads + 63u) >> 6;
+   for (uint32_t blk = blockIdx.x * 256 + threadIdx.x; blk < nblocks; blk += stride) {
+      uint64_t mask = a.bmask[blk];
+      uint32_t k = a.boff[blk];
+      while (mask) {
+         const uint32_t r = blk * 64u + (uint32_t)__builtin_ctzll(mask);
+         mask &= mask - 1ull;
+         if (k >= a.cap) break;                            /* (the overflow is reported by k_packed_counts) */
+         const uint32_t cd = a.cand[r];
+         a.hit_start[k] = a.cslot[r] * a.pitch;
+         a.hit_line[k] = (uint32_t)(a.line_base + r + 1u);
+         a.hit_col[k] = cd >> 16;
+         a.hit_last[k] = cd & 0xFFFFu;
+         a.nh[k] = 0u;
+         k++;
       }
    }
 }

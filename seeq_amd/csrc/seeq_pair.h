@@ -23,8 +23,8 @@
  *     BETWEEN a step's two gathers and the instructions that need their results, i.e. in the shadow of the LDS latency
  *     the walk is made of (fast check: upper case A C G T N and newlines only -- v_perm + v_sad_u8 per word; a tile that
  *     fails it takes the exact check of k_stream over its text fetched again; newline flags: v_perm + v_dot4 per word).
- *     With the gathers halved the kernel is no longer held by the LDS unit (57 % busy, of which half bank conflicts) but
- *     runs within 15 % of what the memory system delivers for this access pattern.
+ *     With the gathers halved the kernel is no longer held by the LDS unit alone (60 % busy, of which half bank conflicts):
+ *     it sits 1.2 - 1.4 x above both the memory system's floor and the gather unit's at once.
  *
  * Why every line with a hit gets a candidate, and why the exact pass may start m + tau columns before a line's FIRST
  * candidate (tests/test_kernel_core_host.py::test_pair_automaton_... checks both on the host against the oracle):
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       in 128 registers at half the occupancy: 1.06 / 0.92 / 0.81 ms per launch against 0.78 without.  A lane's eight
       pieces lie inside one 128-byte line and only loads issued back to back are merged into one fetch of it; and with
       every load behind a wave-uniform branch awaited where the branch ends, or a spilled value reloaded through the same
-      in-order counter, the early request waits anyway.  Without the bookkeeping the kernel runs at 0.645 ms = 6.2 TB/s,
-      what a plain read sweep reaches: DESIGN.md section 5.) */
+      in-order counter, the early request waits anyway.  Without the bookkeeping the kernel runs at 0.645 ms per launch
+      (5.9 TB/s; a plain read sweep of this layout: 6.2): DESIGN.md section 5.) */
    fused_v4u v[NQ];
    uint32_t halo = 0;                                     /* lanes 0..7: the eight words before the tile (lane 0's warm-up comes from them) */
    uint32_t tile = gwave;
