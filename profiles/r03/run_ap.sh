@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r03au; mkdir -p $O
+O=gpurun_out/r03bb; mkdir -p $O
 export TMPDIR=/tmp; REPO=$PWD; cd /tmp
 cat > /tmp/mb.py <<'PY'
 import os, sys, time
@@ -26,7 +26,7 @@ python3 - <<'PY'
 import csv, glob
 for w in ("cnt", "rec"):
   print("==", w)
-  for f in glob.glob("gpurun_out/r03au/trace_%s/**/*kernel_stats.csv" % w, recursive=True):
+  for f in glob.glob("gpurun_out/r03bb/trace_%s/**/*kernel_stats.csv" % w, recursive=True):
     for r in list(csv.DictReader(open(f)))[:16]:
         print("%-60s calls %5s avg_us %10.2f total_ms %8.2f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY

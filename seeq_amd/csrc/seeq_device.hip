@@ -445,12 +445,13 @@ __global__ void k_seg_mid(ScanArgs a)
 }
 
 /* Before the EMIT pass: do the records fit? */
-__global__ void k_rec_check(ScanArgs a)
+__device__ __forceinline__ void rec_check_body(const ScanArgs &a)
 {
    Counters *c = a.cnt;
    c->need_records = c->records + c->seg_nrec;     /* running total incl. this segment */
    if (c->records + c->seg_nrec > a.cap_records) atomicOr(&c->overflow, 4u);
 }
+__global__ void k_rec_check(ScanArgs a) { rec_check_body(a); }
 
 /* ========================================================================== */
 /* K4/K5: exact pass over the hit lines                                       */
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(WG) void k_rec_offsets(ScanArgs a)
 }
 
 /* Lines with >= 1 verified hit, from the per-line counts (before they are scanned into offsets). */
-__global__ __launch_bounds__(WG) void k_count_nonzero(ScanArgs a)
+__device__ __forceinline__ void count_nonzero_body(const ScanArgs &a)
 {
    __shared__ uint32_t s_n[WG / 64];
    const uint32_t nhl = a.cnt->seg_nhitlines;
@@ -528,7 +529,9 @@ __global__ __launch_bounds__(WG) void k_count_nonzero(ScanArgs a)
       if (n) atomicAdd(&a.cnt->seg_nmatch, n);
    }
 }
-__global__ void k_seg_end(ScanArgs a, int flags /* 1: hits come from nh[]; 2: nh[] holds 0/1 verdicts, their sum = matching lines */)
+__global__ __launch_bounds__(WG) void k_count_nonzero(ScanArgs a) { count_nonzero_body(a); }
+
+__device__ __forceinline__ void seg_end_body(const ScanArgs &a, int flags /* 1: hits come from nh[]; 2: nh[] holds 0/1 verdicts, their sum = matching lines */)
 {
    Counters *c = a.cnt;
    const uint32_t counted = c->seg_nlines - c->seg_nheaders;
@@ -542,6 +545,7 @@ __global__ void k_seg_end(ScanArgs a, int flags /* 1: hits come from nh[]; 2: nh
    if (a.want == SEEQDEV_WANT_RECORDS) c->records += seg_hits;
    c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = c->seg_nmatch = c->seg_novf = 0;
 }
+__global__ void k_seg_end(ScanArgs a, int flags) { seg_end_body(a, flags); }
 
 /* SINGLELINE: the buffer is one string -> one line starting at 0. */
 __global__ void k_single_line(ScanArgs a)
@@ -946,6 +950,8 @@ struct seeqdev_scan {
    uint32_t *mp_idx, *mp_nh; size_t cap_mp;               /* npat regions of cap_mp / npat entries: index into the per-line arrays, hits */
    uint32_t *m_bsum; size_t cap_m_bsum;
    Counters *d_mcnt, *h_mcnt;                             /* [SEEQ_MULTI_MAX], h_ pinned */
+   MultiExact *d_mx, *h_mx; size_t mx_slots, mx_next;      /* per segment the patterns' exact-pass arguments: device copy, pinned ring of mx_slots segments */
+   uint32_t *m_scan_ws; size_t cap_m_scan_ws;             /* block sums of the per-pattern scans */
    int       last_multi;                                  /* the last multi scan: 1 = one walk for all patterns, 0 = a scan per pattern */
    /* packed read batches (seeqdevScanPacked) */
    uint32_t *pk_cand, *pk_slot, *pk_coff; uint64_t *pk_bmask; size_t cap_pk_reads;      /* candidate columns per read of a segment; per block of 64 reads: candidates before it, their mask */
@@ -1050,8 +1056,9 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
       for (void *b : ob) if (b) (void)hipFree(b);
    }
    { void *pk[] = {s->pk_cand, s->pk_slot, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
-   { void *mw[] = {s->ml_mask, s->ml_first, s->ml_last, s->mp_idx, s->mp_nh, s->m_bsum, s->d_mcnt}; for (void *b : mw) if (b) (void)hipFree(b); }
+   { void *mw[] = {s->ml_mask, s->ml_first, s->ml_last, s->mp_idx, s->mp_nh, s->m_bsum, s->d_mcnt, s->d_mx, s->m_scan_ws}; for (void *b : mw) if (b) (void)hipFree(b); }
    if (s->h_mcnt) (void)hipHostFree(s->h_mcnt);
+   if (s->h_mx) (void)hipHostFree(s->h_mx);
    multi_plan_free(s->mplan);
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
@@ -1827,6 +1834,19 @@ static int multi_ws_ensure(seeqdev_scan *s, int npat)
       if (ws_alloc((void **)&s->mp_nh, s->cap_hitlines * sizeof(uint32_t))) return -1;
       s->cap_mp = s->cap_hitlines;
    }
+   if (!s->d_mx) {
+      s->mx_slots = 64;                                    /* segments whose argument arrays may be in flight (a run of more segments waits for the stream in between) */
+      HIP_TRY(hipMalloc((void **)&s->d_mx, s->mx_slots * SEEQ_MULTI_MAX * sizeof(MultiExact)), ENOMEM);
+      HIP_TRY(hipHostMalloc((void **)&s->h_mx, s->mx_slots * SEEQ_MULTI_MAX * sizeof(MultiExact), hipHostMallocDefault), ENOMEM);
+      s->mx_next = 0;
+   }
+   {
+      const size_t nbp = (s->cap_hitlines / (size_t)npat) / SCAN_BLOCK + 2;
+      if ((size_t)npat * nbp > s->cap_m_scan_ws) {
+         if (ws_alloc((void **)&s->m_scan_ws, (size_t)npat * nbp * sizeof(uint32_t))) return -1;
+         s->cap_m_scan_ws = (size_t)npat * nbp;
+      }
+   }
    const size_t nb = s->cap_hitlines / MULTI_BLOCK + 2;
    if ((size_t)npat * nb > s->cap_m_bsum) {
       if (ws_alloc((void **)&s->m_bsum, (size_t)npat * nb * sizeof(uint32_t))) return -1;
@@ -1877,12 +1897,23 @@ static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
       if (trust) { HIP_TRY(hipGetLastError(), EIO); return 0; }
       hipLaunchKernelGGL(k_multi_apply, dim3(m.nb), dim3(256), 0, st, m);
    }
+   /* The exact pass, every pattern in one launch per step (blockIdx.y = pattern; one-word patterns first, then the two-word
+      ones): the patterns' arguments go to HBM through a page-locked ring, one slot per segment. */
    const size_t hit_blocks = ((size_t)capP + WG - 1) / WG;
-   unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 16 ? hit_blocks : (size_t)s->ncu * 16);
+   unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 4 ? hit_blocks : (size_t)s->ncu * 4);      /* (x npat workgroups per launch) */
    if (grid_hits == 0) grid_hits = 1;
-   for (int k = 0; k < npat; k++) {
-      Counters *pc = s->d_mcnt + k;
-      ScanArgs a = ua;
+   if (s->mx_next == s->mx_slots) { HIP_TRY(hipStreamSynchronize(st), EIO); s->mx_next = 0; }
+   MultiExact *hx = s->h_mx + s->mx_next * SEEQ_MULTI_MAX, *dx = s->d_mx + s->mx_next * SEEQ_MULTI_MAX;
+   s->mx_next++;
+   const uint32_t nbp = (uint32_t)((size_t)capP / SCAN_BLOCK + 2);
+   int order[SEEQ_MULTI_MAX], n1 = 0, n2 = 0;
+   for (int k = 0; k < npat; k++) if (mp->fw[k] == 1) order[n1++] = k;
+   for (int k = 0; k < npat; k++) if (mp->fw[k] != 1) order[n1 + n2++] = k;
+   for (int q = 0; q < npat; q++) {
+      const int k = order[q];
+      MultiExact &x = hx[q];
+      ScanArgs &a = x.a;
+      a = ua;
       a.m = mp->m[k]; a.tau = mp->tau[k];
       a.hit_start = s->hit_start; a.hit_line = s->hit_line; a.cap_hitlines = capP;      /* the union's lines, through this pattern's index list */
       a.hit_idx = s->mp_idx + (size_t)k * capP;
@@ -1893,25 +1924,32 @@ static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
       a.hit_last = s->ml_last;
       a.window_ok = 1u;
       a.tile_dirty = nullptr; a.tile_dmask = nullptr; a.stream_ntiles = 0; a.stream_ch = 0;
-      a.cnt = pc;
-      const int fw = mp->fw[k];
-      const uint32_t *eqp = mp->d_eq + (size_t)k * 1536;
-      const uint32_t *hcol = s->ml_first;
-      uint4 *ecache = want == SEEQDEV_WANT_RECORDS ? s->ow.tmp + (size_t)k * capP : nullptr;
-      if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-      else hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-      if (nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
-      launch_scan<0>(s, st, a.nh, a.nh, capP, &pc->seg_nhitlines, 0u, 0u, &pc->seg_nrec);
-      if (want == SEEQDEV_WANT_RECORDS) {
-         hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);
-         const int mo = match_opt == SQ_COUNT ? SQ_FIRST : match_opt;
-         if (fw == 2) { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-                        else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
-         else { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-                else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
-      }
-      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 1 | (!nh_is_count ? 2 : 0));
+      a.cnt = s->d_mcnt + k;
+      x.eq = mp->d_eq + (size_t)k * 1536;
+      x.hcol = s->ml_first;
+      x.cache = want == SEEQDEV_WANT_RECORDS ? s->ow.tmp + (size_t)k * capP : nullptr;
+      x.scan_ws = s->m_scan_ws + (size_t)k * nbp;
+      x.nb = nbp;
+      x.seg_end_flags = 1 | (!nh_is_count ? 2 : 0);
    }
+   HIP_TRY(hipMemcpyAsync(dx, hx, (size_t)npat * sizeof(MultiExact), hipMemcpyHostToDevice, st), EIO);
+   const int mo = match_opt == SQ_COUNT ? SQ_FIRST : match_opt;
+   if (n1) hipLaunchKernelGGL((k_exact1m<SQ_MODE_COUNT, 1, -1>), dim3(grid_hits, (unsigned)n1), dim3(WG), 0, st, (const MultiExact *)dx);
+   if (n2) hipLaunchKernelGGL((k_exact1m<SQ_MODE_COUNT, 2, -1>), dim3(grid_hits, (unsigned)n2), dim3(WG), 0, st, (const MultiExact *)(dx + n1));
+   if (nh_is_count) hipLaunchKernelGGL(k_multi_count_nonzero, dim3(grid_hits < 128 ? grid_hits : 128, (unsigned)npat), dim3(WG), 0, st, (const MultiExact *)dx);
+   hipLaunchKernelGGL(k_multi_scan_reduce, dim3(nbp, (unsigned)npat), dim3(WG), 0, st, (const MultiExact *)dx);
+   hipLaunchKernelGGL(k_multi_scan_top, dim3((unsigned)npat), dim3(WG), 0, st, (const MultiExact *)dx, want == SEEQDEV_WANT_RECORDS ? 1 : 0);
+   hipLaunchKernelGGL(k_multi_scan_apply, dim3(nbp, (unsigned)npat), dim3(WG), 0, st, (const MultiExact *)dx);
+   if (want == SEEQDEV_WANT_RECORDS) {
+      if (mo == SQ_BEST) {
+         if (n1) hipLaunchKernelGGL((k_exact1m<SQ_MODE_EMIT, 1, SQ_BEST>), dim3(grid_hits, (unsigned)n1), dim3(WG), 0, st, (const MultiExact *)dx);
+         if (n2) hipLaunchKernelGGL((k_exact1m<SQ_MODE_EMIT, 2, SQ_BEST>), dim3(grid_hits, (unsigned)n2), dim3(WG), 0, st, (const MultiExact *)(dx + n1));
+      } else {
+         if (n1) hipLaunchKernelGGL((k_exact1m<SQ_MODE_EMIT, 1, -1>), dim3(grid_hits, (unsigned)n1), dim3(WG), 0, st, (const MultiExact *)dx);
+         if (n2) hipLaunchKernelGGL((k_exact1m<SQ_MODE_EMIT, 2, -1>), dim3(grid_hits, (unsigned)n2), dim3(WG), 0, st, (const MultiExact *)(dx + n1));
+      }
+   }
+   hipLaunchKernelGGL(k_multi_seg_end, dim3((unsigned)npat), dim3(1), 0, st, (const MultiExact *)dx);
    HIP_TRY(hipGetLastError(), EIO);
    return 0;
 }

@@ -142,7 +142,7 @@ template <> __device__ __forceinline__ void exact1_take<2>(fused_state_t<2> &st,
  * Only when a region is too small (Counters.seg_novf set) does EMIT scan the lines with more than one record again. */
 /* WALK: compile the window walk in (long-line inputs); without it the per-character loop carries no walk state */
 template <int MODE, int W, int OPT, bool WALK>
-__global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
+__device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
 {
    __shared__ __align__(8) uint32_t s_eqf[256 * W];
    __shared__ __align__(8) uint32_t s_eqr[256 * W];
@@ -474,6 +474,31 @@ __global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *e
          a.rec_off[slot] = off;
       }
    }
+}
+
+template <int MODE, int W, int OPT, bool WALK>
+__global__ __launch_bounds__(256, 6) void k_exact1(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
+{
+   exact1_body<MODE, W, OPT, WALK>(a, eq2, hit_col, cache);
+}
+
+/* Several patterns in ONE launch (seeq_multi.h): blockIdx.y selects the pattern -- its arguments (its own index list, counters,
+   record region, m, tau), its EQ tables, its COUNT -> EMIT cache -- from an array in HBM (scalar loads: the index is uniform). */
+struct MultiExact {
+   ScanArgs        a;
+   const uint32_t *eq;
+   const uint32_t *hcol;
+   uint4          *cache;
+   uint32_t       *scan_ws;      /* this pattern's block sums of the scan over its per-pair counts */
+   uint32_t        nb;           /* blocks of that scan */
+   int             seg_end_flags;
+};
+
+template <int MODE, int W, int OPT>
+__global__ __launch_bounds__(256, 6) void k_exact1m(const MultiExact *mx)
+{
+   const MultiExact &m = mx[blockIdx.y];
+   exact1_body<MODE, W, OPT, false>(m.a, m.eq, m.hcol, m.cache);
 }
 
 #endif

@@ -13,8 +13,10 @@
  *   k_multi_reduce / _top / _apply   a scan per pattern (blockIdx.y = pattern) over bit p of the sets: the (line, pattern)
  *                     pairs, grouped by pattern, in line order -- pattern p's candidate list, in its own region of the
  *                     workspace, with its own Counters.
- *   k_exact1 COUNT / EMIT per pattern over its own list (window = the line's union window): counts and records as a scan
- *                     of the pattern alone produces them -- the kernels, the rules and the record order are the same.
+ *   k_exact1m COUNT / EMIT (blockIdx.y = pattern: every pattern in one launch, its arguments from an array in HBM) over each
+ *                     pattern's own list (window = the line's union window): counts and records as a scan of the pattern
+ *                     alone produces them -- the kernel body, the rules and the record order are k_exact1's; the scans of
+ *                     the per-pair counts, the record check and the segment's bookkeeping likewise one launch each.
  *
  * Host side of the superset / window argument: tests/test_kernel_core_host.py::test_multi_pattern_automata_...
  */
@@ -244,5 +246,78 @@ __global__ __launch_bounds__(256) void k_multi_apply(MultiArgs a)
       }
    }
 }
+
+/* ---- the per-pattern bookkeeping of the exact pass, every pattern in one launch (blockIdx.y / blockIdx.x = pattern) ---- */
+__global__ __launch_bounds__(WG) void k_multi_count_nonzero(const MultiExact *mx) { count_nonzero_body(mx[blockIdx.y].a); }
+
+/* exclusive scan of a pattern's per-pair counts nh[0 .. seg_nhitlines) in place, total -> seg_nrec: reduce, top, apply */
+__global__ __launch_bounds__(WG) void k_multi_scan_reduce(const MultiExact *mx)
+{
+   __shared__ uint32_t s_wave[4];
+   const MultiExact &m = mx[blockIdx.y];
+   const uint32_t n = m.a.cnt->seg_nhitlines;
+   const uint32_t base = blockIdx.x * SCAN_BLOCK;
+   if (base >= n) return;
+   uint32_t v = 0;
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      if (i < n) v += m.a.nh[i];
+   }
+   uint32_t tot;
+   block_excl_scan(v, &tot, s_wave);
+   if (threadIdx.x == 0) m.scan_ws[blockIdx.x] = tot;
+}
+
+/* (one workgroup per pattern; with records wanted also what k_rec_check does) */
+__global__ __launch_bounds__(WG) void k_multi_scan_top(const MultiExact *mx, int check_records)
+{
+   __shared__ uint32_t s_wave[4];
+   const MultiExact &m = mx[blockIdx.x];
+   Counters *c = m.a.cnt;
+   const uint32_t n = c->seg_nhitlines;
+   const uint32_t nbu = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+   uint32_t running = 0;
+   for (uint32_t b0 = 0; b0 < nbu; b0 += WG) {
+      const uint32_t i = b0 + threadIdx.x;
+      const uint32_t v = i < nbu ? m.scan_ws[i] : 0;
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan(v, &tot, s_wave);
+      if (i < nbu) m.scan_ws[i] = running + ex;
+      running += tot;
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) {
+      c->seg_nrec = running;
+      if (check_records) rec_check_body(m.a);
+   }
+}
+
+__global__ __launch_bounds__(WG) void k_multi_scan_apply(const MultiExact *mx)
+{
+   __shared__ uint32_t s_wave[4];
+   const MultiExact &m = mx[blockIdx.y];
+   const uint32_t n = m.a.cnt->seg_nhitlines;
+   const uint32_t base = blockIdx.x * SCAN_BLOCK;
+   if (base >= n) return;
+   uint32_t item[SCAN_ITEMS];
+   uint32_t v = 0;
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      item[k] = i < n ? m.a.nh[i] : 0;
+      v += item[k];
+   }
+   uint32_t tot;
+   uint32_t ex = block_excl_scan(v, &tot, s_wave) + m.scan_ws[blockIdx.x];
+#pragma unroll
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
+      if (i < n) m.a.nh[i] = ex;
+      ex += item[k];
+   }
+}
+
+__global__ void k_multi_seg_end(const MultiExact *mx) { seg_end_body(mx[blockIdx.x].a, mx[blockIdx.x].seg_end_flags); }
 
 #endif
