@@ -471,6 +471,7 @@ def main():
     ap.add_argument("--no-per-call", action="store_true", help="skip the seeqStringMatch per-call measurement")
     ap.add_argument("--no-packed", action="store_true", help="skip the packed-batch scan of the same reads")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI wall-clock measurement (timed region iii)")
+    ap.add_argument("--no-multi", action="store_true", help="skip the sixteen-barcode multi-pattern measurement")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--check-lines", type=int, default=1_000_000,
                     help="prefix verified against the oracle (plus every 97th 64 Ki-line block and the segment seams); 0 = no check")
@@ -746,6 +747,54 @@ def main():
                 del pb, pn
             except Exception as e:                      # (a pattern without a pair automaton: ENOTSUP)
                 out["packed_scan"] = {"error": str(e)}
+        if world == 1 and not args.no_multi and args.workload in ("best", "count", "all"):
+            # Sixteen barcodes over the first 10 M reads of the buffer (row f4b, seeq_multi.h): ONE walk for the set against a scan per
+            # pattern (SEEQ_MULTI=sequential) -- the set holds three windows of the planted pattern and thirteen random 10-mers, d = 1;
+            # counts and (for the records run) every record of every pattern compared between the two paths.
+            try:
+                import random as _random
+                rng_ = _random.Random(2025)
+                m_plain = dev.plain_pattern(PATTERN)
+                m_names = [m_plain[i:i + 10] for i in (0, 5, 10) if len(m_plain) >= i + 10]
+                while len(m_names) < 16:
+                    m_names.append("".join(rng_.choice("ACGT") for _ in range(10)))
+                mp = [dev.Pattern(b, 1) for b in m_names]
+                m_nm = min(n, 10_000_000)
+                m_sub = text[:m_nm * (READ_LEN + 1)]
+                scm = dev.Scanner(stream)
+                m_res = {}
+                for m_mode in ("one_walk", "per_pattern"):
+                    if m_mode == "per_pattern":
+                        os.environ["SEEQ_MULTI"] = "sequential"
+                    else:
+                        os.environ.pop("SEEQ_MULTI", None)
+                    for m_wname, o_, w_ in (("count_lines", 0, dev.WANT_COUNTLINES), ("best_records", dev.SQ_BEST, dev.WANT_RECORDS)):
+                        m_best = None
+                        for m_it in range(3):
+                            torch.cuda.synchronize()
+                            m_t1 = time.perf_counter()
+                            m_got = scm.scan_tensor_multi(mp, m_sub, o_, w_, copy=False)
+                            m_dt = time.perf_counter() - m_t1
+                            if m_it:
+                                m_best = m_dt if m_best is None else min(m_best, m_dt)
+                        m_res[(m_mode, m_wname)] = (m_best, scm.last_multi_one_pass(), [g["nmatchlines"] for g in m_got],
+                                              [g["records"].copy() for g in m_got] if w_ == dev.WANT_RECORDS else None)
+                os.environ.pop("SEEQ_MULTI", None)
+                m_sec = {"patterns": 16, "pattern_len": 10, "distance": 1, "lines": m_nm}
+                for m_wname in ("count_lines", "best_records"):
+                    a_, b_ = m_res[("one_walk", m_wname)], m_res[("per_pattern", m_wname)]
+                    m_same = a_[2] == b_[2] and (a_[3] is None or all(np.array_equal(x, y) for x, y in zip(a_[3], b_[3])))
+                    m_sec[m_wname] = {"one_walk_ms": a_[0] * 1e3, "per_pattern_ms": b_[0] * 1e3, "speedup": b_[0] / a_[0], "one_walk_ran": bool(a_[1]),
+                                  "matching_line_pattern_pairs": int(sum(a_[2])), "identical_results": bool(m_same)}
+                m_sec["note"] = ("seeqdevScanRunMulti on resident text: one k_pair walk over the union automaton of the set + pattern sets per candidate line + "
+                               "the exact pass over (line, pattern) pairs, against sixteen scans of the same text; records land in page-locked host memory "
+                               "in both cases (DESIGN.md section 8, profiles/multi_bench.py for planted barcode sets)")
+                out["multi_pattern"] = m_sec
+                scm.close()
+                for p_ in mp:
+                    p_.close()
+            except Exception as e:
+                out["multi_pattern"] = {"error": str(e)}
         if world == 1 and not args.no_per_call:
             out["per_call"] = per_call_rates(PATTERN, TAU, READ_LEN)
         if not args.no_cpu_baseline and world == 1:
