@@ -1375,3 +1375,41 @@ def test_multi_pattern_edges_and_fallbacks(gpu, capi, oracle):
     check(two, [1, 1], text_for(two, [1, 1], 2000, foreign=True), options=dev.SQ_IGNORE, expect_one_pass=False)
     check(["ACG", "GATTACAGA"], [2, 1], text_for(["ACG", "GATTACAGA"], [2, 1], 1500), expect_one_pass=False)     # shorter than d + 2
     check(["GATTACAGA"], [1], text_for(["GATTACAGA"], [1], 1500), expect_one_pass=False)
+
+
+def test_multi_pattern_workspace_growth(gpu, capi, oracle):
+    """The one-walk multi-pattern scan with a workspace that is far too small for its candidates, its (line, pattern) pairs and
+    its records (seeqdevScanReserve with tiny capacities): the device reports what it needs, the scan is run again, the
+    results are the oracle's -- for one dominant pattern (its region of the shared workspace overflows first) and for a spread."""
+    from seeq_amd import device as dev
+    rng = random.Random(99)
+    barcodes = ["GATTACAGAC", "TTGACCGATA", "CCATGGTACA", "AGAGTCTCTG"]
+    taus = [1, 1, 1, 1]
+    for weights in ([1, 1, 1, 1], [30, 1, 1, 1]):
+        lines = []
+        for _ in range(30000):
+            n = 100
+            t = [rng.choice("ACGT") for _ in range(n)]
+            for _ in range(2):
+                k = rng.choices(range(4), weights)[0]
+                c = _mutate(rng, barcodes[k], rng.randint(0, 1))
+                q = rng.randrange(n - len(c) + 1)
+                t[q:q + len(c)] = list(c)
+            lines.append("".join(t)[:n])
+        buf = ("\n".join(lines) + "\n").encode()
+        pats = [dev.Pattern(b, t) for b, t in zip(barcodes, taus)]
+        for opt, want in ((SQ_ALL, dev.WANT_RECORDS), (SQ_BEST, dev.WANT_RECORDS), (0, dev.WANT_COUNTMATCH)):
+            sc = dev.Scanner()
+            sc.reserve(len(buf), len(lines) + 64, 2000, 1500)
+            got = sc.scan_host_multi(pats, buf, opt, want)
+            assert sc.last_multi_one_pass()
+            for k, (b, t) in enumerate(zip(barcodes, taus)):
+                exp = oracle.buffer_scan(b, t, buf, opt if want == dev.WANT_RECORDS else SQ_ALL)
+                assert got[k]["nmatchlines"] == exp["nmatchlines"], (weights, k, opt, want)
+                if want == dev.WANT_RECORDS:
+                    assert np.array_equal(got[k]["records"].astype(np.uint64), exp["records"]), (weights, k, opt)
+                else:
+                    assert got[k]["nhits"] == len(exp["records"]), (weights, k)
+            sc.close()
+        for p in pats:
+            p.close()
