@@ -9,9 +9,9 @@ O=gpurun_out/r03final; mkdir -p $O
 export TMPDIR=/tmp
 if [ $PART = all ] || [ $PART = bench ]; then
 timeout -k 10 400 python bench.py > $O/bench_best.json 2> $O/bench_best.err; echo "best exit $?"
-timeout -k 10 200 python bench.py --workload count --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed > $O/bench_count.json 2> $O/bench_count.err; echo "count exit $?"
-timeout -k 10 200 python bench.py --workload all --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed > $O/bench_all.json 2> $O/bench_all.err; echo "all exit $?"
-timeout -k 10 400 python bench.py --workload cfg5 --steps 20 --warmup 3 --no-e2e --no-per-call --no-cli --no-packed > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo "cfg5 exit $?"
+timeout -k 10 200 python bench.py --workload count --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi > $O/bench_count.json 2> $O/bench_count.err; echo "count exit $?"
+timeout -k 10 200 python bench.py --workload all --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi > $O/bench_all.json 2> $O/bench_all.err; echo "all exit $?"
+timeout -k 10 400 python bench.py --workload cfg5 --steps 20 --warmup 3 --no-e2e --no-per-call --no-cli --no-packed --no-multi > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo "cfg5 exit $?"
 for f in $O/bench_*.json; do python3 - "$f" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))
@@ -21,8 +21,8 @@ done
 timeout -k 10 600 python3 profiles/multi_bench.py 10000000 > $O/multi.jsonl 2> $O/multi.err; echo "multi exit $?"
 fi
 if [ $PART = all ] || [ $PART = profile ]; then
-TEXT_BYTES_TOTAL=60400000000 timeout -k 10 500 bash profiles/gpu_profile.sh r03_final_best --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --check-lines 0 > $O/profile_best.log 2>&1; echo "profile best exit $?"
-TEXT_BYTES_TOTAL=100400000000 timeout -k 10 500 bash profiles/gpu_profile.sh r03_final_cfg5 --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --check-lines 0 > $O/profile_cfg5.log 2>&1; echo "profile cfg5 exit $?"
+TEXT_BYTES_TOTAL=60400000000 timeout -k 10 500 bash profiles/gpu_profile.sh r03_final_best --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi --check-lines 0 > $O/profile_best.log 2>&1; echo "profile best exit $?"
+TEXT_BYTES_TOTAL=100400000000 timeout -k 10 500 bash profiles/gpu_profile.sh r03_final_cfg5 --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi --check-lines 0 > $O/profile_cfg5.log 2>&1; echo "profile cfg5 exit $?"
 find gpurun_out/prof_r03_final_best gpurun_out/prof_r03_final_cfg5 -name "*.csv" -size +2M -delete
 head -30 gpurun_out/prof_r03_final_best/summary.txt
 fi
