@@ -1413,3 +1413,39 @@ def test_multi_pattern_workspace_growth(gpu, capi, oracle):
             sc.close()
         for p in pats:
             p.close()
+
+
+@pytest.mark.parametrize("m,k", [(42, 8), (42, 15), (34, 10), (27, 8), (20, 5), (20, 3)])
+def test_published_sweep_cells_small(gpu, capi, oracle, m, k):
+    """The reference's published sweep (doc/response.tex:209-232: chromosome lines, m = 20 / 27 / 34 / 42 x k) at a size the oracle
+    finishes in seconds: six lines of 200-400 KB of random DNA with mutated copies of the pattern planted, `--all` with
+    positions and both counts against the oracle.  Patterns without an automaton that fits (all but m = 20, k = 3) take
+    k_stream's Myers mode; the full-size cells are profiles/r03_chrom_sweep.txt."""
+    from seeq_amd import device as dev
+    rng = random.Random(1000 * m + k)
+    pattern = "".join(rng.choice("ACGT") for _ in range(m))
+    lines = []
+    for i in range(6):
+        n = rng.choice([200_000, 300_000, 400_000])
+        t = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(40):
+            c = _mutate(rng, pattern, rng.randint(0, k + 2))
+            q = rng.randrange(n - len(c))
+            t[q:q + len(c)] = list(c)
+        if i == 2:
+            t[rng.randrange(n)] = "N"
+        lines.append("".join(t))
+    buf = ("\n".join(lines) + "\n").encode()
+    pat = dev.Pattern(pattern, k)
+    sc = dev.Scanner()
+    exp = oracle.buffer_scan(pattern, k, buf, SQ_ALL)
+    got = sc.scan_host(pat, buf, SQ_ALL, dev.WANT_RECORDS)
+    assert sc.last_kernel() == ("k_stream" if (m, k) == (20, 3) else "k_myers"), sc.last_kernel()
+    assert got["nlines"] == exp["nlines"] == 6 and got["nmatchlines"] == exp["nmatchlines"]
+    assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (m, k)
+    expb = oracle.buffer_scan(pattern, k, buf, SQ_BEST)
+    gotb = sc.scan_host(pat, buf, SQ_BEST, dev.WANT_RECORDS)
+    assert np.array_equal(gotb["records"].astype(np.uint64), expb["records"]), (m, k)
+    c2 = sc.scan_host(pat, buf, 0, dev.WANT_COUNTMATCH)
+    assert c2["nhits"] == len(exp["records"]) and c2["nmatchlines"] == exp["nmatchlines"]
+    sc.close(); pat.close()
