@@ -94,7 +94,7 @@ struct Counters {
    uint64_t records;
    uint64_t headers;
    /* workspace overflow report */
-   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant; 64: a hit entry points outside its segment (a bug: the scan fails) */
+   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant; 64: a hit entry points outside its segment (a bug: the scan fails); 128: k_pair, a line with candidates on both sides of a seam; 256: long lines, a leader's fresh start lies inside the walk before it (the run is void, the next one keeps a line in one lane) */
    uint32_t need_lines;     /* max over segments */
    uint32_t need_hitlines;  /* max over segments */
    uint32_t seg_novf;       /* k_exact1: 1 when a wave's overflow list (emissions beyond the first of their lines, COUNT -> EMIT) did not fit */
@@ -138,6 +138,7 @@ struct ScanArgs {
    uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
    uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: m + tau - 1 */
    const uint32_t *hit_last;    /* packed read batches: per hit line the column of its LAST candidate (else NULL: the repeats in the hit list say) */
+   uint32_t       *walk_end;    /* long lines, leaders (seeq_stream.h): per entry where the walk of the group before it ended; NULL: off */
    const uint32_t *hit_idx;     /* several patterns, one walk: this pattern's list holds indices into the shared per-line arrays (else NULL) */
    uint32_t       window_ok;    /* k_pair: every candidate the walk dropped is announced (nh[] bit 1 of the kept one) and repeats of a line
                                    follow it in the hit list -- a line with ONE candidate is scanned over that candidate's window only */
@@ -891,6 +892,7 @@ struct ScanKnobs {
    int  pair_exp;        /* SEEQ_PAIR_EXP=2..4: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
    bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
+   bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -931,6 +933,7 @@ struct seeqdev_scan {
    int last_path;                 /* 1 generic, 2 fused: what the last run used */
    seeqdev_hit_t *records; uint64_t *rec_off; size_t cap_records;
    uint32_t *scan_ws;           size_t cap_scan_ws;
+   uint32_t *lead_fidx, *lead_flag, *lead_wend; size_t cap_lead;      /* long lines, leaders (seeq_stream.h): per hit-list entry */
    Counters *d_cnt;
    Counters *h_cnt;            /* pinned */
    /* seeqdevStringMatch: one string per call in ONE launch (pinned, device-visible) */
@@ -974,6 +977,7 @@ struct seeqdev_scan {
    bool no_stream;             /* k_stream met a line it cannot address (starts > 1 GiB before its segment): use the per-line kernels */
    bool force_ll;              /* a read-length looking buffer had hits inside very long lines: use k_stream's long-line variant */
    bool no_stream_nd;          /* SQ_CONVERT / SQ_IGNORE: the text has non-DNA bytes, k_stream (exact for clean text only) is off */
+   bool no_leaders;            /* long lines with many hits: a leader's fresh start lay inside the walk before it -- every line stays with one lane */
    bool no_window;             /* k_pair's candidates: a line had candidates on both sides of a segment seam -- whole lines are scanned */
    int  fallback_ttl;          /* scans left before the three fall-back flags above are dropped and the fast path is tried again (one text with a
                                   long line or foreign bytes must not slow a long-lived context down for good) */
@@ -1023,6 +1027,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       const char *v;
       v = getenv("SEEQ_FUSED_KERNEL"); kn.kernel = v ? (!strcmp(v, "stream") ? 1 : !strcmp(v, "direct") ? 2 : !strcmp(v, "pair") ? 3 : 0) : 0;
       v = getenv("SEEQ_DFA_WGS");      kn.wgs_per_cu = v ? atoi(v) : 0;
+      v = getenv("SEEQ_NO_LEADERS");   kn.no_leaders = v && atoi(v) == 1;
       v = getenv("SEEQ_TILE_BYTES");   kn.tile_bytes = v ? atoi(v) : 0;
       v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
@@ -1062,7 +1067,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    multi_plan_free(s->mplan);
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
-                   s->nh, s->hit_col, s->records, s->scan_ws, s->d_cnt, s->d_text};
+                   s->nh, s->hit_col, s->records, s->scan_ws, s->lead_fidx, s->lead_flag, s->lead_wend, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
    if (s->h_eqtab) (void)hipHostFree(s->h_eqtab);
@@ -1610,6 +1615,23 @@ static int run_segments(seeqdev_scan *s)
             HIP_TRY(hipGetLastError(), EIO);
             continue;
          }
+         /* long lines, every hit counted: candidates far behind the one before them get a lane of their own (seeq_stream.h, leaders) */
+         const bool leaders = use_stream && stream_ll && nh_is_count && use_fused && !generic_exact && !kn.no_leaders && !s->no_leaders;
+         const uint32_t lead_wback = a.skip_back > 32u ? a.skip_back : 32u;
+         if (leaders) {
+            if (s->cap_hitlines > s->cap_lead) {
+               if (ws_alloc((void **)&s->lead_fidx, s->cap_hitlines * sizeof(uint32_t))) return -1;
+               if (ws_alloc((void **)&s->lead_flag, s->cap_hitlines * sizeof(uint32_t))) return -1;
+               if (ws_alloc((void **)&s->lead_wend, s->cap_hitlines * sizeof(uint32_t))) return -1;
+               s->cap_lead = s->cap_hitlines;
+            }
+            const unsigned nbl = (unsigned)(s->cap_hitlines / LEAD_BLOCK + 1);
+            hipLaunchKernelGGL(k_lead_reduce, dim3(nbl), dim3(256), 0, st, a, s->scan_ws);
+            hipLaunchKernelGGL(k_lead_top, dim3(1), dim3(256), 0, st, a, s->scan_ws);
+            hipLaunchKernelGGL(k_lead_apply, dim3(nbl), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->scan_ws, s->lead_fidx, s->lead_flag, ow.tmp, lead_wback);
+            a.walk_end = s->lead_wend;
+            hipLaunchKernelGGL(k_lead_commit, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col, (const uint4 *)ow.tmp);
+         }
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
          uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? ow.tmp : nullptr;   /* COUNT -> EMIT */
          /* (Tried behind k_pair: a lane-queue kernel -- a wave owns 256 .. 512 hit-list entries staged in LDS and a lane that has
@@ -1627,7 +1649,11 @@ static int run_segments(seeqdev_scan *s)
             }
             else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, st, a);
             /* lines with >= 1 verified hit: with 0/1 verdicts that is the scan total (seg_nrec) -- no extra pass */
-            if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
+            if (leaders) {
+               hipLaunchKernelGGL(k_lead_check, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->lead_flag, lead_wback);
+               hipLaunchKernelGGL(k_lead_lines, dim3(grid_hits < 512 ? grid_hits : 512), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_flag);
+            }
+            else if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
             launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */
@@ -1991,7 +2017,7 @@ static int scan_setup(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const voi
    s->pat = pat; s->text = d_text; s->nbytes = nbytes; s->options = options; s->want = want;
    s->ran = false;
    s->is_packed = false;
-   if ((s->no_stream || s->no_stream_nd || s->force_ll || s->no_window) && --s->fallback_ttl <= 0) s->no_stream = s->no_stream_nd = s->force_ll = s->no_window = false;
+   if ((s->no_stream || s->no_stream_nd || s->force_ll || s->no_window || s->no_leaders) && --s->fallback_ttl <= 0) s->no_stream = s->no_stream_nd = s->force_ll = s->no_window = s->no_leaders = false;
    /* Optimistic default workspace: lines average >= 32 bytes, one line in 8 hits, 1 record per hit line.
       A too-small workspace is detected on the device and fixed by one re-run in seeqdevScanFetch. */
    const size_t seg = nbytes < s->seg_bytes ? nbytes : s->seg_bytes;
@@ -2068,7 +2094,8 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
       if (h.overflow & 16u) s->no_stream_nd = true;
       if (h.overflow & 32u) s->force_ll = true;
       if (h.overflow & 128u) s->no_window = true;            /* a line with candidates on both sides of a segment seam */
-      if (h.overflow & (8u | 16u | 32u | 128u)) s->fallback_ttl = 32;
+      if (h.overflow & 256u) s->no_leaders = true;           /* a leader's fresh start inside the walk before it */
+      if (h.overflow & (8u | 16u | 32u | 128u | 256u)) s->fallback_ttl = 32;
       if (h.overflow & 4u) {
          /* need_records keeps counting after the overflow, so it is the total of this run. */
          nrec = (size_t)h.need_records + (size_t)(h.need_records >> 3) + 64;

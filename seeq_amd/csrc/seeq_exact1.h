@@ -401,7 +401,13 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
             if (pos >= wend) {
                /* the window is done and the columns behind are clean: nothing can hide before the next candidate */
                for (;;) {
-                  if (!(knext < nhl && a.hit_start[knext] == 0xFFFFFFFFu)) { done = true; break; }   /* no candidate left */
+                  if (!(knext < nhl && a.hit_start[knext] == 0xFFFFFFFFu)) {                       /* no candidate left */
+                     /* (seeq_stream.h, leaders: the entry behind my group learns where my walk ended -- k_lead_check holds its
+                        fresh start against it) */
+                     if (MODE == SQ_MODE_COUNT && a.walk_end && knext < nhl) a.walk_end[knext] = hs + pos;
+                     done = true;
+                     break;
+                  }
                   const uint32_t cpos = hit_col[knext++];                 /* position of the repeat's first hit */
                   const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs;
                   if (ccol > pos + wback && exact1_clean(a, off + pos, off + ccol - wback)) {   /* jump: fresh column `wback` columns before it */

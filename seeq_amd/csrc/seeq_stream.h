@@ -638,4 +638,182 @@ __global__ __launch_bounds__(256) void k_stream_bounds(ScanArgs a, uint32_t *hit
    }
 }
 
+/* ==========================================================================================================================
+ * Long lines with MANY hits (the dense cells of the reference's published sweep: 10^4 .. 10^6 records in 24 chromosome
+ * lines): the exact pass walks a line's candidates one after the other in one lane.  Where every hit is counted (SQ_ALL
+ * records, COUNTMATCH) a candidate far enough behind the one before it may be walked by a lane of its own: between two
+ * candidate chunks with a candidate-free chunk between them no hit ends (the scan kernel's verdict), the window of the
+ * earlier one ends inside that free chunk at the latest (it is extended while the last columns of a chunk hold a score
+ * <= tau, and a free chunk holds none), and the walk would jump to `wback` columns before the later candidate with a fresh
+ * column anyway (k_exact1, WALK).  Such a candidate -- a LEADER -- gets what a line's first entry has: the line's start in
+ * hit_start[], its column in hit_col[]; the entries behind it up to the next leader stay its repeats.  k_exact1 runs
+ * unchanged; hits per entry add up per line as before, and the lines with a hit are counted once each (k_lead_lines).
+ * Clean text only (a gap is jumped only when it is proven clean: with foreign bytes about, the line stays with one lane).
+ * ========================================================================================================================== */
+static constexpr int LEAD_ITEMS = 8;
+static constexpr int LEAD_BLOCK = 256 * LEAD_ITEMS;
+
+__device__ __forceinline__ uint32_t lead_block_incl_max(uint32_t v, uint32_t *s_wave /* >= 4 */)
+{
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   uint32_t x = v;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x = x > y ? x : y;
+   }
+   if (lane == 63) s_wave[wave] = x;
+   __syncthreads();
+   uint32_t before = 0;
+   for (int w = 0; w < wave; w++) before = before > s_wave[w] ? before : s_wave[w];
+   __syncthreads();
+   return x > before ? x : before;
+}
+
+/* per block of LEAD_BLOCK entries: index + 1 of its last first-entry (0: none) */
+__global__ __launch_bounds__(256) void k_lead_reduce(ScanArgs a, uint32_t *bmax)
+{
+   __shared__ uint32_t s_wave[4];
+   const uint32_t nhl = a.cnt->seg_nhitlines;
+   const uint32_t base = blockIdx.x * LEAD_BLOCK;
+   if (base >= nhl) return;
+   uint32_t v = 0;
+#pragma unroll
+   for (int i = 0; i < LEAD_ITEMS; i++) {
+      const uint32_t k = base + threadIdx.x * LEAD_ITEMS + i;
+      if (k < nhl && a.hit_start[k] != 0xFFFFFFFFu) v = k + 1u;
+   }
+   const uint32_t m = lead_block_incl_max(v, s_wave);
+   if (threadIdx.x == 255) bmax[blockIdx.x] = m;
+}
+
+/* exclusive prefix maximum over the blocks (one workgroup) */
+__global__ __launch_bounds__(256) void k_lead_top(ScanArgs a, uint32_t *bmax)
+{
+   __shared__ uint32_t s_wave[4];
+   const uint32_t nb = (a.cnt->seg_nhitlines + LEAD_BLOCK - 1) / LEAD_BLOCK;
+   uint32_t running = 0;
+   for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
+      const uint32_t i = b0 + threadIdx.x;
+      const uint32_t v = i < nb ? bmax[i] : 0u;
+      const uint32_t incl = lead_block_incl_max(v, s_wave);
+      const uint32_t prev = __shfl_up(incl, 1, 64);
+      __shared__ uint32_t s_last[4];
+      if ((threadIdx.x & 63) == 63) s_last[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      uint32_t excl = (threadIdx.x & 63) ? prev : (threadIdx.x >> 6 ? s_last[(threadIdx.x >> 6) - 1] : 0u);
+      excl = excl > running ? excl : running;
+      if (i < nb) bmax[i] = excl;
+      running = running > s_last[3] ? running : s_last[3];
+      __syncthreads();
+   }
+}
+
+/* fidx[k] = index of the first entry of k's line (0xFFFFFFFF: that entry belongs to the segment before); leaders marked in
+   tmp[k] = {leader ? 1 : 0, line start, column, 0} -- committed by k_lead_commit once every lane has read its neighbour */
+__global__ __launch_bounds__(256) void k_lead_apply(ScanArgs a, const uint32_t *hit_col, const uint32_t *bmax, uint32_t *fidx, uint32_t *lflag, uint4 *tmp,
+                                                    uint32_t wback)
+{
+   __shared__ uint32_t s_wave[4];
+   const Counters *c = a.cnt;
+   const uint32_t nhl = c->seg_nhitlines;
+   const uint32_t base = blockIdx.x * LEAD_BLOCK;
+   if (base >= nhl) return;
+   uint32_t item[LEAD_ITEMS];
+   uint32_t v = 0;
+#pragma unroll
+   for (int i = 0; i < LEAD_ITEMS; i++) {
+      const uint32_t k = base + threadIdx.x * LEAD_ITEMS + i;
+      if (k < nhl && a.hit_start[k] != 0xFFFFFFFFu) v = k + 1u;
+      item[i] = v;                                         /* running maximum inside the thread */
+   }
+   const uint32_t incl = lead_block_incl_max(v, s_wave);
+   uint32_t before = __shfl_up(incl, 1, 64);
+   __shared__ uint32_t s_last[4];
+   if ((threadIdx.x & 63) == 63) s_last[threadIdx.x >> 6] = incl;
+   __syncthreads();
+   before = (threadIdx.x & 63) ? before : (threadIdx.x >> 6 ? s_last[(threadIdx.x >> 6) - 1] : 0u);
+   const uint32_t bprev = bmax[blockIdx.x];
+   before = before > bprev ? before : bprev;
+   const bool promote = c->dirty == 0u;
+   const uint32_t ch = a.stream_ch;
+   const uint32_t lastnl = c->seg_last_nl;
+   const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
+#pragma unroll
+   for (int i = 0; i < LEAD_ITEMS; i++) {
+      const uint32_t k = base + threadIdx.x * LEAD_ITEMS + i;
+      if (k >= nhl) break;
+      const uint32_t f1 = item[i] > before ? item[i] : before;      /* first entry of my line, + 1 */
+      fidx[k] = f1 ? f1 - 1u : 0xFFFFFFFFu;
+      const uint32_t hs = a.hit_start[k];
+      uint4 t = make_uint4(0u, 0u, 0u, 0u);
+      if (hs != 0xFFFFFFFFu || !(promote && f1 && k > 0)) lflag[k] = 0u;      /* (a first entry's flag: "the line has a hit", set by k_lead_lines) */
+      if (hs == 0xFFFFFFFFu && promote && f1 && k > 0) {
+         /* positions relative to the segment's (biased) base: a repeat holds its own, a first entry start + column */
+         const uint32_t ps = a.hit_start[k - 1];
+         const uint32_t pabs = ps != 0xFFFFFFFFu ? ps + hit_col[k - 1] : hit_col[k - 1];
+         const uint32_t abs_ = hit_col[k];
+         const uint32_t free_end = ((pabs / ch) + 2u) * ch;          /* end of the chunk behind the previous candidate's */
+         const uint32_t ls = a.hit_start[f1 - 1u];
+         /* (k_exact1 walks windows only in lines that end inside the segment: the same test) */
+         const bool win = ls != 0xFFFFFFFFu && (last_seg || (lastnl != 0u && (int64_t)ls - (int64_t)a.pos_bias < (int64_t)lastnl));
+         if (win && abs_ >= free_end + wback + 64u) {          /* (the walk advances in blocks of 64 columns) */
+            t = make_uint4(1u, ls, abs_ - ls, 0u);
+            lflag[k] = 2u;                                  /* a leader: k_lead_check looks at it */
+         } else {
+            lflag[k] = 0u;
+         }
+      }
+      tmp[k] = t;
+   }
+}
+
+__global__ __launch_bounds__(256) void k_lead_commit(ScanArgs a, uint32_t *hit_col, const uint4 *tmp)
+{
+   const uint32_t nhl = a.cnt->seg_nhitlines;
+   const uint32_t stride = gridDim.x * 256;
+   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
+      const uint4 t = tmp[k];
+      if (t.x) { a.hit_start[k] = t.y; hit_col[k] = t.z; a.walk_end[k] = 0xFFFFFFFFu; }      /* (walk_end: "not yet vouched for" -- the walk before it writes where it stopped) */
+   }
+}
+
+/* lines with >= 1 hit, each once: nh[] holds the entries' hit counts; per wave one atomic pair per line it sees */
+__global__ __launch_bounds__(256) void k_lead_lines(ScanArgs a, const uint32_t *fidx, uint32_t *lflag)
+{
+   const uint32_t nhl = a.cnt->seg_nhitlines;
+   const uint32_t stride = gridDim.x * 256;
+   const uint32_t kmax = (nhl + stride - 1) / stride * stride;
+   const uint32_t lane = threadIdx.x & 63u;
+   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < kmax; k += stride) {
+      const bool live = k < nhl;
+      const uint32_t f = live ? fidx[k] : 0xFFFFFFFEu;
+      const bool has = live && f != 0xFFFFFFFFu && a.nh[k] != 0u;
+      const uint32_t fprev = __shfl_up(f, 1, 64);
+      const bool head = lane == 0 || f != fprev;
+      const uint64_t heads = __ballot(head), hass = __ballot(has);
+      if (head) {
+         const uint64_t above = lane == 63 ? 0ull : heads >> (lane + 1u);
+         const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+         const uint64_t seg = (hass >> lane) & (len >= 64u ? ~0ull : ((1ull << len) - 1ull));
+         if (seg && f < 0xFFFFFFFEu && atomicExch(&lflag[f], 1u) == 0u) atomicAdd(&a.cnt->seg_nmatch, 1u);
+      }
+   }
+}
+
+/* after COUNT: every leader's fresh start (wback columns before its candidate) must lie behind the end of the walk before
+   it -- else that walk would have gone on into the leader's window (a score <= tau near the end of every chunk between them:
+   periodic patterns in periodic text) and the two lanes have counted the stretch twice: the run is void (overflow 256) */
+__global__ __launch_bounds__(256) void k_lead_check(ScanArgs a, const uint32_t *hit_col, const uint32_t *lflag, uint32_t wback)
+{
+   const uint32_t nhl = a.cnt->seg_nhitlines;
+   const uint32_t stride = gridDim.x * 256;
+   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
+      if (lflag[k] != 2u) continue;
+      const uint32_t abs_ = a.hit_start[k] + hit_col[k];
+      /* (a walk that ran on to the end of its line never looked at this entry: the mark of k_lead_commit is still there) */
+      if (!((uint64_t)abs_ > (uint64_t)a.walk_end[k] + wback)) atomicOr(&a.cnt->overflow, 256u);
+   }
+}
+
 #endif

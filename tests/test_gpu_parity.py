@@ -1449,3 +1449,57 @@ def test_published_sweep_cells_small(gpu, capi, oracle, m, k):
     c2 = sc.scan_host(pat, buf, 0, dev.WANT_COUNTMATCH)
     assert c2["nhits"] == len(exp["records"]) and c2["nmatchlines"] == exp["nmatchlines"]
     sc.close(); pat.close()
+
+
+LEADERS = r"""
+import os, sys, random, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from oracle.pyoracle import Oracle, SQ_ALL, SQ_BEST
+from seeq_amd import device as dev
+from test_gpu_parity import _mutate
+o = Oracle()
+rng = random.Random(%(seed)d)
+cases = [("GATGTAGCGCGATTAGCCTG", 4, 2500, "random"), ("GATGTAGCGCGATTAGCCTGAAAATGCGAGTACGGCGCGAAT", 12, 1500, "random"),
+         ("AAAAAAAAAAAAAAAAAAAA", 3, 300, "polyA"), ("ACACACACACACACACACACACAC", 4, 300, "periodic")]
+for pattern, tau, nplant, kind in cases:
+    lines = []
+    for i in range(4):
+        n = rng.choice([300_000, 500_000])
+        t = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(nplant):
+            if kind == "random":
+                c = _mutate(rng, pattern, rng.randint(0, tau + 1))
+            elif kind == "polyA":
+                c = "A" * rng.randint(10, 700)                       # runs far longer than a chunk: the walk goes on from chunk to chunk
+            else:
+                c = "AC" * rng.randint(5, 400)
+            q = rng.randrange(n - len(c))
+            t[q:q + len(c)] = list(c)
+        lines.append("".join(t))
+    buf = ("\n".join(lines) + "\n").encode()
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner()
+    exp = o.buffer_scan(pattern, tau, buf, SQ_ALL)
+    got = sc.scan_host(pat, buf, SQ_ALL, dev.WANT_RECORDS)
+    assert got["nlines"] == 4 and got["nmatchlines"] == exp["nmatchlines"], (pattern, got["nmatchlines"], exp["nmatchlines"])
+    assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, kind, len(got["records"]), len(exp["records"]))
+    c2 = sc.scan_host(pat, buf, 0, dev.WANT_COUNTMATCH)
+    assert c2["nhits"] == len(exp["records"]) and c2["nmatchlines"] == exp["nmatchlines"], (pattern, kind)
+    gb = sc.scan_host(pat, buf, SQ_BEST, dev.WANT_RECORDS)
+    assert np.array_equal(gb["records"].astype(np.uint64), o.buffer_scan(pattern, tau, buf, SQ_BEST)["records"]), (pattern, kind)
+    print(pattern[:12], kind, len(exp["records"]), "records", sc.last_kernel())
+    sc.close(); pat.close()
+print("LEADERS OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"SEEQ_NO_LEADERS": "1"}, {"SEEQ_SEGMENT_BYTES": "1048576"}], ids=["leaders", "one-lane-per-line", "1MiB-segments"])
+def test_long_lines_with_many_hits(gpu, capi, oracle, env):
+    """Long lines whose candidates are counted in the thousands (the dense cells of the published sweep): candidates far
+    behind the one before them are walked by lanes of their own (seeq_stream.h, leaders) -- random text with thousands of
+    planted copies, and periodic text (poly-A runs, AC repeats of up to 800 bytes) where the walk of one candidate runs
+    on into the next one's window: there the run is declared void and repeated with one lane per line.  Every record of
+    `--all`, both counts and `--best` against the oracle; also with the leaders switched off and with 1 MiB segments."""
+    code = LEADERS % dict(root=ROOT, seed=12)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+    assert r.returncode == 0 and "LEADERS OK" in r.stdout, (r.stdout[-600:], r.stderr[-3000:])
