@@ -981,6 +981,7 @@ struct seeqdev_scan {
    bool no_window;             /* k_pair's candidates: a line had candidates on both sides of a segment seam -- whole lines are scanned */
    int  fallback_ttl;          /* scans left before the three fall-back flags above are dropped and the fast path is tried again (one text with a
                                   long line or foreign bytes must not slow a long-lived context down for good) */
+   bool sample_dirty;          /* the sampled prefix holds more than one byte outside the alphabet per 4 KB: k_pair stays out */
    unsigned sample_age;        /* runs since the line-length sample was taken (a reused buffer may hold other text by now) */
 };
 
@@ -1368,7 +1369,7 @@ static int run_segments(seeqdev_scan *s)
       const int nd = options & MASK_NONDNA;
       const bool long_lines = (s->avg_line > 600.0 && kn.kernel != 3) || s->force_ll;      /* (a candidate inside a line of a whole tile sets force_ll) */
       if (fusable && s->force_path != 1 && (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || nd == SQ_CONVERT) && !long_lines && !s->no_stream &&
-          (kn.kernel == 0 || kn.kernel == 3) && s->seg_bytes % (64u * 128u) == 0) {
+          (kn.kernel == 3 || (kn.kernel == 0 && !(s->sample_dirty && s->line_hint <= 0))) && s->seg_bytes % (64u * 128u) == 0) {
          seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
          if (__atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
          use_pair = mp->pair_state == 1 && (kn.kernel == 3 || s->multi_active || mp->pair_pacc * s->avg_line <= 0.25);
@@ -2041,8 +2042,17 @@ static int scan_setup(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const voi
       HIP_TRY(hipMemcpyAsync(s->h_sample, d_text, n, hipMemcpyDeviceToHost, s->stream), EIO);
       HIP_TRY(hipStreamSynchronize(s->stream), EIO);
       size_t nl = 0;
-      for (size_t i = 0; i < n; i++) nl += s->h_sample[i] == '\n';
+      size_t foreign = 0;                                  /* bytes outside A C G T N (either case) and newline; FASTA: outside the header lines */
+      bool header = (options & SEEQDEV_FASTA) && n && s->h_sample[0] == '>';
+      for (size_t i = 0; i < n; i++) {
+         const uint8_t b = s->h_sample[i];
+         if (b == '\n') { nl++; header = (options & SEEQDEV_FASTA) && i + 1 < n && s->h_sample[i + 1] == '>'; }
+         else if (!header) foreign += sq_class_of(b, 0) >= 5;
+      }
       s->avg_line = nl ? (double)n / (double)nl : 1e9;
+      /* more than one foreign byte per 4 KB (FASTQ: every quality line): nearly every 8 KB tile of k_pair would take its slow
+         path (exact alphabet check over the text fetched again) -- k_stream walks such text at full speed */
+      s->sample_dirty = foreign * 4096 > n;
       s->avg_text = d_text;
       s->avg_nbytes = nbytes;
    }

