@@ -933,7 +933,7 @@ struct seeqdev_scan {
    int last_path;                 /* 1 generic, 2 fused: what the last run used */
    seeqdev_hit_t *records; uint64_t *rec_off; size_t cap_records;
    uint32_t *scan_ws;           size_t cap_scan_ws;
-   uint32_t *lead_fidx, *lead_flag, *lead_wend; size_t cap_lead;      /* long lines, leaders (seeq_stream.h): per hit-list entry */
+   uint32_t *lead_fidx, *lead_flag, *lead_wend; unsigned long long *lead_key; size_t cap_lead;      /* long lines, leaders (seeq_stream.h): per hit-list entry */
    Counters *d_cnt;
    Counters *h_cnt;            /* pinned */
    /* seeqdevStringMatch: one string per call in ONE launch (pinned, device-visible) */
@@ -1068,7 +1068,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    multi_plan_free(s->mplan);
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
-                   s->nh, s->hit_col, s->records, s->scan_ws, s->lead_fidx, s->lead_flag, s->lead_wend, s->d_cnt, s->d_text};
+                   s->nh, s->hit_col, s->records, s->scan_ws, s->lead_fidx, s->lead_flag, s->lead_wend, s->lead_key, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
    if (s->h_eqtab) (void)hipHostFree(s->h_eqtab);
@@ -1617,20 +1617,25 @@ static int run_segments(seeqdev_scan *s)
             continue;
          }
          /* long lines, every hit counted: candidates far behind the one before them get a lane of their own (seeq_stream.h, leaders) */
-         const bool leaders = use_stream && stream_ll && nh_is_count && use_fused && !generic_exact && !kn.no_leaders && !s->no_leaders;
+         const bool lead_best = want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST;      /* (one record per line: the groups' best hits are reduced per line) */
+         const bool leaders = use_stream && stream_ll && (nh_is_count || lead_best) && use_fused && !generic_exact && !kn.no_leaders && !s->no_leaders;
          const uint32_t lead_wback = a.skip_back > 32u ? a.skip_back : 32u;
          if (leaders) {
             if (s->cap_hitlines > s->cap_lead) {
                if (ws_alloc((void **)&s->lead_fidx, s->cap_hitlines * sizeof(uint32_t))) return -1;
                if (ws_alloc((void **)&s->lead_flag, s->cap_hitlines * sizeof(uint32_t))) return -1;
                if (ws_alloc((void **)&s->lead_wend, s->cap_hitlines * sizeof(uint32_t))) return -1;
+               if (ws_alloc((void **)&s->lead_key, s->cap_hitlines * sizeof(unsigned long long))) return -1;
                s->cap_lead = s->cap_hitlines;
             }
             const unsigned nbl = (unsigned)(s->cap_hitlines / LEAD_BLOCK + 1);
             hipLaunchKernelGGL(k_lead_reduce, dim3(nbl), dim3(256), 0, st, a, s->scan_ws);
             hipLaunchKernelGGL(k_lead_top, dim3(1), dim3(256), 0, st, a, s->scan_ws);
-            hipLaunchKernelGGL(k_lead_apply, dim3(nbl), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->scan_ws, s->lead_fidx, s->lead_flag, ow.tmp, lead_wback);
+            hipLaunchKernelGGL(k_lead_apply, dim3(nbl), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->scan_ws, s->lead_fidx, s->lead_flag, ow.tmp, lead_wback, lead_best ? s->lead_key : (unsigned long long *)nullptr);
             a.walk_end = s->lead_wend;
+            /* SQ_BEST: COUNT has to walk every group itself (and leave each group's best hit in the cache) instead of trusting the hit
+               list and leaving the scan to EMIT, one lane per line */
+            if (lead_best) a.filter = 1u;
             hipLaunchKernelGGL(k_lead_commit, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col, (const uint4 *)ow.tmp);
          }
          const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
@@ -1652,7 +1657,11 @@ static int run_segments(seeqdev_scan *s)
             /* lines with >= 1 verified hit: with 0/1 verdicts that is the scan total (seg_nrec) -- no extra pass */
             if (leaders) {
                hipLaunchKernelGGL(k_lead_check, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->lead_flag, lead_wback);
-               hipLaunchKernelGGL(k_lead_lines, dim3(grid_hits < 512 ? grid_hits : 512), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_flag);
+               if (lead_best) {
+                  hipLaunchKernelGGL(k_lead_best, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_key, (const uint4 *)ecache, 0);
+                  hipLaunchKernelGGL(k_lead_best, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_key, (const uint4 *)ecache, 1);
+               }
+               else hipLaunchKernelGGL(k_lead_lines, dim3(grid_hits < 512 ? grid_hits : 512), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_flag);
             }
             else if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
             launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);

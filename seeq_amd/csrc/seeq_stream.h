@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void k_lead_top(ScanArgs a, uint32_t *bmax)
 /* fidx[k] = index of the first entry of k's line (0xFFFFFFFF: that entry belongs to the segment before); leaders marked in
    tmp[k] = {leader ? 1 : 0, line start, column, 0} -- committed by k_lead_commit once every lane has read its neighbour */
 __global__ __launch_bounds__(256) void k_lead_apply(ScanArgs a, const uint32_t *hit_col, const uint32_t *bmax, uint32_t *fidx, uint32_t *lflag, uint4 *tmp,
-                                                    uint32_t wback)
+                                                    uint32_t wback, unsigned long long *lkey)
 {
    __shared__ uint32_t s_wave[4];
    const Counters *c = a.cnt;
@@ -747,6 +747,7 @@ __global__ __launch_bounds__(256) void k_lead_apply(ScanArgs a, const uint32_t *
       fidx[k] = f1 ? f1 - 1u : 0xFFFFFFFFu;
       const uint32_t hs = a.hit_start[k];
       uint4 t = make_uint4(0u, 0u, 0u, 0u);
+      if (hs != 0xFFFFFFFFu && lkey) lkey[k] = ~0ull;       /* (SQ_BEST: the line's best group, k_lead_best) */
       if (hs != 0xFFFFFFFFu || !(promote && f1 && k > 0)) lflag[k] = 0u;      /* (a first entry's flag: "the line has a hit", set by k_lead_lines) */
       if (hs == 0xFFFFFFFFu && promote && f1 && k > 0) {
          /* positions relative to the segment's (biased) base: a repeat holds its own, a first entry start + column */
@@ -813,6 +814,22 @@ __global__ __launch_bounds__(256) void k_lead_check(ScanArgs a, const uint32_t *
       const uint32_t abs_ = a.hit_start[k] + hit_col[k];
       /* (a walk that ran on to the end of its line never looked at this entry: the mark of k_lead_commit is still there) */
       if (!((uint64_t)abs_ > (uint64_t)a.walk_end[k] + wback)) atomicOr(&a.cnt->overflow, 256u);
+   }
+}
+
+/* SQ_BEST with leaders: every group of a line has found ITS best hit (nh[k] = 1, the hit in the COUNT -> EMIT cache); the
+   line's record is the one with the smallest distance, the first of those: atomicMin over {distance, entry} per line, then
+   the groups that lost give up their record slot. */
+__global__ __launch_bounds__(256) void k_lead_best(ScanArgs a, const uint32_t *fidx, unsigned long long *lkey, const uint4 *cache, int pass)
+{
+   const uint32_t nhl = a.cnt->seg_nhitlines;
+   const uint32_t stride = gridDim.x * 256;
+   for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nhl; k += stride) {
+      if (a.nh[k] == 0u) continue;
+      const uint32_t f = fidx[k];
+      if (f == 0xFFFFFFFFu) continue;
+      if (pass == 0) atomicMin(&lkey[f], ((unsigned long long)cache[k].y << 32) | k);
+      else if ((uint32_t)lkey[f] != k) a.nh[k] = 0u;
    }
 }
 
