@@ -78,72 +78,8 @@ extern "C" int seeqdevSetDevice(int device)
    return 0;
 }
 
-/* ========================================================================== */
-/* Device-side bookkeeping                                                    */
-/* ========================================================================== */
-struct Counters {
-   /* per segment */
-   uint32_t seg_nlines;     /* raw lines starting in the segment (FASTA headers included) */
-   uint32_t seg_nhitlines;
-   uint32_t seg_nheaders;
-   uint32_t seg_nrec;       /* hits (records) of the segment */
-   /* running totals over segments */
-   uint64_t lines;          /* counted lines (headers excluded) */
-   uint64_t matchlines;
-   uint64_t hits;
-   uint64_t records;
-   uint64_t headers;
-   /* workspace overflow report */
-   uint32_t overflow;       /* 1 lines, 2 hit lines, 4 records (workspace too small); 8, 16: k_stream cannot serve this text; 32: wants its long-line variant; 64: a hit entry points outside its segment (a bug: the scan fails); 128: k_pair, a line with candidates on both sides of a seam; 256: long lines, a leader's fresh start lies inside the walk before it (the run is void, the next one keeps a line in one lane) */
-   uint32_t need_lines;     /* max over segments */
-   uint32_t need_hitlines;  /* max over segments */
-   uint32_t seg_novf;       /* k_exact1: 1 when a wave's overflow list (emissions beyond the first of their lines, COUNT -> EMIT) did not fit */
-   uint32_t seg_nmatch;     /* lines of the segment with >= 1 verified hit (superset filters) */
-   uint32_t dirty;          /* k_stream: the text holds bytes outside {ACGTN, acgtn, '\n'}: its hit lines need verifying */
-   uint64_t need_records;   /* total */
-   uint32_t prev_hit_line;  /* k_stream: line number of the last hit line of the previous segment (a line can span segments) */
-   uint32_t seg_last_nl;    /* k_stream: segment-relative offset + 1 of the last newline of the segment (0: none) */
-   uint32_t seg_dirty_tiles; /* k_stream, long-line mode: tiles of the segment that hold a non-alphabet byte */
-   uint32_t pad4;
-};
-
-struct ScanArgs {
-   const uint8_t *text;      /* whole buffer */
-   uint64_t       nbytes;
-   uint64_t       seg_base;  /* first byte of the segment */
-   uint32_t       seg_len;
-   uint32_t       first_seg; /* 1 for segment 0 */
-   const uint32_t *peq;      /* [2][5][W]: forward, reverse */
-   int            m, tau, options, want;
-   uint32_t      *line_start;   uint32_t cap_lines;
-   uint32_t      *tile_cnt;     uint32_t ntiles;
-   uint64_t      *hitmask;
-   uint64_t      *hdrmask;
-   uint32_t      *wave_off;
-   uint32_t      *hdr_off;
-   uint32_t      *hit_start;    /* per hit line: segment-relative offset of its first byte */
-   uint32_t      *hit_line;     /* per hit line: 1-based counted line number (reference seeq.c:377) */
-   uint32_t       cap_hitlines;
-   uint32_t      *nh;           /* per hit line: hits, then exclusive offsets */
-   seeqdev_hit_t *records;      uint64_t cap_records;
-   uint64_t      *rec_off;      /* per record: byte offset (in the whole buffer) of the line it belongs to */
-   uint32_t       use_nh;       /* record slots / line verdicts come from the per-line counts nh[]: 1 = ALL, COUNTMATCH;
-                                   3 = k_stream (superset only when Counters.dirty or `filter`,
-                                   hit list may repeat a line: hit_start = 0xFFFFFFFF marks a repeat) */
-   uint32_t       pos_bias;     /* k_stream: seg_base here is the segment's base minus this (multiple of 128) */
-   const uint32_t *tile_dirty;  /* k_stream, long-line mode: exclusive prefix of the per-tile "holds a non-alphabet byte" flags */
-   const uint64_t *tile_dmask;  /* ... and per tile one bit per 128-byte chunk */
-   uint32_t       stream_ntiles, stream_tile_bytes;
-   uint32_t       stream_ch;    /* k_stream: bytes per lane chunk (0 = another kernel made the hit list) */
-   uint32_t       filter;       /* k_stream walked a partition FILTER automaton: every hit line is only a candidate */
-   uint32_t       skip_back;    /* columns before a candidate from which a fresh column gives exact scores: m + tau - 1 */
-   const uint32_t *hit_last;    /* packed read batches: per hit line the column of its LAST candidate (else NULL: the repeats in the hit list say) */
-   uint32_t       *walk_end;    /* long lines, leaders (seeq_stream.h): per entry where the walk of the group before it ended; NULL: off */
-   const uint32_t *hit_idx;     /* several patterns, one walk: this pattern's list holds indices into the shared per-line arrays (else NULL) */
-   uint32_t       window_ok;    /* k_pair: every candidate the walk dropped is announced (nh[] bit 1 of the kept one) and repeats of a line
-                                   follow it in the hit list -- a line with ONE candidate is scanned over that candidate's window only */
-   Counters      *cnt;
-};
+#include "seeq_types.h"
+#include "seeq_scan_common.h"
 
 static constexpr int WG = 256;           /* 4 waves */
 static constexpr int TILE = 16384;       /* bytes per newline-index workgroup: 64 B per thread */
@@ -155,38 +91,6 @@ static constexpr size_t SAMPLE_BYTES = 65536;     /* prefix sampled to estimate 
 /* ========================================================================== */
 /* Block-level helpers                                                        */
 /* ========================================================================== */
-/* Exclusive prefix sum over the 256 threads of a block; *total = block sum. */
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *s_wave /* >= 4 */)
-{
-   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   uint32_t x = v;
-#pragma unroll
-   for (int d = 1; d < 64; d <<= 1) {
-      uint32_t y = __shfl_up(x, d, 64);
-      if (lane >= d) x += y;
-   }
-   if (lane == 63) s_wave[wave] = x;
-   __syncthreads();
-   uint32_t base = 0, tot = 0;
-#pragma unroll
-   for (int w = 0; w < WG / 64; w++) {
-      uint32_t s = s_wave[w];
-      if (w < wave) base += s;
-      tot += s;
-   }
-   __syncthreads();
-   *total = tot;
-   return base + x - v;
-}
-
-/* Exact per-byte "== '\n'" flags of 4 packed bytes (bit 7 of each byte). */
-__device__ __forceinline__ uint32_t nl_flags(uint32_t w)
-{
-   const uint32_t x = w ^ 0x0A0A0A0Au;
-   const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
-   return ~t & 0x80808080u;
-}
-
 /* 64-bit mask of newline positions among the 64 bytes this thread owns
  * (bytes seg_base + tile*TILE + tid*64 ...), restricted to positions q with
  * q < seg_base+seg_len and q + 1 < nbytes (a final '\n' starts no line). */
@@ -445,13 +349,6 @@ __global__ void k_seg_mid(ScanArgs a)
    c->seg_nrec = nhl;            /* overwritten by the nh scan for SQ_ALL / COUNTMATCH */
 }
 
-/* Before the EMIT pass: do the records fit? */
-__device__ __forceinline__ void rec_check_body(const ScanArgs &a)
-{
-   Counters *c = a.cnt;
-   c->need_records = c->records + c->seg_nrec;     /* running total incl. this segment */
-   if (c->records + c->seg_nrec > a.cap_records) atomicOr(&c->overflow, 4u);
-}
 __global__ void k_rec_check(ScanArgs a) { rec_check_body(a); }
 
 /* ========================================================================== */
@@ -532,20 +429,6 @@ __device__ __forceinline__ void count_nonzero_body(const ScanArgs &a)
 }
 __global__ __launch_bounds__(WG) void k_count_nonzero(ScanArgs a) { count_nonzero_body(a); }
 
-__device__ __forceinline__ void seg_end_body(const ScanArgs &a, int flags /* 1: hits come from nh[]; 2: nh[] holds 0/1 verdicts, their sum = matching lines */)
-{
-   Counters *c = a.cnt;
-   const uint32_t counted = c->seg_nlines - c->seg_nheaders;
-   const uint32_t seg_hits = (flags & 1) ? c->seg_nrec : c->seg_nhitlines;
-   if (flags & 2) c->seg_nmatch = c->seg_nrec;
-   c->lines += counted;
-   c->headers += c->seg_nheaders;
-   c->matchlines += a.use_nh >= 2 ? c->seg_nmatch : c->seg_nhitlines;   /* >= 2: the filter was a superset */
-   if (a.use_nh == 3 && c->seg_nhitlines) c->prev_hit_line = a.hit_line[c->seg_nhitlines - 1];
-   c->hits += seg_hits;
-   if (a.want == SEEQDEV_WANT_RECORDS) c->records += seg_hits;
-   c->seg_nlines = c->seg_nhitlines = c->seg_nheaders = c->seg_nrec = c->seg_nmatch = c->seg_novf = 0;
-}
 __global__ void k_seg_end(ScanArgs a, int flags) { seg_end_body(a, flags); }
 
 /* SINGLELINE: the buffer is one string -> one line starting at 0. */
@@ -556,13 +439,14 @@ __global__ void k_single_line(ScanArgs a)
    a.line_start[0] = 0;
 }
 
-#include "seeq_scan_common.h"
+#include "seeq_fused_post.h"
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_stream.h"
 #include "seeq_pair.h"
 #include "seeq_packed.h"
 #include "seeq_multi.h"
+#include "seeq_post.h"
 static_assert(STREAM_NW == STREAM_NW_HOST, "waves per k_stream workgroup");
 extern "C" {
 #include "seeq_dfa.h"
@@ -893,6 +777,7 @@ struct ScanKnobs {
    bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
+   bool old_verify;      /* SEEQ_VERIFY=old: k_exact1<COUNT> + the three-launch scan behind the filters, as before round 4 (A/B, tests) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
 
@@ -913,7 +798,7 @@ struct seeqdev_scan {
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
-   uint32_t *hit_start, *hit_line, *nh, *hit_col; size_t cap_hitlines;
+   uint32_t *hit_start, *hit_line, *nh, *hit_col, *nh_sum; size_t cap_hitlines;      /* nh_sum: per 256 entries (k_verify) */
    /* one-pass kernels: what the scan kernel of a segment writes and its post-pass reads */
    struct OnePassWs {
       uint32_t *tile_cl, *tile_hits, *tile_dirty; uint64_t *tile_dmask;   /* [cap_ftiles] */
@@ -1037,6 +922,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_MYERS");     kn.no_myers = v && atoi(v) == 1;
       v = getenv("SEEQ_NO_WINDOW");    kn.no_window = v && atoi(v) == 1;
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
+      v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
       s->ncu = 256;
       int dev = 0;
       hipDeviceProp_t prop;
@@ -1068,7 +954,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    multi_plan_free(s->mplan);
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
-                   s->nh, s->hit_col, s->records, s->scan_ws, s->lead_fidx, s->lead_flag, s->lead_wend, s->lead_key, s->d_cnt, s->d_text};
+                   s->nh, s->hit_col, s->nh_sum, s->records, s->scan_ws, s->lead_fidx, s->lead_flag, s->lead_wend, s->lead_key, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
    if (s->h_eqtab) (void)hipHostFree(s->h_eqtab);
@@ -1127,6 +1013,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
       if (ws_alloc((void **)&s->ow.tmp, max_hitlines * sizeof(uint4))) return -1;
       if (ws_alloc((void **)&s->nh, max_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->hit_col, max_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->nh_sum, 2 * (max_hitlines / 256 + 2) * sizeof(uint32_t))) return -1;      /* + the chunks' entries with a hit */
       s->cap_hitlines = max_hitlines;
    }
    if (max_records > s->cap_records) {
@@ -1645,7 +1532,23 @@ static int run_segments(seeqdev_scan *s)
             slower, 296 against 257 us per segment: at 4 waves per SIMD the per-block loads of a lane are not hidden.  Not kept;
             tag r03-experiment-overlap-postpass holds it, profiles/r03/verify_ab.txt the numbers.) */
          /* ---- K4: hits per hit line ---- */
-         if (need_nh) {
+         /* behind the filters (every hit line is a candidate) on text where no byte is skipped: k_verify (seeq_verify.h) -- the lean
+            two-phase exact pass with the scan of its counts inside; the EMIT pass behind it ends the segment */
+         bool emitted = false;                                /* the records are out (k_emit1) */
+         const bool verify = need_nh && use_fused && !generic_exact && filter && !a.stream_ch && !kn.old_verify &&
+                             (options & (SQ_IGNORE | SQ_STREAM)) == 0 && !a.tile_dirty;
+         const int seg_flags = (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0);
+         if (verify) {
+            const bool count_any = want != SEEQDEV_WANT_COUNTMATCH && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+            const int var = (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST) ? VERIFY_BEST : count_any ? VERIFY_ANY : VERIFY_ALL;
+            a.nh_sum = s->nh_sum;
+            a.nz_sum = superset && nh_is_count ? s->nh_sum + (s->cap_hitlines / 256 + 2) : nullptr;
+            a.fin = want == SEEQDEV_WANT_RECORDS ? 0u : 1u + (uint32_t)seg_flags;      /* (no EMIT pass: k_nh_top ends the segment) */
+            seeq_launch_verify(fw, var, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
+            if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
+            emitted = want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL;
+         }
+         else if (need_nh) {
             if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
 #define SEEQ_COUNT1(WW, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, WW, -1, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
@@ -1667,8 +1570,8 @@ static int run_segments(seeqdev_scan *s)
             launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
          }
          /* ---- K5: records ---- */
-         if (want == SEEQDEV_WANT_RECORDS) {
-            hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);
+         if (want == SEEQDEV_WANT_RECORDS && !emitted) {
+            if (!verify) hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);      /* (k_verify's last workgroup did) */
             if (use_fused && !generic_exact) {
                const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
                const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
@@ -1688,7 +1591,7 @@ static int run_segments(seeqdev_scan *s)
             }
          }
       }
-      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));
+      if (!a.fin) hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));      /* (a.fin: the segment's last launch ended it) */
       if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
       HIP_TRY(hipGetLastError(), EIO);
    }

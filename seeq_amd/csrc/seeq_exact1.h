@@ -219,12 +219,12 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
             /* the line's further candidates are the repeats behind this entry (a third of the hit lines has one: an occurrence
                near the end of a chain is seen by the next chain's warm-up, which then reports its own first pair): the scan
                runs from before the first candidate to behind the last one */
-            uint32_t lastcol = a.hit_last ? a.hit_last[kk] : col, unbounded = a.nh[k] & 2u;      /* (hit_last: packed read batches -- the candidates of a read come as one entry) */
+            uint32_t lastcol = a.hit_last ? a.hit_last[kk] : col, unbounded = 0u;      /* (hit_last: packed read batches -- the candidates of a read come as one entry) */
             if (a.hit_idx) {                               /* the line's window is the union's: it ends maxspan (= skip_back) + 2 behind the last candidate; no last candidate: no end */
                unbounded = lastcol == 0xFFFFFFFFu ? 2u : 0u;
                lastcol += a.skip_back - (m + tau1 - 1u);
             }
-            else for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) { lastcol = hit_col[j] - hs; unbounded |= a.nh[j] & 2u; }
+            else for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) lastcol = hit_col[j] - hs;
             if (!unbounded) stop_at = lastcol + m + tau1 + 1u;
          }
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */
@@ -241,10 +241,10 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
       bool from_cache = false;
       if (MODE == SQ_MODE_EMIT && !done) {
          line_no = a.hit_line[kk];
-         if (match_opt == SQ_ALL) { out = a.records + c->records + a.nh[k]; out_cap = 0xFFFFFFFFu; }
-         else { out = a.records + c->records + (by_nh ? a.nh[k] : k); out_cap = 1; }
+         if (match_opt == SQ_ALL) { out = a.records + c->records + nh_at(a, k); out_cap = 0xFFFFFFFFu; }
+         else { out = a.records + c->records + (by_nh ? nh_at(a, k) : k); out_cap = 1; }
          if (cache_ok) {
-            ncached = (k + 1 < nhl ? a.nh[k + 1] : c->seg_nrec) - a.nh[k];
+            ncached = (k + 1 < nhl ? nh_at(a, k + 1) : c->seg_nrec) - nh_at(a, k);
             if (ncached <= 1 || !ovf_lost) {               /* the first record from the cache, the others from the overflow list */
                if (ncached) { const uint4 ce = cache[k]; ce0 = ce.x; ce1 = ce.y; cstart = ce.z; chas = ce.w; }
                from_cache = true;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
          const uint4 o = ovf[e];                                    /* {hit-list entry, index in the line, end, dist} */
          const uint32_t ox = a.hit_idx ? a.hit_idx[o.x] : o.x;
          const uint64_t off = a.seg_base + a.hit_start[ox];
-         const uint64_t slot = c->records + a.nh[o.x] + o.y;
+         const uint64_t slot = c->records + nh_at(a, o.x) + o.y;
          seeqdev_hit_t h;
          h.line = a.hit_line[ox];
          h.start = exact1_reverse<W>(a.text, off, a.nbytes, o.z, o.w, eqr_base, m, tau1, row);

@@ -97,9 +97,6 @@ __global__ __launch_bounds__(MULTI_RESOLVE_WG) void k_multi_resolve(MultiArgs a)
       bool all = whole;
       if (!repeat) {
          a.lfirst[k] = c;
-         uint32_t unbounded = a.nh[k] & 2u;                /* a chain dropped candidates of this line: the whole line */
-         for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) unbounded |= a.nh[j] & 2u;
-         all = all || unbounded != 0;
          if (all) { a.lfirst[k] = 0u; atomicMax(&a.llast[k], 0xFFFFFFFFu); }      /* (column 0: k_exact1 starts at the line's first byte and scans to its end) */
       }
       uint32_t from = c;

@@ -1,0 +1,23 @@
+/*
+ * seeq_post.h -- host-side launchers of the post-pass kernels that live in their own translation unit
+ * (seeq_verify.hip: compiled beside seeq_device.hip).
+ */
+#ifndef SEEQ_POST_H_
+#define SEEQ_POST_H_
+
+#include <hip/hip_runtime.h>
+#include "seeq_types.h"
+
+#define VERIFY_ANY  0          /* presence is enough, or the first emission is the record (SQ_FIRST / SQ_COUNT, line counts) */
+#define VERIFY_BEST 1          /* SQ_BEST records: the first emission with the smallest distance */
+#define VERIFY_ALL  2          /* every emission counts (SQ_ALL records, match counts) */
+
+/* k_verify<W, VAR> (seeq_verify.h) + k_nh_top: fw = column words (1, 2); var = VERIFY_ANY / _BEST / _ALL; grid workgroups of 256 (an
+   EMIT pass of k_exact1 behind it must use the same grid); a.nz_sum != NULL: Counters.seg_nmatch = entries with >= 1 hit;
+   a.fin != 0: k_nh_top ends the segment */
+void seeq_launch_verify(int fw, int var, unsigned grid, hipStream_t st, const ScanArgs &a, const uint32_t *eq, const uint32_t *hit_col,
+                        uint4 *cache);
+/* k_emit1: the records of a segment with one record per line at most, from k_verify's cache */
+void seeq_launch_emit1(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *cache);
+
+#endif

@@ -531,9 +531,8 @@ __global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t ns
             const uint32_t dst = th[u] + (e[u].y & 0x1FFFu);
             hit_start[dst] = e[u].z;
             hit_line[dst] = lines0 + tc[u] + e[u].w + 1u;   /* 1-based, reference seeq.c:377 */
-            /* bit 0: e.z is the hit itself (the line starts before the tile); bit 1 (k_pair): the chain dropped further
-               candidates of this line -- the exact pass must not stop behind this one's window */
-            unresolved[dst] = (e[u].x >> 31) | ((e[u].y >> 31) << 1);
+            /* 1: e.z is the hit itself (the line starts before the tile) */
+            unresolved[dst] = e[u].x >> 31;
             hit_col[dst] = (e[u].y >> 13) & 0x3FFFFu;
          }
       }
