@@ -33,7 +33,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_sq2"):
             k = r.get("Kernel_Name", "")[:48]
             agg[k][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
 for k in sorted(agg):
-    if not any(s in k for s in ("k_forward", "k_nl_", "k_exact", "k_fused", "k_direct", "k_scan", "k_compact", "k_stream", "k_dfa", "k_pair", "k_packed", "k_multi")):
+    if not any(s in k for s in ("k_forward", "k_nl_", "k_exact", "k_fused", "k_direct", "k_scan", "k_compact", "k_stream", "k_dfa", "k_pair", "k_packed", "k_multi", "k_verify", "k_emit", "k_nh_top", "k_tiles")):
         continue
     print(k)
     for c in sorted(agg[k]):
@@ -62,3 +62,35 @@ if scan:
     print(json.dumps(res, indent=1))
     with open(os.path.join(out, "pmc_scan_kernel.json"), "w") as fh:
         json.dump(res, fh, indent=1)
+
+
+# Effective core clock per dispatch of the scan kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration.
+# (round 4: the scan kernel runs at two speeds -- is it the clock?)
+try:
+    dur = {}
+    for f in find("pmc_sq2", "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            dur[r["Dispatch_Id"]] = (r["Kernel_Name"], float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    rows = []
+    for f in find("pmc_sq2", "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] in dur:
+                name, ns = dur[r["Dispatch_Id"]]
+                if ns > 0 and any(s_ in name for s_ in ("k_pair<", "k_stream<", "k_verify<", "k_exact1<")):
+                    rows.append((name.split("(")[0][:40], ns / 1e3, float(r["Counter_Value"]) / 8.0, float(r["Counter_Value"]) / 8.0 / ns))
+    if rows:
+        print()
+        print("== effective clock per dispatch (GRBM_GUI_ACTIVE / 8 / duration) ==")
+        by = defaultdict(list)
+        for name, us, cyc, ghz in rows:
+            by[name].append((us, cyc, ghz))
+        for name in sorted(by):
+            v = by[name]
+            print("%-42s n=%-4d us: min %.1f mean %.1f max %.1f   cycles/8: mean %.4g   GHz: min %.3f mean %.3f max %.3f" % (
+                name, len(v), min(x[0] for x in v), sum(x[0] for x in v) / len(v), max(x[0] for x in v),
+                sum(x[1] for x in v) / len(v), min(x[2] for x in v), sum(x[2] for x in v) / len(v), max(x[2] for x in v)))
+            if "k_pair" in name:
+                for us, cyc, ghz in v:
+                    print("      %.1f us  %.4g cycles  %.3f GHz" % (us, cyc, ghz))
+except Exception as e:   # noqa
+    print("clock table: skipped (%s)" % e)

@@ -777,6 +777,7 @@ struct ScanKnobs {
    bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
+   bool old_order;       /* SEEQ_ORDER=old: k_fused_post + k_scanset_* + k_stream_reorder + k_stream_bounds on read-length lines too, as before round 4 (A/B, tests) */
    bool old_verify;      /* SEEQ_VERIFY=old: k_exact1<COUNT> + the three-launch scan behind the filters, as before round 4 (A/B, tests) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
 };
@@ -798,6 +799,7 @@ struct seeqdev_scan {
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
    uint64_t *hitmask, *hdrmask; uint32_t *wave_off, *hdr_off; size_t cap_chunks;
+   uint4    *ent;                /* [cap_hitlines] k_order -> k_bounds2 (seeq_order.h) */
    uint32_t *hit_start, *hit_line, *nh, *hit_col, *nh_sum; size_t cap_hitlines;      /* nh_sum: per 256 entries (k_verify) */
    /* one-pass kernels: what the scan kernel of a segment writes and its post-pass reads */
    struct OnePassWs {
@@ -923,6 +925,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_WINDOW");    kn.no_window = v && atoi(v) == 1;
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
       v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
+      v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
       s->ncu = 256;
       int dev = 0;
       hipDeviceProp_t prop;
@@ -954,7 +957,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    multi_plan_free(s->mplan);
    void *bufs[] = {s->rec_off, s->line_start, s->tile_cnt, s->hitmask, s->hdrmask, s->wave_off, s->hdr_off, s->hit_start,
                    s->hit_line, s->d_eqtab,
-                   s->nh, s->hit_col, s->nh_sum, s->records, s->scan_ws, s->lead_fidx, s->lead_flag, s->lead_wend, s->lead_key, s->d_cnt, s->d_text};
+                   s->nh, s->hit_col, s->nh_sum, s->ent, s->records, s->scan_ws, s->lead_fidx, s->lead_flag, s->lead_wend, s->lead_key, s->d_cnt, s->d_text};
    for (void *b : bufs) if (b) (void)hipFree(b);
    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
    if (s->h_eqtab) (void)hipHostFree(s->h_eqtab);
@@ -1013,6 +1016,7 @@ static int reserve_impl(seeqdev_scan *s, size_t max_bytes, size_t max_lines, siz
       if (ws_alloc((void **)&s->ow.tmp, max_hitlines * sizeof(uint4))) return -1;
       if (ws_alloc((void **)&s->nh, max_hitlines * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->hit_col, max_hitlines * sizeof(uint32_t))) return -1;
+      if (ws_alloc((void **)&s->ent, max_hitlines * sizeof(uint4))) return -1;
       if (ws_alloc((void **)&s->nh_sum, 2 * (max_hitlines / 256 + 2) * sizeof(uint32_t))) return -1;      /* + the chunks' entries with a hit */
       s->cap_hitlines = max_hitlines;
    }
@@ -1395,6 +1399,7 @@ static int run_segments(seeqdev_scan *s)
    for (size_t sg = 0; sg < nseg; sg++) {
       hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
       uint32_t stream_ntiles = 0;
+      bool order2 = false;                                /* the hit list is made by seeq_order.h's kernels */
       seeqdev_scan::OnePassWs &ow = s->ow;
       hipStream_t st = s->stream;
       ScanArgs a;
@@ -1454,8 +1459,16 @@ static int run_segments(seeqdev_scan *s)
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st, f);
          else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st, f);
          if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
-         hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, st, f, (uint32_t)nsl);
-         if (want != SEEQDEV_WANT_COUNTLINES || superset) {
+         /* read-length lines behind k_pair / k_stream: the three launches of seeq_order.h; else (long lines, k_direct) the seven of before */
+         const uint32_t order_nb = (f.ntiles + SEEQ_ORDER_BLOCK - 1) / SEEQ_ORDER_BLOCK;
+         order2 = use_stream && !f.tile_dirty && !kn.old_order && order_nb <= SEEQ_ORDER_MAX_BLOCKS && 2 * (size_t)order_nb <= s->cap_scan_ws;
+         if (order2) {
+            const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
+            seeq_launch_tiles_post(st, f, (uint32_t)nsl, s->scan_ws, order_nb);
+            seeq_launch_order(rgrid, st, f, (uint32_t)nsl, (const uint32_t *)s->scan_ws, order_nb, s->ent);
+         }
+         else hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, st, f, (uint32_t)nsl);
+         if (!order2 && (want != SEEQDEV_WANT_COUNTLINES || superset)) {
             launch_scanset(s, st, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
             const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
             if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
@@ -1493,7 +1506,8 @@ static int run_segments(seeqdev_scan *s)
          const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
          unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
          if (grid_hits == 0) grid_hits = 1;
-         if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col,
+         if (order2) seeq_launch_bounds2(grid_hits, st, a, (const uint4 *)s->ent, s->hit_col);
+         else if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col,
                                             (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
          if (s->multi_active) {
             /* several patterns: the candidate list is the union's -- pattern sets per line, a list per pattern, the exact pass per pattern */

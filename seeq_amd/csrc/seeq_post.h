@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include "seeq_types.h"
+#include "seeq_scan_common.h"      /* FusedArgs */
 
 #define VERIFY_ANY  0          /* presence is enough, or the first emission is the record (SQ_FIRST / SQ_COUNT, line counts) */
 #define VERIFY_BEST 1          /* SQ_BEST records: the first emission with the smallest distance */
@@ -19,5 +20,13 @@ void seeq_launch_verify(int fw, int var, unsigned grid, hipStream_t st, const Sc
                         uint4 *cache);
 /* k_emit1: the records of a segment with one record per line at most, from k_verify's cache */
 void seeq_launch_emit1(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *cache);
+
+/* seeq_order.h: per-wave hit slices -> ordered per-line arrays on read-length lines (three launches).  bsum: 2 * nb words of
+   workspace, nb = blocks of 2 048 tiles (<= SEEQ_ORDER_MAX_BLOCKS); ent: one uint4 per hit-list entry */
+#define SEEQ_ORDER_MAX_BLOCKS 1024
+#define SEEQ_ORDER_BLOCK      2048
+void seeq_launch_tiles_post(hipStream_t st, const FusedArgs &f, uint32_t nslices, uint32_t *bsum, uint32_t nb);
+void seeq_launch_order(unsigned grid, hipStream_t st, const FusedArgs &f, uint32_t nslices, const uint32_t *bsum, uint32_t nb, uint4 *ent);
+void seeq_launch_bounds2(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *ent, uint32_t *hit_col);
 
 #endif

@@ -40,42 +40,46 @@ __device__ __forceinline__ uint32_t verify_top(uint32_t x, uint32_t n) { return 
 #define VERIFY_ADDR(dst, word, SEL) \
    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #SEL : "=v"(dst) : "v"(sh), "v"(word))
 
-/* One column: the Myers step of seeq_scan_common.h with the top bits of ph / mh exposed.  S != 0: the stream of
- * "score > lim" bits (lim = tau forward, the match distance backwards). */
+/* One column: the Myers step of seeq_scan_common.h.  MODE 2 (forward): four streams -- the terminator flag of the EQ word, the top
+ * bits of ph / mh (+1 / -1 on D[m][j]) and "score > lim" (lim = tau); MODE 1 (reverse): "score > lim" only (lim = the match
+ * distance); MODE 0 (the warm-up columns of a window, where no score can be <= tau): the bare step, 13 VALU with its look-up. */
+#define VERIFY_BARE 0
+#define VERIFY_REV  1
+#define VERIFY_FWD  2
 template <int W> struct verify_col;
 template <> struct verify_col<1> {
-   template <bool FWD>
+   template <int MODE>
    static __device__ __forceinline__ void run(const fused_eq_t<1> &e, fused_state_t<1> &st, uint32_t lim, uint32_t &L, uint32_t &PH, uint32_t &MH, uint32_t &T)
    {
       const uint32_t eq = e.w0, pv = st.pv, mv = st.mv;
-      if (FWD) T = __builtin_amdgcn_alignbit(eq, T, 1);
+      if (MODE == VERIFY_FWD) T = __builtin_amdgcn_alignbit(eq, T, 1);
       const uint32_t s = (eq & pv) + pv;
       const uint32_t d0 = ((s ^ pv) | eq) | mv;
       const uint32_t ph = mv | ~(d0 | pv);
       const uint32_t mh = pv & d0;
-      if (FWD) { PH = __builtin_amdgcn_alignbit(PH, ph, 31); MH = __builtin_amdgcn_alignbit(MH, mh, 31); }
+      if (MODE == VERIFY_FWD) { PH = __builtin_amdgcn_alignbit(PH, ph, 31); MH = __builtin_amdgcn_alignbit(MH, mh, 31); }
       uint32_t ph2, mh2, score = st.score;
       asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "=v"(ph2), "+v"(score) : "v"(ph) : "vcc");
       asm("v_add_co_u32 %0, vcc, %2, %2\n\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc" : "=v"(mh2), "+v"(score) : "v"(mh) : "vcc");
       st.pv = mh2 | ~(d0 | ph2);
       st.mv = ph2 & d0;
       st.score = score;
-      L = __builtin_amdgcn_alignbit(L, lim - score, 31);
+      if (MODE != VERIFY_BARE) L = __builtin_amdgcn_alignbit(L, lim - score, 31);
    }
 };
 template <> struct verify_col<2> {
-   template <bool FWD>
+   template <int MODE>
    static __device__ __forceinline__ void run(const fused_eq_t<2> &e, fused_state_t<2> &st, uint32_t lim, uint32_t &L, uint32_t &PH, uint32_t &MH, uint32_t &T)
    {
       const uint32_t pv0 = st.pv0, pv1 = st.pv1, mv0 = st.mv0, mv1 = st.mv1;
-      if (FWD) T = __builtin_amdgcn_alignbit(e.w0, T, 1);
+      if (MODE == VERIFY_FWD) T = __builtin_amdgcn_alignbit(e.w0, T, 1);
       const uint64_t pv = ((uint64_t)pv1 << 32) | pv0, eq = ((uint64_t)e.w1 << 32) | e.w0;
       const uint64_t s = (eq & pv) + pv;
       const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
       const uint32_t d00 = ((s0 ^ pv0) | e.w0) | mv0, d01 = ((s1 ^ pv1) | e.w1) | mv1;
       const uint32_t ph0 = mv0 | ~(d00 | pv0), ph1 = mv1 | ~(d01 | pv1);
       const uint32_t mh0 = pv0 & d00, mh1 = pv1 & d01;
-      if (FWD) { PH = __builtin_amdgcn_alignbit(PH, ph1, 31); MH = __builtin_amdgcn_alignbit(MH, mh1, 31); }
+      if (MODE == VERIFY_FWD) { PH = __builtin_amdgcn_alignbit(PH, ph1, 31); MH = __builtin_amdgcn_alignbit(MH, mh1, 31); }
       uint32_t p0, p1, m0, m1, score = st.score;
       asm("v_add_co_u32 %0, vcc, %3, %3\n\tv_addc_co_u32 %1, vcc, %4, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
           : "=&v"(p0), "=&v"(p1), "+v"(score) : "v"(ph0), "v"(ph1) : "vcc");
@@ -84,12 +88,12 @@ template <> struct verify_col<2> {
       st.pv0 = m0 | ~(d00 | p0); st.pv1 = m1 | ~(d01 | p1);
       st.mv0 = p0 & d00;         st.mv1 = p1 & d01;
       st.score = score;
-      L = __builtin_amdgcn_alignbit(L, lim - score, 31);
+      if (MODE != VERIFY_BARE) L = __builtin_amdgcn_alignbit(L, lim - score, 31);
    }
 };
 
-/* the four columns of one text word into the streams (FWD) / the one stream (reverse: bytes 3, 2, 1, 0) */
-template <int W, bool FWD>
+/* the four columns of one text word (reverse: bytes 3, 2, 1, 0) */
+template <int W, int MODE>
 __device__ __forceinline__ void verify_word(uint32_t word, uint32_t eq_base, uint32_t sh, fused_state_t<W> &st, uint32_t lim,
                                             uint32_t &L, uint32_t &PH, uint32_t &MH, uint32_t &T)
 {
@@ -97,16 +101,16 @@ __device__ __forceinline__ void verify_word(uint32_t word, uint32_t eq_base, uin
    VERIFY_ADDR(a0, word, 0); VERIFY_ADDR(a1, word, 1); VERIFY_ADDR(a2, word, 2); VERIFY_ADDR(a3, word, 3);
    const fused_eq_t<W> e0 = fused_eq_load<W>(eq_base + a0), e1 = fused_eq_load<W>(eq_base + a1),
                        e2 = fused_eq_load<W>(eq_base + a2), e3 = fused_eq_load<W>(eq_base + a3);
-   if (FWD) {
-      verify_col<W>::template run<true>(e0, st, lim, L, PH, MH, T);
-      verify_col<W>::template run<true>(e1, st, lim, L, PH, MH, T);
-      verify_col<W>::template run<true>(e2, st, lim, L, PH, MH, T);
-      verify_col<W>::template run<true>(e3, st, lim, L, PH, MH, T);
+   if (MODE != VERIFY_REV) {
+      verify_col<W>::template run<MODE>(e0, st, lim, L, PH, MH, T);
+      verify_col<W>::template run<MODE>(e1, st, lim, L, PH, MH, T);
+      verify_col<W>::template run<MODE>(e2, st, lim, L, PH, MH, T);
+      verify_col<W>::template run<MODE>(e3, st, lim, L, PH, MH, T);
    } else {
-      verify_col<W>::template run<false>(e3, st, lim, L, PH, MH, T);
-      verify_col<W>::template run<false>(e2, st, lim, L, PH, MH, T);
-      verify_col<W>::template run<false>(e1, st, lim, L, PH, MH, T);
-      verify_col<W>::template run<false>(e0, st, lim, L, PH, MH, T);
+      verify_col<W>::template run<MODE>(e3, st, lim, L, PH, MH, T);
+      verify_col<W>::template run<MODE>(e2, st, lim, L, PH, MH, T);
+      verify_col<W>::template run<MODE>(e1, st, lim, L, PH, MH, T);
+      verify_col<W>::template run<MODE>(e0, st, lim, L, PH, MH, T);
    }
 }
 
@@ -148,7 +152,7 @@ __device__ __forceinline__ uint32_t verify_reverse(const ScanArgs &a, bool need,
       const bool more = fast && (g < 8 || Rh == 0xFFFFFFFFu) && seen == full && 4u * g < i;
       if (!__any(more)) { nsteps = 4u * g; break; }
       const uint32_t word = verify_word_of(v, NV * 4 - 1 - g);
-      verify_word<W, false>(word, eqr_base, sh, st, dist, g < 8 ? Rh : Rl, dummy, dummy, dummy);
+      verify_word<W, VERIFY_REV>(word, eqr_base, sh, st, dist, g < 8 ? Rh : Rl, dummy, dummy, dummy);
    }
    uint32_t start = 0;
    bool slow = need && !fast;
@@ -162,6 +166,47 @@ __device__ __forceinline__ uint32_t verify_reverse(const ScanArgs &a, bool need,
    if (slow) start = exact1_reverse<W>(a.text, off, a.nbytes, i, dist, eqr_base, m, tau1, nullptr);
    return start;
 }
+
+/* Phase 2 over the 32 columns of one stream register (first column in bit 31): the acceptance rules at the columns that follow a
+ * score <= tau.  L: sub-threshold columns (already cut at the terminator), tcol: column of the terminator's step within the group
+ * (> 32: none here), s_in: the score before the group, p0: line column of the group's first one. */
+template <int VAR>
+struct verify_rules {
+   uint32_t prevL, latch, nhits, best_d, best_end, ce0, ce1;
+   bool done;
+   template <typename EMIT2>
+   __device__ __forceinline__ void group(uint32_t L, uint32_t PH, uint32_t MH, uint32_t tcol, uint32_t s_in, uint32_t p0, EMIT2 second)
+   {
+      uint32_t Q = (L >> 1) | (prevL << 31);
+      int lastj = -1;
+      while (Q) {
+         const uint32_t j = (uint32_t)__builtin_clz(Q);
+         Q &= ~(0x80000000u >> j);
+         const uint32_t below = ~(0xFFFFFFFFu >> j);                                   /* columns 0 .. j-1 of the group */
+         const uint32_t streak = s_in + (uint32_t)__popc(PH & below) - (uint32_t)__popc(MH & below);   /* sc[j-1], exact (<= tau) */
+         const bool rise = j == tcol || ((PH << j) & 0x80000000u) != 0u;
+         const bool zero = streak == 0u;
+         const uint32_t p = p0 + j;
+         if (VAR == VERIFY_BEST) {
+            /* no latch: an emission the latch suppresses never beats best_d (exact1_body) */
+            if ((rise || zero) && streak < best_d) { best_d = streak; best_end = p; }
+         } else {
+            if ((int)j != lastj + 1) latch = 0u;
+            const bool emit = rise ? latch == 0u : zero;
+            latch = (rise || zero) ? 1u : 0u;
+            lastj = (int)j;
+            if (emit) {
+               if (nhits == 0u) { ce0 = p; ce1 = streak; }
+               else second(p, streak);
+               nhits++;
+               if (VAR == VERIFY_ANY) { Q = 0; done = true; }
+            }
+         }
+      }
+      if (VAR != VERIFY_BEST && lastj != 31) latch = 0u;
+      prevL = L & 1u;
+   }
+};
 
 template <int W, int VAR>
 __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
@@ -211,7 +256,14 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
       }
       fused_state_t<W> st;
       st.init(m);
-      uint32_t prevL = 0, latch = 0, nhits = 0, best_d = tau1, best_end = 0, ce0 = 0, ce1 = 0;
+      verify_rules<VAR> r;
+      r.prevL = 0; r.latch = 0; r.nhits = 0; r.best_d = tau1; r.best_end = 0; r.ce0 = 0; r.ce1 = 0; r.done = false;
+      auto second = [&](uint32_t p, uint32_t streak) {      /* second and later emissions of a line: to my wave's overflow list */
+         if (VAR == VERIFY_ALL && caching) {
+            const uint32_t idx = atomicAdd(&s_novf[wave_id], 1u) + 1u;
+            if (idx < ovf_r) ovf[idx] = make_uint4(k, r.nhits, p, streak);
+         }
+      };
       while (__any(!done)) {
          /* ---- phase 1: up to 64 columns from registers ---- */
          fused_v4u v[4];
@@ -232,55 +284,32 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
 #pragma unroll
          for (int g = 0; g < 16; g++) {
             if (!__any(stop_rel > 4u * g)) { ncols = 4u * g; break; }
-            verify_word<W, true>(verify_word_of(v, g), eqf_base, sh, st, tau, g < 8 ? Lh : Ll, g < 8 ? Ph : Pl, g < 8 ? Mh : Ml, g < 8 ? Th : Tl);
+            verify_word<W, VERIFY_FWD>(verify_word_of(v, g), eqf_base, sh, st, tau, g < 8 ? Lh : Ll, g < 8 ? Ph : Pl, g < 8 ? Mh : Ml, g < 8 ? Th : Tl);
          }
-         /* the streams, first column in bit 63 */
+         /* the streams, first column of a register in bit 31 */
          const uint32_t nh_ = ncols < 32u ? ncols : 32u, nl_ = ncols > 32u ? ncols - 32u : 0u;
-         uint64_t Lm = ((uint64_t)verify_top(~Lh, nh_) << 32) | verify_top(~Ll, nl_);
-         const uint64_t PHm = ((uint64_t)verify_top(Ph, nh_) << 32) | verify_top(Pl, nl_);
-         const uint64_t MHm = ((uint64_t)verify_top(Mh, nh_) << 32) | verify_top(Ml, nl_);
-         const uint64_t Tm = ((uint64_t)verify_top(__builtin_bitreverse32(Th), nh_) << 32) | verify_top(__builtin_bitreverse32(Tl), nl_);
+         Lh = verify_top(~Lh, nh_); Ph = verify_top(Ph, nh_); Mh = verify_top(Mh, nh_); Th = verify_top(__builtin_bitreverse32(Th), nh_);
+         Ll = verify_top(~Ll, nl_); Pl = verify_top(Pl, nl_); Ml = verify_top(Ml, nl_); Tl = verify_top(__builtin_bitreverse32(Tl), nl_);
          /* the line's terminator (a flagged EQ word) or the end of the window, whichever comes first: that step sees tau + 1 */
-         uint32_t tcol = Tm ? (uint32_t)__builtin_clzll(Tm) : 64u;
+         uint32_t tcol = Th ? (uint32_t)__builtin_clz(Th) : Tl ? 32u + (uint32_t)__builtin_clz(Tl) : 64u;
          tcol = stop_rel < tcol ? stop_rel : tcol;
-         if (done) { Lm = 0; prevL = 0; }
-         if (tcol < 64u) Lm &= ~(~(uint64_t)0 >> tcol);
+         if (done) { Lh = 0; Ll = 0; r.prevL = 0; }
+         if (tcol < 32u) { Lh &= ~(0xFFFFFFFFu >> tcol); Ll = 0; }
+         else if (tcol < 64u) Ll &= ~(0xFFFFFFFFu >> (tcol - 32u));
          /* ---- phase 2: the acceptance rules at the columns that follow a score <= tau ---- */
-         uint64_t Q = (Lm >> 1) | ((uint64_t)prevL << 63);
-         int lastj = -1;
-         while (Q) {
-            const uint32_t j = (uint32_t)__builtin_clzll(Q);
-            Q &= ~((uint64_t)1 << (63u - j));
-            const uint64_t below = j ? ~(uint64_t)0 << (64u - j) : (uint64_t)0;
-            const uint32_t streak = s_in + (uint32_t)__popcll(PHm & below) - (uint32_t)__popcll(MHm & below);      /* sc[j-1], exact (<= tau) */
-            const bool rise = j == tcol || ((PHm >> (63u - j)) & 1u) != 0;
-            const bool zero = streak == 0u;
-            const uint32_t p = pos + j;
-            if (VAR == VERIFY_BEST) {
-               /* no latch: an emission the latch suppresses never beats best_d (exact1_body) */
-               if ((rise || zero) && streak < best_d) { best_d = streak; best_end = p; }
-            } else {
-               if ((int)j != lastj + 1) latch = 0u;
-               const bool emit = rise ? latch == 0u : zero;
-               latch = rise ? 1u : (zero ? 1u : 0u);
-               lastj = (int)j;
-               if (emit) {
-                  if (nhits == 0u) { ce0 = p; ce1 = streak; }
-                  else if (VAR == VERIFY_ALL && caching) {          /* second and later: to my wave's overflow list */
-                     const uint32_t idx = atomicAdd(&s_novf[wave_id], 1u) + 1u;
-                     if (idx < ovf_r) ovf[idx] = make_uint4(k, nhits, p, streak);
-                  }
-                  nhits++;
-                  if (VAR == VERIFY_ANY) { Q = 0; done = true; }
-               }
-            }
+         r.group(Lh, Ph, Mh, tcol, s_in, pos, second);
+         if (__any(!r.done && (Ll | r.prevL) != 0u)) {
+            const uint32_t s_mid = s_in + (uint32_t)__popc(Ph) - (uint32_t)__popc(Mh);
+            if (!r.done) r.group(Ll, Pl, Ml, tcol - 32u, s_mid, pos + 32u, second);
+         } else {
+            if (VAR != VERIFY_BEST) r.latch = 0u;            /* (nothing walked in the second half) */
+            r.prevL = 0u;
          }
-         if (VAR != VERIFY_BEST && lastj != 63) latch = 0u;
-         if (tcol < 64u) done = true;
-         prevL = (uint32_t)Lm & 1u;
+         if (tcol < 64u || r.done) done = true;
          pos += done ? 0u : 64u;
       }
-      if (VAR == VERIFY_BEST) { nhits = best_d < tau1 ? 1u : 0u; ce0 = best_end; ce1 = best_d; }
+      uint32_t nhits = r.nhits, ce0 = r.ce0, ce1 = r.ce1;
+      if (VAR == VERIFY_BEST) { nhits = r.best_d < tau1 ? 1u : 0u; ce0 = r.best_end; ce1 = r.best_d; }
       /* one record per line: its start is recovered here, EMIT only copies */
       uint32_t ce2 = 0, ce3 = 0;
       if (VAR != VERIFY_ALL && caching) {
@@ -379,8 +408,8 @@ __global__ __launch_bounds__(256) void k_emit1(ScanArgs a, const uint4 *cache)
    }
 }
 
-template <int W, int VAR>
-__global__ __launch_bounds__(256, W == 1 ? 8 : 6) void k_verify(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
+template <int W, int VAR, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_verify(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
 {
    verify_body<W, VAR>(a, eq2, hit_col, cache);
 }

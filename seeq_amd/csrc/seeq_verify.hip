@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "seeq_amd.h"
 #include "seeq_kernel_core.h"
@@ -13,12 +15,16 @@
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_verify.h"
+#include "seeq_order.h"
 #include "seeq_post.h"
 
 void seeq_launch_verify(int fw, int var, unsigned grid, hipStream_t st, const ScanArgs &a, const uint32_t *eq, const uint32_t *hit_col,
                         uint4 *cache)
 {
-#define SEEQ_VERIFY(WW, VV) hipLaunchKernelGGL((k_verify<WW, VV>), dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache)
+   static int occ_knob = -1;                                /* SEEQ_VERIFY_OCC=lo: the instances built for fewer waves per SIMD (experiments) */
+   if (occ_knob < 0) { const char *v = getenv("SEEQ_VERIFY_OCC"); occ_knob = v && !strcmp(v, "lo") ? 1 : 0; }
+#define SEEQ_VERIFY(WW, VV) do { if (occ_knob) hipLaunchKernelGGL((k_verify<WW, VV, (WW == 1 ? 6 : 5)>), dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache); \
+                                 else hipLaunchKernelGGL((k_verify<WW, VV, (WW == 1 ? 8 : 6)>), dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache); } while (0)
    if (fw == 1) {
       if (var == VERIFY_BEST) SEEQ_VERIFY(1, VERIFY_BEST); else if (var == VERIFY_ALL) SEEQ_VERIFY(1, VERIFY_ALL); else SEEQ_VERIFY(1, VERIFY_ANY);
    } else {
@@ -31,4 +37,21 @@ void seeq_launch_verify(int fw, int var, unsigned grid, hipStream_t st, const Sc
 void seeq_launch_emit1(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *cache)
 {
    hipLaunchKernelGGL(k_emit1, dim3(grid), dim3(256), 0, st, a, cache);
+}
+
+static_assert(ORDER_MAX_BLOCKS == SEEQ_ORDER_MAX_BLOCKS && ORDER_SCAN_BLOCK == SEEQ_ORDER_BLOCK, "seeq_order.h / seeq_post.h");
+
+void seeq_launch_tiles_post(hipStream_t st, const FusedArgs &f, uint32_t nslices, uint32_t *bsum, uint32_t nb)
+{
+   hipLaunchKernelGGL(k_tiles_post, dim3(nb ? nb : 1, 3), dim3(256), 0, st, f, nslices, bsum, nb);
+}
+
+void seeq_launch_order(unsigned grid, hipStream_t st, const FusedArgs &f, uint32_t nslices, const uint32_t *bsum, uint32_t nb, uint4 *ent)
+{
+   hipLaunchKernelGGL(k_order, dim3(grid), dim3(256), 0, st, f, nslices, bsum, nb, ent);
+}
+
+void seeq_launch_bounds2(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *ent, uint32_t *hit_col)
+{
+   hipLaunchKernelGGL(k_bounds2, dim3(grid), dim3(256), 0, st, a, ent, hit_col);
 }

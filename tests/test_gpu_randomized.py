@@ -121,7 +121,8 @@ def test_fuzz_long_lines_fresh_seed(gpu, capi, oracle):
 VARIANTS = [{"SEEQ_FUSED_KERNEL": "pair"}, {"SEEQ_FUSED_KERNEL": "stream"}, {"SEEQ_FUSED_KERNEL": "direct"}, {"SEEQ_PATH": "generic"},
             {"SEEQ_NO_FILTER": "1"}, {"SEEQ_STREAM_SUB": "0"}, {"SEEQ_SEGMENT_BYTES": "65536"}, {"SEEQ_STREAM_WU": "8"},
             {"SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"}, {"SEEQ_EXACT": "generic"}, {"SEEQ_NO_LEADERS": "1"}, {"SEEQ_NO_WINDOW": "1"},
-            {"SEEQ_NO_MYERS": "1"}, {"SEEQ_VERIFY": "old"}, {"SEEQ_VERIFY": "old", "SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"}]
+            {"SEEQ_NO_MYERS": "1"}, {"SEEQ_VERIFY": "old"}, {"SEEQ_VERIFY": "old", "SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"},
+            {"SEEQ_ORDER": "old"}, {"SEEQ_ORDER": "old", "SEEQ_VERIFY": "old"}, {"SEEQ_VERIFY_OCC": "lo"}]
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in sorted(v.items())))
