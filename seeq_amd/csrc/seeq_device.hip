@@ -1557,7 +1557,8 @@ static int run_segments(seeqdev_scan *s)
             const int var = (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST) ? VERIFY_BEST : count_any ? VERIFY_ANY : VERIFY_ALL;
             a.nh_sum = s->nh_sum;
             a.nz_sum = superset && nh_is_count ? s->nh_sum + (s->cap_hitlines / 256 + 2) : nullptr;
-            a.fin = want == SEEQDEV_WANT_RECORDS ? 0u : 1u + (uint32_t)seg_flags;      /* (no EMIT pass: k_nh_top ends the segment) */
+            /* k_nh_top ends the segment unless k_exact1's EMIT pass follows (SQ_ALL records): k_emit1 works from what k_nh_top saved */
+            a.fin = (want == SEEQDEV_WANT_RECORDS && var == VERIFY_ALL) ? 0u : 1u + (uint32_t)seg_flags;
             seeq_launch_verify(fw, var, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
             if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
             emitted = want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL;

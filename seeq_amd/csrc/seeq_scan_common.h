@@ -223,20 +223,20 @@ __device__ __forceinline__ void fused_post_body(const FusedArgs &a, uint32_t nsl
 {
    __shared__ uint32_t s_red[4][4];
    uint32_t lines = 0, hdrs = 0, hits = 0, mx = 0, ovf = 0, lastnl = 0, flags = 0, busy = 0, crowded = 0;
-   /* one 16-byte load per slice, four slices per thread in flight (this kernel is one workgroup on an idle chip: its time is
+   /* one 16-byte load per slice, eight slices per thread in flight (this kernel is one workgroup on an idle chip: its time is
       the latency of its loads) */
    const uint4 *part = reinterpret_cast<const uint4 *>(a.wg_part);
-   for (uint32_t i0 = threadIdx.x; i0 < nslices; i0 += 1024) {
-      uint4 pv[4];
-      uint32_t lv[4];
+   for (uint32_t i0 = threadIdx.x; i0 < nslices; i0 += 2048) {
+      uint4 pv[8];
+      uint32_t lv[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 8; u++) {
          const uint32_t i = i0 + 256u * u;
          pv[u] = i < nslices ? part[i] : make_uint4(0u, 0u, 0u, 0u);
          lv[u] = a.wg_lastnl && i < nslices ? a.wg_lastnl[i] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 8; u++) {
          lastnl = lv[u] > lastnl ? lv[u] : lastnl;
          lines += pv[u].x;
          hdrs += pv[u].y;

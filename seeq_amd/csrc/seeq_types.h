@@ -34,7 +34,9 @@ struct Counters {
    uint32_t prev_hit_line;  /* k_stream: line number of the last hit line of the previous segment (a line can span segments) */
    uint32_t seg_last_nl;    /* k_stream: segment-relative offset + 1 of the last newline of the segment (0: none) */
    uint32_t seg_dirty_tiles; /* k_stream, long-line mode: tiles of the segment that hold a non-alphabet byte */
-   uint32_t pad4[3];
+   uint32_t emit_nhl;       /* k_nh_top -> k_emit1: the segment's hit-list length and record base, kept past the end of the segment */
+   uint32_t pad4[2];
+   uint64_t emit_base;
 };
 
 struct ScanArgs {

@@ -382,6 +382,8 @@ __global__ __launch_bounds__(256) void k_nh_top(ScanArgs a)
       c->seg_nrec = running;
       if (a.nz_sum) c->seg_nmatch = nz;
       if (a.want == SEEQDEV_WANT_RECORDS) rec_check_body(a);
+      c->emit_nhl = nhl;                                    /* (k_emit1 runs behind the end of the segment) */
+      c->emit_base = c->records;
       if (a.fin) seg_end_body(a, (int)a.fin - 1);
    }
 }
@@ -391,8 +393,8 @@ __global__ __launch_bounds__(256) void k_emit1(ScanArgs a, const uint4 *cache)
 {
    const Counters *c = a.cnt;
    if (c->overflow & 4u) return;
-   const uint32_t nhl = c->seg_nhitlines;
-   const uint64_t base = c->records;
+   const uint32_t nhl = c->emit_nhl;
+   const uint64_t base = c->emit_base;
    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < nhl; k += gridDim.x * 256u) {
       const uint4 ce = cache[k];                            /* {end, dist, start, has a record} */
       if (!ce.w) continue;

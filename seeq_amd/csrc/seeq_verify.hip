@@ -5,8 +5,6 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
-#include <stdlib.h>
-#include <string.h>
 
 #include "seeq_amd.h"
 #include "seeq_kernel_core.h"
@@ -21,10 +19,8 @@
 void seeq_launch_verify(int fw, int var, unsigned grid, hipStream_t st, const ScanArgs &a, const uint32_t *eq, const uint32_t *hit_col,
                         uint4 *cache)
 {
-   static int occ_knob = -1;                                /* SEEQ_VERIFY_OCC=lo: the instances built for fewer waves per SIMD (experiments) */
-   if (occ_knob < 0) { const char *v = getenv("SEEQ_VERIFY_OCC"); occ_knob = v && !strcmp(v, "lo") ? 1 : 0; }
-#define SEEQ_VERIFY(WW, VV) do { if (occ_knob) hipLaunchKernelGGL((k_verify<WW, VV, (WW == 1 ? 6 : 5)>), dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache); \
-                                 else hipLaunchKernelGGL((k_verify<WW, VV, (WW == 1 ? 8 : 6)>), dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache); } while (0)
+   /* (6 / 5 waves per SIMD: the instances built for 8 / 6 spill ten registers each and are 2 - 4 % slower -- profiles/r04) */
+#define SEEQ_VERIFY(WW, VV) hipLaunchKernelGGL((k_verify<WW, VV, (WW == 1 ? 6 : 5)>), dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache)
    if (fw == 1) {
       if (var == VERIFY_BEST) SEEQ_VERIFY(1, VERIFY_BEST); else if (var == VERIFY_ALL) SEEQ_VERIFY(1, VERIFY_ALL); else SEEQ_VERIFY(1, VERIFY_ANY);
    } else {
