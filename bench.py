@@ -248,6 +248,161 @@ json.dump(res, open(sys.argv[1] + ".out", "w"))
 '''
 
 
+class ClockSampler:
+    """Core clock / power of the GPU while the timed steps run, read from sysfs every 20 ms by a thread (no GPU call, no
+    subprocess): the scan kernel comes in two speeds box by box -- is it the clock?  Empty when the files are not readable."""
+
+    def __init__(self, index):
+        import glob
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+        if index < len(cards):
+            base = cards[index]
+            self.files["sclk_dpm"] = os.path.join(base, "pp_dpm_sclk")
+            for h in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+                for name, key in (("freq1_input", "sclk_hz"), ("power1_average", "power_uw"), ("power1_input", "power_uw"),
+                                  ("temp1_input", "temp_mc")):
+                    f = os.path.join(h, name)
+                    if os.path.exists(f) and key not in self.files:
+                        self.files[key] = f
+        self.samples = {k: [] for k in self.files}
+        self._stop = False
+        self._thread = None
+
+    def _read(self):
+        for k, f in self.files.items():
+            try:
+                txt = open(f).read()
+            except OSError:
+                continue
+            if k == "sclk_dpm":
+                cur = [ln for ln in txt.splitlines() if ln.rstrip().endswith("*")]
+                if cur:
+                    try:
+                        self.samples[k].append(float(cur[0].split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", "")))
+                    except (ValueError, IndexError):
+                        pass
+            else:
+                try:
+                    self.samples[k].append(float(txt.strip()))
+                except ValueError:
+                    pass
+
+    def _loop(self):
+        while not self._stop:
+            self._read()
+            time.sleep(0.02)
+
+    def start(self):
+        import threading
+        if not self.files:
+            return
+        self._read()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread:
+            self._thread.join()
+            self._read()
+
+    def summary(self):
+        out = {}
+        scale = {"sclk_dpm": ("sclk_mhz_dpm", 1.0), "sclk_hz": ("sclk_mhz", 1e-6), "power_uw": ("power_w", 1e-6), "temp_mc": ("temp_c", 1e-3)}
+        for k, v in self.samples.items():
+            if v:
+                name, f = scale[k]
+                out[name] = {"min": min(v) * f, "mean": sum(v) / len(v) * f, "max": max(v) * f, "samples": len(v)}
+        return out or None
+
+
+def stats3(v):
+    v = sorted(v)
+    return {"min": v[0], "median": v[len(v) // 2], "max": v[-1]} if v else None
+
+
+def reference_full_check(text, n, read_len, pattern, tau, mode, rec, matching_lines, shard_lines=1_000_000):
+    """EVERY line of the run against the reference itself (oracle/_ref/seeq_ref, the reference's own C files): the device text
+    goes to /dev/shm in waves of P shards (P = the host cores this process may use), P pinned reference processes print
+    `line:start-end:dist` rows (src/seeq.c:131-137, -f) -- or their count (-c) -- and every row is compared with the GPU's record
+    list; the total with the GPU's count.  Returns a dict for the bench line, or None when the binary is not there."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.pyoracle import REF_BIN
+    if not os.path.exists(REF_BIN):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    procs = len(allowed)
+    quota = cpu_quota()
+    if quota and quota < procs:
+        procs = max(1, int(quota))
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    base = os.path.join(tmpdir, "seeq_bench_full_%d" % os.getpid())
+    L = read_len + 1
+    flags = {"first": ["-c"], "best": ["-b", "-f"], "all": ["-a", "-f"]}[mode]
+    shards = [(f0, min(shard_lines, n - f0)) for f0 in range(0, n, shard_lines)]
+    t0 = time.perf_counter()
+    rows_total = lines_total = count_total = 0
+    ref_seconds = 0.0
+    table = bytes.maketrans(b":-", b"  ")
+    files = []
+    try:
+        with ThreadPoolExecutor(max_workers=min(8, procs)) as pool:
+            for w0 in range(0, len(shards), procs):
+                wave = shards[w0:w0 + procs]
+                paths = ["%s_%d.txt" % (base, k) for k in range(len(wave))]
+                files = paths + [p_ + ".out" for p_ in paths]
+
+                def dump(k):
+                    f0, cnt = wave[k]
+                    text[f0 * L:(f0 + cnt) * L].cpu().numpy().tofile(paths[k])
+                list(pool.map(dump, range(len(wave))))
+                t1 = time.perf_counter()
+                children = []
+                for k in range(len(wave)):
+                    out = open(paths[k] + ".out", "wb")
+                    children.append((subprocess.Popen([REF_BIN, "-d", str(tau)] + flags + [pattern, paths[k]], stdout=out,
+                                                      preexec_fn=(lambda c=allowed[k % len(allowed)]: os.sched_setaffinity(0, {c}))), out))
+                for proc, out in children:
+                    assert proc.wait() == 0, "the reference binary failed"
+                    out.close()
+                ref_seconds += time.perf_counter() - t1
+                for k, (f0, cnt) in enumerate(wave):
+                    raw = open(paths[k] + ".out", "rb").read()
+                    if mode == "first":
+                        count_total += int(raw.split()[0]) if raw.split() else 0
+                    else:
+                        exp = np.array(raw.translate(table).split(), dtype=np.int64).reshape(-1, 4) if raw else np.zeros((0, 4), np.int64)
+                        exp[:, 0] += f0                               # the shard's line numbers start at 1
+                        exp[:, 2] += 1                                # printed end is inclusive (seeq.c:135)
+                        lo = np.searchsorted(rec[:, 0], f0 + 1, side="left")
+                        hi = np.searchsorted(rec[:, 0], f0 + cnt, side="right")
+                        got = rec[lo:hi].astype(np.int64)
+                        assert np.array_equal(got, exp), "GPU records differ from the reference binary in lines [%d, %d)" % (f0, f0 + cnt)
+                        rows_total += len(exp)
+                        count_total += len(np.unique(exp[:, 0]))
+                    lines_total += cnt
+                for f in files:
+                    if os.path.exists(f):
+                        os.unlink(f)
+                files = []
+    finally:
+        for f in files:
+            if os.path.exists(f):
+                os.unlink(f)
+    assert count_total == matching_lines, ("matching lines: reference %d, GPU %d" % (count_total, matching_lines))
+    if rec is not None:
+        assert rows_total == len(rec), ("records: reference %d, GPU %d" % (rows_total, len(rec)))
+    return {"reference_lines_checked": lines_total, "reference_rows_compared": rows_total, "matching_lines": count_total,
+            "command": " ".join(["seeq", "-d", str(tau)] + flags + [pattern]), "processes": procs, "shard_lines": shard_lines,
+            "reference_seconds": ref_seconds, "reference_check_seconds": time.perf_counter() - t0, "reference_result": "identical"}
+
+
 def oracle_check(text, ranges, read_len, pattern, tau, opt, want_records, rec, scan_block, procs):
     """Run the oracle over the given line ranges of the device text in `procs` child processes (the text of each
     range is copied from HBM to /dev/shm) and compare: records (line, start, end, dist) bit for bit, and per range
@@ -473,6 +628,16 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI wall-clock measurement (timed region iii)")
     ap.add_argument("--no-multi", action="store_true", help="skip the sixteen-barcode multi-pattern measurement")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) even at world size 1 and run the step's collectives over it "
+                         "(start it under torch.distributed.run --nproc-per-node 1, or alone: the rendezvous variables are set here)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="allocate ONE rank's text, workspace and record buffers, print what it needs of the GPU's memory "
+                         "(per rank of --gpus N: every rank holds the same) and exit -- no scan, no launcher")
+    ap.add_argument("--log-clocks", action="store_true", help="sample the GPU's clock / power from sysfs during the timed steps (a thread)")
+    ap.add_argument("--check", choices=["full", "sample"], default="full",
+                    help="full (default when oracle/_ref/seeq_ref exists): besides the oracle sample, EVERY line of the run is compared with the "
+                         "reference binary's output, outside the timed region; sample: the oracle sample only")
     ap.add_argument("--check-lines", type=int, default=1_000_000,
                     help="prefix verified against the oracle (plus every 97th 64 Ki-line block and the segment seams); 0 = no check")
     args = ap.parse_args()
@@ -481,7 +646,7 @@ def main():
         if args.gpus != 1:
             sys.exit("bench.py: --workload chrom runs on one GPU")
         return bench_chrom(args)
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.dry_run:
         sys.exit(launch_ranks(args))
 
     wl = WORKLOADS[args.workload]
@@ -499,14 +664,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus and not args.dry_run:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
         sys.exit(2)
     share = os.environ.get("SEEQ_BENCH_SHARE_GPU") == "1"
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    dist_info = None
+    if world == 1 and args.force_dist and not args.dry_run:
+        # the RCCL rehearsal: the same process group, all-reduce and all-gather the multi-GPU line uses, over one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=device)         # RCCL
+        ones = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        gathered = [torch.zeros(1, dtype=torch.int64, device=device)]
+        dist.all_gather(gathered, torch.full((1,), 7, dtype=torch.int64, device=device))
+        torch.cuda.synchronize()
+        dist_info = {"backend": dist.get_backend(), "world": dist.get_world_size(), "all_reduce_of_ones": int(ones.item()),
+                     "all_gather_ok": int(gathered[0].item()) == 7}
+        if dist_info["all_reduce_of_ones"] != 1 or not dist_info["all_gather_ok"]:
+            sys.stderr.write("bench.py: the RCCL collectives over one rank returned %r\n" % (dist_info,))
+            sys.exit(3)
+    if world > 1 and not args.dry_run:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo")
@@ -519,13 +702,16 @@ def main():
             sys.stderr.write("bench.py: %d ranks joined the all-reduce, expected %d\n" % (int(ones.item()), args.gpus))
             sys.exit(3)
     red_device = "cpu" if (share and world > 1) else device
+    force_dist = dist_info is not None
 
     n = args.reads
     first = rank * n                                           # this rank's read-index range (weak scaling)
     nbytes = n * (READ_LEN + 1)
     stream = torch.cuda.current_stream().cuda_stream
+    mem_free0, mem_total = torch.cuda.mem_get_info(dev_index)
     text = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    dev.synth_reads(text.data_ptr(), first, n, READ_LEN, dev.plain_pattern(PATTERN), TAU, stream=stream)
+    if not args.dry_run:
+        dev.synth_reads(text.data_ptr(), first, n, READ_LEN, dev.plain_pattern(PATTERN), TAU, stream=stream)
     torch.cuda.synchronize()
 
     opt = {"best": dev.SQ_BEST, "first": 0, "all": dev.SQ_ALL}[mode]
@@ -537,28 +723,52 @@ def main():
     rec_cap = n // 8 + 1024 if mode != "all" else n // 4 + 1024
     sc.reserve(nbytes, seg_lines + 64, max(seg_lines // 6 + 1024, 8192 * 64), rec_cap)
     sc.set_profiling(True)
+    torch.cuda.synchronize()
+    mem_free1, _ = torch.cuda.mem_get_info(dev_index)
+    hbm = {"total_bytes": int(mem_total), "free_before_bytes": int(mem_free0), "text_bytes": int(nbytes),
+           "text_workspace_records_bytes": int(mem_free0 - mem_free1), "free_after_bytes": int(mem_free1),
+           "note": "one rank's allocations (text + scan workspace reserved for its segments + record buffers), measured with "
+                   "hipMemGetInfo around them; every rank of a multi-GPU run holds the same"}
+    if args.dry_run:
+        hbm["ranks"] = args.gpus
+        hbm["fits"] = bool(mem_free1 > (1 << 30))               # a GiB to spare for the packed / multi-pattern sections' own buffers
+        print(json.dumps({"dry_run": True, "workload": wl[5] % n, "hbm_per_rank": hbm}))
+        return
 
     def step():
         sc.run(pat, text.data_ptr(), nbytes, opt, want)
         cnt = sc.fetch()
-        return shard.reduce_counts(cnt, device=red_device), cnt
+        return shard.reduce_counts(cnt, device=red_device, force=force_dist), cnt
 
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    clocks = ClockSampler(dev_index) if (rank == 0 and args.log_clocks) else None
+    if clocks:
+        clocks.start()
     t0 = time.perf_counter()
     fwd_ms = 0.0
     fwd_launches = 0
     idx_ms = ex_ms = 0.0
+    step_wall, step_fwd, step_post, launch_ms = [], [], [], []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         total, local = step()
+        step_wall.append(1e3 * (time.perf_counter() - ts))     # (inside the timed region: two clock reads per step)
         tm = sc.last_times_ms()
         fwd_ms += tm["forward"]
         fwd_launches += tm["forward_launches"]
         idx_ms += tm["index"]
         ex_ms += tm["exact"]
+        step_fwd.append(tm["forward"]); step_post.append(tm["exact"])
+        launch_ms.extend(sc.last_launch_times_ms())
+    if clocks:
+        clocks.stop()
+    if force_dist:      # the all-gather of the global line numbering (seeq.c:377) through the shard layer, over RCCL
+        dist_info["line_base_of_rank0"] = shard.line_base(local["nlines"], device=device, force=True)
+        dist_info["count_reduce_per_step"] = "all_reduce of (lines, matching lines, hits) over RCCL inside every timed step"
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -596,6 +806,11 @@ def main():
             assert len(np.unique(rec[:, 0])) == local["nmatchlines"]
         check = {"oracle_lines_checked": lines_checked, "ranges": nranges, "segment_seams_checked": len(seams),
                  "seconds": time.perf_counter() - tchk, "result": "bit-exact"}
+        if args.check == "full" and args.workload in ("best", "all", "count", "cfg5"):
+            # the whole buffer against the reference itself (bit-exact match start / end / distance / count)
+            full = reference_full_check(text, n, READ_LEN, PATTERN, TAU, "first" if want != dev.WANT_RECORDS else mode, rec, local["nmatchlines"])
+            if full:
+                check.update(full)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -645,6 +860,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int (u16 automaton state ids; exact-pass columns u32 bit-vectors)" if kern in ("k_stream", "k_pair") else "u32 bit-vectors",
             "data": "synthetic",
+            "dist": dist_info, "hbm_per_rank": hbm,
             "config": {"workload": wl[5] % n,
                        "pattern": PATTERN, "distance": TAU, "read_len": READ_LEN, "reads_per_gpu": n,
                        "parallelism": "line-sharded x%d, RCCL count all-reduce" % world},
@@ -652,6 +868,12 @@ def main():
                         "oracle_check": check, "oracle_lines_checked": check["oracle_lines_checked"] if check else 0},
             "device_ms_per_step": {"newline_index": idx_ms / args.steps, "forward_scan": fwd_ms / args.steps,
                                    "compaction_exact_records": ex_ms / args.steps},
+            # the spread behind the means: per step (host clock around run + fetch; device events of its two parts) and per launch of
+            # the scan kernel (full-size launches only: the last segment of a buffer is shorter)
+            "per_step": {"ms": stats3(step_wall), "forward_scan_ms": stats3(step_fwd), "post_pass_ms": stats3(step_post),
+                         "scan_launch_ms_full_segments": stats3([x for i, x in enumerate(launch_ms) if (i + 1) % max(1, int(launches_per_step)) != 0 or launches_per_step == 1]),
+                         "scan_launch_ms_all": [round(x, 4) for x in launch_ms[:64]],
+                         "gpu_clock_power_during_steps": clocks.summary() if clocks else None},
             "roofline": {"bound": "hbm", "kernel": kern + (" (partition filter automaton)" if filt else ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -745,7 +967,7 @@ def main():
                     sc3.close()
                 scp.close()
                 del pb, pn
-            except Exception as e:                      # (a pattern without a pair automaton: ENOTSUP)
+            except Exception as e:                      # (reported, not fatal: the ASCII line above is the graded one)
                 out["packed_scan"] = {"error": str(e)}
         if world == 1 and not args.no_multi and args.workload in ("best", "count", "all"):
             # Sixteen barcodes over the first 10 M reads of the buffer (row f4b, seeq_multi.h): ONE walk for the set against a scan per

@@ -178,7 +178,9 @@ int seeqdevScanLastMulti(const seeqdev_scan_t * scan);     /* 1: one walk for al
  * The result is that of seeqdevScanRun over the same reads as ASCII text, one read per line ('line' of a record = read
  * index + 1), for every match option and every `want` -- the scan kernel walks the packed bytes (one read per lane, no warm-
  * up, seeq_packed.h), candidate reads are unpacked and verified by the exact pass.  Asynchronous: seeqdevScanFetch waits.
- * Patterns of up to 62 positions that have a pair automaton (else -1, errno ENOTSUP: scan the text).
+ * Any pattern: those of more than 62 positions, or without a pair automaton, are served by unpacking the batch on the device
+ * (nreads * (read_len + 1) bytes of scratch) and scanning that text.  seeqdevScanCopyOffsets after a packed scan reports, per
+ * record, the offset its read has in the ASCII form of the batch: (line - 1) * (read_len + 1).
  * What replaces what: the reference has no packed input; this is the boundary's batch entry for callers that do. */
 typedef struct {
    const void * bases;
@@ -211,6 +213,9 @@ int seeqdevScanLastCopyMs(const seeqdev_scan_t * scan, float * h2d_ms);
 int seeqdevScanSetProfiling(seeqdev_scan_t * scan, int on);
 int seeqdevScanLastTimes(const seeqdev_scan_t * scan, float ms[4]);
 int seeqdevScanLastLaunches(const seeqdev_scan_t * scan);
+/* The same per launch: the duration (ms) of each of the last run's forward-scan
+ * launches, in launch order, up to `cap` of them; returns how many there were. */
+int seeqdevScanLastLaunchTimes(const seeqdev_scan_t * scan, float * ms, int cap);
 
 /* Synthetic shape-R reads written straight into HBM (bench/test input; spec
  * in SURVEY.md section 8d, CPU twin in oracle/seeq_oracle.c): n lines of

@@ -64,7 +64,7 @@ EXPORTS = [
     "seeqdevDeviceCount", "seeqdevSetDevice", "seeqdevLastError", "seeqdevPatternNew", "seeqdevPatternFree",
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
-    "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevSynthReads",
+    "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevScanLastLaunchTimes", "seeqdevSynthReads",
     "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
     "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanLastMulti", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
@@ -169,6 +169,8 @@ def lib():
     L.seeqdevScanLastTimes.restype = C.c_int
     L.seeqdevScanLastLaunches.argtypes = [C.c_void_p]
     L.seeqdevScanLastLaunches.restype = C.c_int
+    L.seeqdevScanLastLaunchTimes.argtypes = [C.c_void_p, P(C.c_float), C.c_int]
+    L.seeqdevScanLastLaunchTimes.restype = C.c_int
     L.seeqdevScanSetLineHint.argtypes = [C.c_void_p, C.c_double]
     L.seeqdevScanSetLineHint.restype = C.c_int
     L.seeqdevScanLastPath.argtypes = [C.c_void_p]

@@ -791,6 +791,7 @@ struct seeqdev_scan {
    hipEvent_t  ev_h2d[2];         /* profiling: around the H2D copy of seeqdevScanHostBegin */
    bool        have_h2d_ev;
    float       h2d_ms;            /* ... of the last fetched scan */
+   float      *launch_ms; size_t cap_launch_ms;      /* per forward-scan launch of the last fetched scan (profiling) */
    int         ncu;               /* compute units of the device (cached) */
    ScanKnobs   knobs;
    OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
@@ -846,6 +847,7 @@ struct seeqdev_scan {
    /* packed read batches (seeqdevScanPacked) */
    uint32_t *pk_cand, *pk_slot, *pk_coff; uint64_t *pk_bmask; size_t cap_pk_reads;      /* candidate columns per read of a segment; per block of 64 reads: candidates before it, their mask */
    uint8_t  *pk_stage; size_t cap_pk_stage;               /* ASCII lines of the candidate reads */
+   uint8_t  *d_unpack; size_t cap_unpack;                 /* the whole batch as ASCII text: patterns the packed walk does not serve */
    uint32_t *pk_last; size_t cap_pk_last;                 /* per candidate: column of its last candidate */
    bool      is_packed; seeqdev_packed_t packed;          /* the last run was a packed one (re-run on overflow) */
    /* last run (for the transparent re-run on overflow) */
@@ -950,7 +952,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
       void *ob[] = {s->ow.tile_cl, s->ow.tile_hits, s->ow.tile_dirty, s->ow.tile_dmask, s->ow.tmp, s->ow.wg_hits, s->ow.wg_part, s->ow.wg_lastnl};
       for (void *b : ob) if (b) (void)hipFree(b);
    }
-   { void *pk[] = {s->pk_cand, s->pk_slot, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last}; for (void *b : pk) if (b) (void)hipFree(b); }
+   { void *pk[] = {s->pk_cand, s->pk_slot, s->pk_coff, s->pk_bmask, s->pk_stage, s->pk_last, s->d_unpack}; for (void *b : pk) if (b) (void)hipFree(b); }
    { void *mw[] = {s->ml_mask, s->ml_first, s->ml_last, s->mp_idx, s->mp_nh, s->m_bsum, s->d_mcnt, s->d_mx, s->m_scan_ws}; for (void *b : mw) if (b) (void)hipFree(b); }
    if (s->h_mcnt) (void)hipHostFree(s->h_mcnt);
    if (s->h_mx) (void)hipHostFree(s->h_mx);
@@ -966,6 +968,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    if (s->h_strout) (void)hipHostFree(s->h_strout);
    for (size_t i = 0; i < 4 * s->nev_seg; i++) (void)hipEventDestroy(s->ev[i]);
    free(s->ev);
+   free(s->launch_ms);
    free(s->multi_cnt); free(s->multi_first);
    if (s->multi_rec) (void)hipHostFree(s->multi_rec);
    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -1743,9 +1746,26 @@ static int run_packed(seeqdev_scan *s)
       a.hit_last = s->pk_last;
       a.window_ok = 1u;
       a.cnt = c;
+      a.rec_pitch = L + 1u;                                 /* seeqdevScanCopyOffsets: the read's offset in the ASCII form of the batch */
       const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
       const uint32_t *hcol = s->hit_col;
       uint4 *ecache = want == SEEQDEV_WANT_RECORDS ? s->ow.tmp : nullptr;
+      const int seg_flags = 1 | (!nh_is_count ? 2 : 0);
+      if (!s->knobs.old_verify) {
+         /* the exact pass of k_pair's candidates (seeq_verify.h): the staging text holds ASCII lines, no byte of them is skipped */
+         const bool count_any = want != SEEQDEV_WANT_COUNTMATCH && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+         const int var = (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST) ? VERIFY_BEST : count_any ? VERIFY_ANY : VERIFY_ALL;
+         a.nh_sum = s->nh_sum;
+         a.nz_sum = nh_is_count ? s->nh_sum + (s->cap_hitlines / 256 + 2) : nullptr;
+         a.fin = (want == SEEQDEV_WANT_RECORDS && var == VERIFY_ALL) ? 0u : 1u + (uint32_t)seg_flags;
+         seeq_launch_verify(fw, var, grid_hits, st, a, eqp, hcol, ecache);
+         if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
+         else if (want == SEEQDEV_WANT_RECORDS) {
+            if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+            else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+            hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, seg_flags);
+         }
+      } else {
       if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
       else hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
       if (nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
@@ -1758,7 +1778,8 @@ static int run_packed(seeqdev_scan *s)
          else { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
                 else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
       }
-      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 1 | (!nh_is_count ? 2 : 0));
+      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, seg_flags);
+      }
       if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
       HIP_TRY(hipGetLastError(), EIO);
    }
@@ -2007,10 +2028,15 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
          for (size_t sg = 0; sg < s->prof_segs; sg++) {
             hipEvent_t *ev = s->ev + 4 * sg;
             float t01 = 0, t12 = 0, t23 = 0;
+            if (sg == 0 && s->prof_segs > s->cap_launch_ms) {
+               float *g = (float *)realloc(s->launch_ms, s->prof_segs * sizeof(float));
+               if (g) { s->launch_ms = g; s->cap_launch_ms = s->prof_segs; }
+            }
             (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
             (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
             (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
             s->acc_ms[0] += t01; s->acc_ms[1] += t12; s->acc_ms[2] += t23; s->acc_ms[3] += t01 + t12 + t23;
+            if (sg < s->cap_launch_ms) s->launch_ms[sg] = t12;
          }
          if (s->prof_segs) s->fwd_ms_avg = s->acc_ms[1] / (float)s->prof_segs;
          s->h2d_ms = 0.f;
@@ -2071,9 +2097,25 @@ extern "C" int seeqdevScanPacked(seeqdev_scan_t *s, const seeqdev_pattern_t *pat
    if (pat->device != s->device) { errno = EINVAL; return -1; }
    if (use_device(s->device)) return -1;
    seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
-   if (pat->wlen > FUSED_MAX_WLEN2) { snprintf(g_last_error, sizeof g_last_error, "packed batches: patterns of up to %d positions", FUSED_MAX_WLEN2); errno = ENOTSUP; return -1; }
-   if (__atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
-   if (mp->pair_state != 1) { snprintf(g_last_error, sizeof g_last_error, "packed batches: the pattern has no pair automaton"); errno = ENOTSUP; return -1; }
+   if (pat->wlen <= FUSED_MAX_WLEN2 && __atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
+   if (pat->wlen > FUSED_MAX_WLEN2 || mp->pair_state != 1) {
+      /* not the packed walk's pattern (more than 62 positions, or no pair automaton): the batch is unpacked on the device and the
+         ASCII scan runs over it -- the reference takes any pattern (libseeq.c:43-138), so does this entry */
+      const size_t tbytes = (size_t)batch->nreads * (batch->read_len + 1u);
+      if (tbytes > s->cap_unpack) {
+         if (ws_alloc((void **)&s->d_unpack, tbytes + 64)) return -1;
+         s->cap_unpack = tbytes;
+      }
+      if (batch->nreads) {
+         const uint64_t threads = batch->nreads * (uint64_t)(batch->read_len / 16u + 1u), blocks = (threads + 255) / 256;
+         if (blocks > 0x7FFFFFFFull) { errno = E2BIG; return -1; }
+         hipLaunchKernelGGL(k_unpack_ascii, dim3((unsigned)blocks), dim3(256), 0, s->stream, (const uint8_t *)batch->bases, (const uint8_t *)batch->nmask,
+                            batch->nreads, batch->read_len, batch->stride, batch->nstride, s->d_unpack);
+         HIP_TRY(hipGetLastError(), EIO);
+      }
+      s->avg_text = NULL;                                   /* (new contents behind the same pointer: sample again) */
+      return seeqdevScanRun(s, pat, s->d_unpack, tbytes, options, want);
+   }
    s->pat = pat; s->text = NULL; s->nbytes = 0; s->options = options; s->want = want;
    s->ran = false;
    s->is_packed = true;
@@ -2408,6 +2450,14 @@ extern "C" int seeqdevScanLastCopyMs(const seeqdev_scan_t *s, float *h2d_ms)
 }
 
 extern "C" int seeqdevScanLastLaunches(const seeqdev_scan_t *s) { return s ? (int)s->prof_segs : 0; }
+
+extern "C" int seeqdevScanLastLaunchTimes(const seeqdev_scan_t *s, float *ms, int cap)
+{
+   if (!s || (!ms && cap > 0)) { errno = EINVAL; return -1; }
+   const size_t n = s->prof_segs < s->cap_launch_ms ? s->prof_segs : s->cap_launch_ms;
+   for (size_t i = 0; i < n && (int)i < cap; i++) ms[i] = s->launch_ms[i];
+   return (int)n;
+}
 
 /* ========================================================================== */
 /* One string, one launch: seeqStringMatch (reference libseeq.c:171-352)        */

@@ -438,7 +438,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
                h.end = best_end;
                h.dist = best_d;
                out[0] = h;
-               a.rec_off[out - a.records] = off;
+               a.rec_off[out - a.records] = rec_off_of(a, off, line_no);
             }
          } else {
             /* the first record whole from the COUNT pass's cache (the others: the overflow list, below), or the
@@ -451,7 +451,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
                else { h.end = out[i].end; h.dist = out[i].dist; }      /* (written by this lane, above) */
                h.start = (from_cache && chas) ? cstart : exact1_reverse<W>(a.text, off, a.nbytes, h.end, h.dist, eqr_base, m, tau1, row);
                out[i] = h;
-               a.rec_off[(out - a.records) + i] = off;     /* byte offset of the record's line (seeqdevScanCopyOffsets) */
+               a.rec_off[(out - a.records) + i] = rec_off_of(a, off, line_no);     /* byte offset of the record's line (seeqdevScanCopyOffsets) */
             }
          }
       }
@@ -477,7 +477,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
          h.end = o.z;
          h.dist = o.w;
          a.records[slot] = h;
-         a.rec_off[slot] = off;
+         a.rec_off[slot] = rec_off_of(a, off, h.line);
       }
    }
 }

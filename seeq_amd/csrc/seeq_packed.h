@@ -259,6 +259,39 @@ __global__ __launch_bounds__(256) void k_pack_ascii(const uint8_t *text, uint64_
    }
 }
 
+/* The whole batch as ASCII text (one read per line, read_len bases + newline, N restored): the fall-back of seeqdevScanPacked for
+   patterns the packed walk does not serve (more than 62 positions, no pair automaton) -- the ASCII scan then runs over it.  One
+   thread per 16 output characters. */
+__global__ __launch_bounds__(256) void k_unpack_ascii(const uint8_t *bases, const uint8_t *nmask, uint64_t nreads, uint32_t L, uint32_t stride, uint32_t nstride,
+                                                      uint8_t *out)
+{
+   const uint32_t pieces = L / 16u + 1u;                   /* positions 0 .. L (the newline) */
+   const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+   const uint64_t r = gid / pieces;
+   const uint32_t i = (uint32_t)(gid % pieces);
+   if (r >= nreads) return;
+   const uint8_t *pb = bases + r * (uint64_t)stride, *pn = nmask ? nmask + r * (uint64_t)nstride : nullptr;
+   uint8_t *o = out + r * (uint64_t)(L + 1u);
+   for (uint32_t q = 0; q < 4u; q++) {
+      uint32_t word = 0, nbytes = 0;
+      for (uint32_t j = 0; j < 4u; j++) {
+         const uint32_t p_ = 16u * i + 4u * q + j;
+         if (p_ > L) break;
+         uint32_t ch = '\n';
+         if (p_ < L) {
+            const uint32_t code = (pb[p_ >> 2] >> (6u - 2u * (p_ & 3u))) & 3u;
+            ch = (0x47544341u >> (8u * code)) & 0xFFu;      /* "ACTG"[code]: the code is bits 1-2 of the letter */
+            if (pn && ((pn[p_ >> 3] >> (7u - (p_ & 7u))) & 1u)) ch = 'N';
+         }
+         word |= ch << (8u * j);
+         nbytes++;
+      }
+      uint8_t *dst = o + 16u * i + 4u * q;
+      if (nbytes == 4u) *reinterpret_cast<packed_u32_unaligned *>(dst) = word;
+      else for (uint32_t j = 0; j < nbytes; j++) dst[j] = (uint8_t)(word >> (8u * j));
+   }
+}
+
 #undef PACKED_STEP
 
 #endif

@@ -76,6 +76,8 @@ struct ScanArgs {
                                    follow it in the hit list -- a line with ONE candidate is scanned over that candidate's window only */
    uint32_t       *nh_sum;      /* k_verify: nh[] holds offsets inside chunks of 256 entries, nh_sum[k >> 8] the records before the chunk (NULL: nh[] holds
                                    the segment-wide offsets, made by the three-launch scan) */
+   uint32_t        rec_pitch;   /* packed read batches: the exact pass runs on a private staging text -- a record's line offset is reported as
+                                   (line - 1) * rec_pitch, the offset the same read has in the ASCII form of the batch (0: the line's real offset) */
    uint32_t       *nz_sum;      /* k_verify: per chunk the entries with >= 1 hit (NULL: not wanted) */
    uint32_t        fin;         /* != 0: k_nh_top ends the segment (seg_end_body with flags fin - 1); 0: k_seg_end does, behind the EMIT pass */
    Counters      *cnt;
@@ -84,6 +86,8 @@ struct ScanArgs {
 /* per hit-list entry: records of the segment before it (see nh_sum) */
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint32_t nh_at(const ScanArgs &a, uint32_t k) { return a.nh[k] + (a.nh_sum ? a.nh_sum[k >> 8] : 0u); }
+/* what seeqdevScanCopyOffsets reports for a record of line number `line` whose text starts at byte `off` of the scanned buffer */
+__device__ __forceinline__ uint64_t rec_off_of(const ScanArgs &a, uint64_t off, uint32_t line) { return a.rec_pitch ? (uint64_t)(line - 1u) * a.rec_pitch : off; }
 #endif
 
 

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_emit1(ScanArgs a, const uint4 *cache)
       h.end = ce.x;
       h.dist = ce.y;
       a.records[slot] = h;
-      a.rec_off[slot] = a.seg_base + a.hit_start[kk];       /* byte offset of the record's line (seeqdevScanCopyOffsets) */
+      a.rec_off[slot] = rec_off_of(a, a.seg_base + a.hit_start[kk], h.line);       /* byte offset of the record's line (seeqdevScanCopyOffsets) */
    }
 }
 

@@ -131,6 +131,13 @@ class Scanner:
         return dict(index=ms[0], forward=ms[1], exact=ms[2], total=ms[3],
                     forward_launches=self._lib.seeqdevScanLastLaunches(self._h))
 
+    def last_launch_times_ms(self):
+        """Duration of every forward-scan launch of the last fetched scan (profiling on), in launch order."""
+        n = self._lib.seeqdevScanLastLaunches(self._h)
+        ms = (C.c_float * max(1, n))()
+        got = self._lib.seeqdevScanLastLaunchTimes(self._h, ms, n)
+        return [float(ms[i]) for i in range(max(0, min(got, n)))]
+
     def run(self, pattern, d_ptr, nbytes, options=0, want=WANT_COUNTLINES):
         """Enqueue the scan (asynchronous)."""
         _check(self._lib.seeqdevScanRun(self._h, pattern.handle, C.c_void_p(d_ptr), nbytes, options, want))

@@ -18,21 +18,22 @@ def shard_range(n_total, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
-def reduce_counts(counts, device=None, group=None):
+def reduce_counts(counts, device=None, group=None, force=False):
     """Sum (nlines, nmatchlines, nhits) over ranks; returns a dict with the global values.
-    No-op when torch.distributed is not initialised (single GPU)."""
+    No-op when torch.distributed is not initialised (single GPU) or the group has one rank -- unless `force`
+    (the collective then runs over the one rank: the RCCL rehearsal of bench.py --force-dist)."""
     keys = ("nlines", "nmatchlines", "nhits")
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return {k: int(counts[k]) for k in keys}
     t = torch.tensor([int(counts[k]) for k in keys], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return {k: int(v) for k, v in zip(keys, t.tolist())}
 
 
-def line_base(nlines_local, device=None, group=None):
+def line_base(nlines_local, device=None, group=None, force=False):
     """Number of counted lines on lower ranks = global line number of this rank's line 0
     (needed to print global line numbers; records themselves stay rank-local)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return 0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     mine = torch.tensor([int(nlines_local)], dtype=torch.int64, device=device)

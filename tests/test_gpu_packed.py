@@ -165,3 +165,65 @@ def test_packed_two_segments_equal_the_ascii_scan(gpu, capi):
     assert np.array_equal(ra, rb)
     assert int(rb[:, 0].max()) > (1 << 24)                      # records of the second segment are there
     sc.close(); pat.close()
+
+
+def test_packed_patterns_the_walk_does_not_serve(gpu, capi, oracle):
+    """No refusal (the reference takes any pattern, libseeq.c:43-138): a 70-position pattern (beyond the two-word column) and patterns
+    without a pair automaton are served by unpacking the batch on the device and scanning that text -- same records as the oracle's."""
+    import torch
+    from seeq_amd import device as dev
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate
+    rng = random.Random(77)
+    long_pat = "".join(rng.choice("ACGT") for _ in range(70))
+    for pattern, tau, L in ((long_pat, 6, 150), ("ACG", 2, 40), ("ACGTA", 4, 33), (long_pat[:64] + "N[AC]", 3, 101)):
+        core = pattern.replace("N", "A").replace("[AC]", "C")
+        lines = []
+        for i in range(1500):
+            t = "".join(rng.choice("ACGT") for _ in range(L))
+            if i % 3 == 0 and L >= len(core):
+                cp = mutate(rng, core, rng.randint(0, tau + 2))
+                q = rng.randrange(max(1, L - len(cp) + 1))
+                t = (t[:q] + cp + t[q + len(cp):])[:L]
+            if i % 9 == 0:
+                q = rng.randrange(L)
+                t = t[:q] + "N" + t[q + 1:]
+            lines.append(t)
+        text = ("\n".join(lines) + "\n").encode()
+        pat = dev.Pattern(pattern, tau)
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = oracle.buffer_scan(pattern, tau, text, mo)
+            got = _packed_scan(dev, torch, pat, text, L, mo, dev.WANT_RECORDS)
+            assert got["kernel"] != "k_packed", (pattern, got["kernel"])                 # the fall-back ran
+            assert got["nlines"] == exp["nlines"] == len(lines) and got["nmatchlines"] == exp["nmatchlines"], (pattern, tau, L, mo)
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, L, mo)
+        c2 = _packed_scan(dev, torch, pat, text, L, 0, dev.WANT_COUNTMATCH)
+        expa = oracle.buffer_scan(pattern, tau, text, SQ_ALL)
+        assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau, L)
+        pat.close()
+
+
+def test_packed_record_offsets_are_those_of_the_ascii_form(gpu, capi):
+    """seeqdevScanCopyOffsets after a packed scan: per record the offset its read has in the ASCII form of the batch -- what the
+    ASCII scan of the same reads reports -- not an offset into the scan's private staging text."""
+    import torch
+    from seeq_amd import device as dev
+    n, L = 300_000, 75
+    pattern, tau = "GATGTAGCGCGATTAGCCTG", 3
+    stream = torch.cuda.current_stream().cuda_stream
+    text = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda:0")
+    dev.synth_reads(text.data_ptr(), 0, n, L, pattern, tau, stream=stream)
+    db = torch.empty(n * ((L + 3) // 4), dtype=torch.uint8, device="cuda:0"); dn = torch.empty(n * ((L + 7) // 8), dtype=torch.uint8, device="cuda:0")
+    dev.pack_reads_device(text.data_ptr(), n, L, db.data_ptr(), dn.data_ptr(), stream=stream)
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner(stream)
+    for mo in (SQ_BEST, SQ_ALL, SQ_FIRST):
+        sc.run(pat, text.data_ptr(), text.numel(), mo, dev.WANT_RECORDS)
+        a = sc.fetch(); ra = sc.records(a["nrecords"]); oa = sc.record_offsets(a["nrecords"])
+        sc.run_packed(pat, db.data_ptr(), dn.data_ptr(), n, L, options=mo, want=dev.WANT_RECORDS)
+        b = sc.fetch(); rb = sc.records(b["nrecords"]); ob = sc.record_offsets(b["nrecords"])
+        assert sc.last_kernel() == "k_packed" and a == b and a["nrecords"] > 1000
+        assert np.array_equal(ra, rb)
+        assert np.array_equal(oa, ob), mo
+        assert np.array_equal(ob, (rb[:, 0].astype(np.uint64) - 1) * (L + 1))
+    sc.close(); pat.close()

@@ -194,6 +194,49 @@ def test_bench_launches_its_own_ranks(gpu):
 
 
 @pytest.mark.gpu
+def test_bench_rccl_process_group_over_one_rank(gpu):
+    """The first RCCL call of this repository must not be the driver's 8-GPU run: `bench.py --force-dist` under the driver's own
+    launcher (`python -m torch.distributed.run --nproc-per-node 1`) initialises the `nccl` backend (= RCCL), runs the join
+    check, the per-step count all-reduce and the line-numbering all-gather (seeq.c:377) on the GPU, and says so in its line."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--reads", "2000000",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-per-call", "--no-packed", "--no-cli",
+                        "--no-multi", "--check-lines", "100000"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    d = line["dist"]
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["all_reduce_of_ones"] == 1 and d["all_gather_ok"] and d["line_base_of_rank0"] == 0
+    assert line["n_gpus"] == 1 and line["results"]["lines"] == 2000000 and line["results"]["oracle_lines_checked"] >= 100000
+
+
+@pytest.mark.gpu
+def test_bench_dry_run_reports_the_memory_a_rank_of_eight_needs(gpu):
+    """`bench.py --gpus 8 --dry-run` on ONE GPU: allocates what a rank of the 8-GPU line holds (100 M reads of text, the scan
+    workspace, the record buffers), reports it against the card's memory, starts no ranks and scans nothing."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    h = line["hbm_per_rank"]
+    assert line["dry_run"] and h["ranks"] == 8 and h["fits"]
+    assert h["text_bytes"] == 100_000_000 * 151 and h["text_workspace_records_bytes"] >= h["text_bytes"]
+    assert h["text_workspace_records_bytes"] < h["total_bytes"] // 4           # 288 GB per GPU: a rank's share is a small part of it
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workload,reads", [("best", 30_000_000), ("cfg5", 18_000_000)])
 def test_two_real_segments_full_size_parity(gpu, workload, reads):
     """More than one REAL segment (3.75 GiB each: 30 M x 151 B = 4.5 GB, 18 M x 251 B = 4.5 GB) through `bench.py`'s
@@ -213,3 +256,7 @@ def test_two_real_segments_full_size_parity(gpu, workload, reads):
     assert line["results"]["lines"] == reads and chk["result"] == "bit-exact"
     assert chk["oracle_lines_checked"] >= 1_000_000 and chk["segment_seams_checked"] >= 1
     assert line["roofline"]["launches_per_step"] >= 2
+    # ... and EVERY line against the reference binary itself (bench.py --check full, the default when oracle/_ref travelled)
+    from oracle.pyoracle import REF_BIN
+    if os.path.exists(REF_BIN):
+        assert chk["reference_lines_checked"] == reads and chk["reference_rows_compared"] == line["results"]["hits"] and chk["result"] == "bit-exact"
