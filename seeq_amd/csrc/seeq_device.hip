@@ -773,7 +773,7 @@ struct ScanKnobs {
    bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
-   int  pair_exp;        /* SEEQ_PAIR_EXP=2..4: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
+   int  pair_exp;        /* SEEQ_PAIR_EXP=2..4, builds with -DSEEQ_EXPERIMENTS only: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
    bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
@@ -793,6 +793,7 @@ struct seeqdev_scan {
    float       h2d_ms;            /* ... of the last fetched scan */
    float      *launch_ms; size_t cap_launch_ms;      /* per forward-scan launch of the last fetched scan (profiling) */
    int         ncu;               /* compute units of the device (cached) */
+   size_t      lds_per_wg;        /* LDS a workgroup may allocate on it */
    ScanKnobs   knobs;
    OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
    bool        last_filter;       /* the last run walked a partition filter automaton */
@@ -929,10 +930,11 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
       v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
       s->ncu = 256;
+      s->lds_per_wg = 65536;
       int dev = 0;
       hipDeviceProp_t prop;
       if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-         s->ncu = prop.multiProcessorCount;
+      { s->ncu = prop.multiProcessorCount; s->lds_per_wg = prop.sharedMemPerBlock; }
    }
    if (e != hipSuccess) {
       hip_fail(e, "seeqdevScanNew", EIO);
@@ -1322,8 +1324,10 @@ static int run_segments(seeqdev_scan *s)
 #define SEEQ_PAIR_FN(...) (stream_wu == 4 ? (const void *)k_pair<4, __VA_ARGS__> : stream_wu == 5 ? (const void *)k_pair<5, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_pair<6, __VA_ARGS__> \
                           : stream_wu == 7 ? (const void *)k_pair<7, __VA_ARGS__> : (const void *)k_pair<8, __VA_ARGS__>)
             stream_fn = fasta ? SEEQ_PAIR_FN(true) : SEEQ_PAIR_FN(false);
+#ifdef SEEQ_EXPERIMENTS                                   /* (builds of profiles/ only: the shipped library holds no kernel whose results are void) */
             if (!fasta && stream_wu == 5 && kn.pair_exp >= 2 && kn.pair_exp <= 4)       /* experiments (profiles/r03): timing only */
                stream_fn = kn.pair_exp == 2 ? (const void *)k_pair<5, false, 2> : kn.pair_exp == 3 ? (const void *)k_pair<5, false, 3> : (const void *)k_pair<5, false, 4>;
+#endif
 #undef SEEQ_PAIR_FN
             dfa_lds = (size_t)pat->pair_units * 16;
          }
@@ -1514,7 +1518,7 @@ static int run_segments(seeqdev_scan *s)
                                             (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
          if (s->multi_active) {
             /* several patterns: the candidate list is the union's -- pattern sets per line, a list per pattern, the exact pass per pattern */
-            if (multi_post(s, a, st)) return -1;
+            { const int mr = multi_post(s, a, st); if (mr > 0) return -2; if (mr) return -1; }      /* (1: a launch was refused -- a scan per pattern) */
             hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 3);
             if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
             HIP_TRY(hipGetLastError(), EIO);
@@ -1863,10 +1867,13 @@ static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
       const unsigned grid = (unsigned)(blocks < (size_t)s->ncu * 2 ? blocks : (size_t)s->ncu * 2);      /* persistent: the table is staged once per workgroup */
       HIP_TRY(hipMemsetAsync(s->ml_mask, 0, s->cap_hitlines * sizeof(uint32_t), st), EIO);      /* the lanes of a line's entries OR / MAX into them */
       HIP_TRY(hipMemsetAsync(s->ml_last, 0, s->cap_hitlines * sizeof(uint32_t), st), EIO);
+      /* the automaton in LDS when it fits what a workgroup may ask for beside the kernel's static arrays (the device's limit, not a literal) */
       const size_t lds2 = (size_t)mp->res_states * 20, lds1 = (size_t)mp->res_states * 16;
-      if (lds2 <= 65536) hipLaunchKernelGGL(k_multi_resolve<2>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds2, st, m);
-      else if (lds1 <= 65536) hipLaunchKernelGGL(k_multi_resolve<1>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds1, st, m);
+      const size_t lds_room = s->lds_per_wg > 1024 ? s->lds_per_wg - 1024 : 0;
+      if (lds2 <= lds_room && lds2 <= 65536) hipLaunchKernelGGL(k_multi_resolve<2>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds2, st, m);
+      else if (lds1 <= lds_room && lds1 <= 65536) hipLaunchKernelGGL(k_multi_resolve<1>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds1, st, m);
       else hipLaunchKernelGGL(k_multi_resolve<0>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), 0, st, m);
+      if (hipGetLastError() != hipSuccess) return 1;       /* the launch was refused: a scan per pattern (seeqdevScanRunMulti) */
       hipLaunchKernelGGL(k_multi_reduce, dim3(m.nb), dim3(256), 0, st, m);
       hipLaunchKernelGGL(k_multi_top, dim3((unsigned)npat), dim3(256), 0, st, m);
       if (trust) { HIP_TRY(hipGetLastError(), EIO); return 0; }
