@@ -777,6 +777,7 @@ struct ScanKnobs {
    bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
+   bool no_skipcount;    /* SEEQ_NO_SKIPCOUNT=1: SQ_IGNORE, every chain with a skipped byte in its warm-up window makes up a candidate, as before round 4 */
    bool old_order;       /* SEEQ_ORDER=old: k_fused_post + k_scanset_* + k_stream_reorder + k_stream_bounds on read-length lines too, as before round 4 (A/B, tests) */
    bool old_verify;      /* SEEQ_VERIFY=old: k_exact1<COUNT> + the three-launch scan behind the filters, as before round 4 (A/B, tests) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
@@ -929,6 +930,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
       v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
       v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
+      v = getenv("SEEQ_NO_SKIPCOUNT"); kn.no_skipcount = v && atoi(v) == 1;
       s->ncu = 256;
       s->lds_per_wg = 65536;
       int dev = 0;
@@ -1447,6 +1449,7 @@ static int run_segments(seeqdev_scan *s)
          uint32_t pos_bias = 0;
          if (use_stream) {
             f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
+            f.skip_thr = (stream_sub == 2 && pat->sdfa_parts == 1 && !kn.no_skipcount) ? (uint32_t)(pat->wlen - pat->tau) : 0u;
             if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
             if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
             /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */

@@ -291,7 +291,6 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
                fake = (stream_from_prev_lane(bad_tail, pbad) ? 1u : 0u) | (bad_mid ? 2u : 0u);
                const uint32_t nfake = (uint32_t)__popcll(__ballot((fake & 1u) != 0)) + (uint32_t)__popcll(__ballot((fake & 2u) != 0));
                if (nfake) wv_dirty |= 4u;                 /* the hit lines of this scan are a superset: the exact pass decides */
-               wv_fakes += nfake;
             }
             uint32_t nuls = 0, pnuls = 0;
             if (flag) {                                   /* wave-uniform */
@@ -383,6 +382,66 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
 #pragma unroll
       for (int r = 0; r < NM; r++) nmask[r] = stream_nl_mask32(v[2 * r], v[2 * r + 1], tile_clean);
       if (SUB == 2) {                /* made-up first hits at the first byte of a chain (see SUB) */
+         if (a.skip_thr && __ballot(fake != 0)) {
+            /* Round 4: most made-up candidates can be ruled out by COUNTING.  An occurrence takes at least m - tau characters that
+               are not skipped, all between its line's start and its end -- so a hit this chain's walk may have missed (it ends inside
+               the chain) needs that many between the last newline before the chain and the chain's end.  Per chain: its characters
+               that are not skipped (the bytes stream_sub4 turned into 'H' / 'L' and the newlines taken off); per lane {a newline in
+               it, the characters behind its last newline}; a segmented scan
+               over the lanes gives every lane the count since the last newline before it (unknown when the line starts before the
+               tile: the candidate stays).  FASTQ quality lines hold ~10 such characters in 150: their chains stay silent. */
+            /* rm[g]: the characters of 32-byte group g that are neither skipped nor a newline (first character = bit 31) */
+            uint32_t rm[NM], pc[NM], smk[NM];
+#pragma unroll
+            for (int g = 0; g < NM; g++) {
+               const uint32_t w[8] = {v[2 * g].x, v[2 * g].y, v[2 * g].z, v[2 * g].w, v[2 * g + 1].x, v[2 * g + 1].y, v[2 * g + 1].z, v[2 * g + 1].w};
+               uint32_t sm = 0;
+#pragma unroll
+               for (int k = 0; k < 8; k += 2) {
+                  const uint32_t y0 = (w[k] ^ 0x48484848u) & 0xFBFBFBFBu, y1 = (w[k + 1] ^ 0x48484848u) & 0xFBFBFBFBu;      /* zero byte: 'H' (skipped) or 'L' (dead) */
+                  const uint32_t f0 = ~(((y0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y0) & 0x80808080u, f1 = ~(((y1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y1) & 0x80808080u;
+                  sm = __builtin_amdgcn_udot4(f0 >> 7, 0x10204080u, __builtin_amdgcn_udot4(f1 >> 7, 0x01020408u, sm << 8, false), false);
+               }
+               smk[g] = sm;
+               rm[g] = ~(sm | nmask[g]);
+               pc[g] = (uint32_t)__popc(rm[g]);
+            }
+            const uint32_t rc[2] = {pc[0] + pc[1], pc[2] + pc[3]};
+            static_assert(NM == 4, "two groups per chain");
+            /* (1) a newline in the warm-up window resets the walk: only bytes skipped BEHIND the window's last newline shorten it.
+               Window of chain B: my bytes 32..63 (group 1); of chain A: the previous lane's bytes 96..127 (its group 3; lane 0 keeps
+               the verdict made from the bytes before the tile).  Bits below a mask's lowest one = the characters behind its last newline
+               (no newline: all of them). */
+#define STREAM_BEHIND_MASK(g) ((nmask[g] & (0u - nmask[g])) - 1u)
+            {
+               const uint32_t winB = smk[1] & STREAM_BEHIND_MASK(1), winT = smk[3] & STREAM_BEHIND_MASK(3);
+               const uint32_t keepA = stream_from_prev_lane(winT ? 1u : 0u, 1u);
+               fake &= keepA | (winB ? 2u : 0u);
+            }
+            /* (2) the count: characters that are not skipped since the last newline before the chain + those of the chain in front of
+               ITS first newline (the line the made-up candidate would name ends there) */
+#define STREAM_BEHIND(g) ((uint32_t)__popc(rm[g] & STREAM_BEHIND_MASK(g)))
+#define STREAM_AHEAD(g) ((uint32_t)__popc(rm[g] & ~(0xFFFFFFFFu >> (uint32_t)__builtin_clz(nmask[g]))))      /* (nmask[g] != 0) in front of the group's FIRST newline */
+            const uint32_t nlA = (nmask[0] | nmask[1]) ? 1u : 0u, nlB = (nmask[2] | nmask[3]) ? 1u : 0u;
+            const uint32_t tailA = nmask[1] ? STREAM_BEHIND(1) : STREAM_BEHIND(0) + pc[1];                    /* (used when nlA) */
+            const uint32_t tailB = nmask[3] ? STREAM_BEHIND(3) : STREAM_BEHIND(2) + pc[3];                    /* (used when nlB) */
+            const uint32_t headA = nmask[0] ? STREAM_AHEAD(0) : pc[0] + (nmask[1] ? STREAM_AHEAD(1) : pc[1]);
+            const uint32_t headB = nmask[2] ? STREAM_AHEAD(2) : pc[2] + (nmask[3] ? STREAM_AHEAD(3) : pc[3]);
+#undef STREAM_BEHIND
+#undef STREAM_AHEAD
+#undef STREAM_BEHIND_MASK
+            /* {bit 31: a newline in the lane, low bits: characters since its last one}; combine(before, cur) = cur.flag ? cur : before + cur */
+            uint32_t P = ((nlA | nlB) << 31) | (nlB ? tailB : nlA ? tailA + rc[1] : rc[0] + rc[1]);
+#define STREAM_SEG(ctrl, rmask) { const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, ctrl, rmask, 0xf, true); P = (P >> 31) ? P : y + P; }
+            STREAM_SEG(0x111, 0xf) STREAM_SEG(0x112, 0xf) STREAM_SEG(0x114, 0xf) STREAM_SEG(0x118, 0xf) STREAM_SEG(0x142, 0xa) STREAM_SEG(0x143, 0xc)
+#undef STREAM_SEG
+            const uint32_t before = stream_from_prev_lane(P, 0u);                               /* lane 0: unknown */
+            const uint32_t knownA = before >> 31, cntA = before & 0x7FFFFFFFu;
+            if ((fake & 1u) && knownA && cntA + headA < a.skip_thr) fake &= ~1u;
+            const uint32_t knownB = knownA | nlA, cntB = nlA ? tailA : cntA + rc[0];
+            if ((fake & 2u) && knownB && cntB + headB < a.skip_thr) fake &= ~2u;
+         }
+         wv_fakes += (uint32_t)__popcll(__ballot((fake & 1u) != 0)) + (uint32_t)__popcll(__ballot((fake & 2u) != 0));
          if (fake & 1u) hmask[0] |= 0x80000000u;
          if (fake & 2u) hmask[NM / 2] |= 0x80000000u;
       }

@@ -122,7 +122,7 @@ VARIANTS = [{"SEEQ_FUSED_KERNEL": "pair"}, {"SEEQ_FUSED_KERNEL": "stream"}, {"SE
             {"SEEQ_NO_FILTER": "1"}, {"SEEQ_STREAM_SUB": "0"}, {"SEEQ_SEGMENT_BYTES": "65536"}, {"SEEQ_STREAM_WU": "8"},
             {"SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"}, {"SEEQ_EXACT": "generic"}, {"SEEQ_NO_LEADERS": "1"}, {"SEEQ_NO_WINDOW": "1"},
             {"SEEQ_NO_MYERS": "1"}, {"SEEQ_VERIFY": "old"}, {"SEEQ_VERIFY": "old", "SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"},
-            {"SEEQ_ORDER": "old"}, {"SEEQ_ORDER": "old", "SEEQ_VERIFY": "old"}, {"SEEQ_VERIFY_OCC": "lo"}]
+            {"SEEQ_ORDER": "old"}, {"SEEQ_ORDER": "old", "SEEQ_VERIFY": "old"}, {"SEEQ_NO_SKIPCOUNT": "1"}]
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in sorted(v.items())))
@@ -131,6 +131,78 @@ def test_forced_variants(gpu, capi, oracle, variant):
     length and long lines): the results must be the oracle's whatever ran."""
     _run_fuzz([(REGRESSION_SEEDS[1], 3), (REGRESSION_SEEDS[2], 3)], False, variant, nshort=1500)
     _run_fuzz([(REGRESSION_SEEDS[2], 1)], True, variant, nlong=60)
+
+
+LEAD_STRESS = r"""
+import os, sys, random, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from oracle.pyoracle import Oracle, SQ_ALL, SQ_BEST, SQ_FIRST
+from seeq_amd import device as dev
+from test_gpu_parity import _mutate
+o = Oracle()
+rng = random.Random(%(seed)d)
+kernels = {}
+for it in range(%(iters)d):
+    kind = rng.choice(["random", "random", "periodic", "polyA", "tandem"])
+    m = rng.choice([12, 16, 20, 20, 27, 34, 42])
+    unit = "".join(rng.choice("ACGT") for _ in range(rng.choice([2, 3, 4])))
+    if kind == "polyA":
+        pattern = rng.choice("ACGT") * m
+    elif kind == "periodic":
+        pattern = (unit * m)[:m]
+    else:
+        pattern = "".join(rng.choice("ACGT") for _ in range(m))
+    tau = rng.randint(1, max(1, m // 3))
+    nlines = rng.choice([1, 2, 3])
+    lines = []
+    for i in range(nlines):
+        n = rng.choice([40_000, 90_000, 150_000])
+        t = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(rng.choice([0, 50, 300, 900])):
+            if kind in ("random", "tandem"):
+                c = _mutate(rng, pattern, rng.randint(0, tau + 1))
+                if kind == "tandem":
+                    c = c * rng.randint(1, 6)                   # occurrences back to back: windows that run into one another
+            elif kind == "polyA":
+                c = pattern[0] * rng.randint(m // 2, 700)       # runs far longer than a chunk
+            else:
+                c = (unit * 400)[:rng.randint(m // 2, 800)]
+            q = rng.randrange(max(1, n - len(c)))
+            t[q:q + len(c)] = list(c)[:n - q]
+        lines.append("".join(t))
+    buf = ("\n".join(lines) + "\n").encode()
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner()
+    expa = o.buffer_scan(pattern, tau, buf, SQ_ALL)
+    tag = (it, kind, pattern, tau, nlines)
+    got = sc.scan_host(pat, buf, SQ_ALL, dev.WANT_RECORDS)
+    kernels[sc.last_kernel()] = kernels.get(sc.last_kernel(), 0) + 1
+    assert got["nlines"] == nlines and got["nmatchlines"] == expa["nmatchlines"], (tag, got["nmatchlines"], expa["nmatchlines"])
+    assert np.array_equal(got["records"].astype(np.uint64), expa["records"]), (tag, len(got["records"]), len(expa["records"]))
+    c2 = sc.scan_host(pat, buf, 0, dev.WANT_COUNTMATCH)
+    assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], tag
+    c1 = sc.scan_host(pat, buf, 0, dev.WANT_COUNTLINES)
+    assert c1["nmatchlines"] == expa["nmatchlines"], tag
+    for mo in (SQ_BEST, SQ_FIRST):
+        g = sc.scan_host(pat, buf, mo, dev.WANT_RECORDS)
+        assert np.array_equal(g["records"].astype(np.uint64), o.buffer_scan(pattern, tau, buf, mo)["records"]), (tag, mo)
+    sc.close(); pat.close()
+print("kernels", kernels)
+print("LEAD STRESS OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"SEEQ_NO_LEADERS": "1"}, {"SEEQ_SEGMENT_BYTES": "262144"}], ids=["leaders", "one-lane-per-line", "256KiB-segments"])
+def test_long_lines_fresh_seed_stress(gpu, capi, oracle, env):
+    """The long-line machinery (k_stream's long-line variant and Myers mode, the window walk, leaders with their void-and-repeat
+    rule) under a FRESH seed per run: 70 iterations per variant (210 a run) of 1-3 lines of 40-150 KB, patterns of 12-42 positions
+    that are random, periodic or a single base, text with planted copies, tandem copies (windows that run into one another),
+    poly-base runs and periodic stretches of up to 800 bytes -- --all records, both counts, --best and first-hit records against
+    the oracle; with the leaders, with one lane per line, and with 256 KiB segments (lines that span segments)."""
+    seed = _fresh_seed()
+    code = LEAD_STRESS % dict(root=ROOT, seed=seed, iters=70)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=1200)
+    assert r.returncode == 0 and "LEAD STRESS OK" in r.stdout, (seed, env, r.stdout[-800:], r.stderr[-3000:])
 
 
 def _oracle_count_chunk(args):
