@@ -403,6 +403,97 @@ def reference_full_check(text, n, read_len, pattern, tau, mode, rec, matching_li
             "reference_seconds": ref_seconds, "reference_check_seconds": time.perf_counter() - t0, "reference_result": "identical"}
 
 
+def fastq_shape(reads, nrec, L, pattern, tau, pat, steps=5):
+    """Section `fastq_shape` of the bench line: `nrec` four-line FASTQ records built on the device from the resident reads (torch:
+    plumbing), scanned through the C-ABI under SQ_FAIL / SQ_CONVERT / SQ_IGNORE."""
+    import numpy as np
+    import torch
+    from seeq_amd import device as dev
+    from oracle.pyoracle import Oracle, REF_BIN
+    d = reads.device
+    HDR = 12                                                 # "@r%09d\n"
+    REC = HDR + (L + 1) + 2 + (L + 1)
+    buf = torch.empty((nrec, REC), dtype=torch.uint8, device=d)
+    idx = torch.arange(nrec, device=d, dtype=torch.int64)
+    buf[:, 0] = ord("@"); buf[:, 1] = ord("r")
+    for k in range(9):
+        buf[:, 2 + k] = (48 + (idx // (10 ** (8 - k))) % 10).to(torch.uint8)
+    buf[:, 11] = 10
+    buf[:, HDR:HDR + L + 1] = reads[:nrec * (L + 1)].view(nrec, L + 1)
+    buf[:, HDR + L + 1] = ord("+"); buf[:, HDR + L + 2] = 10
+    g = torch.Generator(device=d); g.manual_seed(7)
+    buf[:, HDR + L + 3:HDR + L + 3 + L] = torch.randint(33, 75, (nrec, L), device=d, generator=g, dtype=torch.uint8)
+    buf[:, REC - 1] = 10
+    text = buf.view(-1)
+    del idx
+    torch.cuda.synchronize()
+    res = {"records": nrec, "lines": 4 * nrec, "bytes": int(text.numel()), "match_option": "--best with positions", "modes": {}}
+    # the reference's counts over the whole buffer: shards of whole records in /dev/shm, one pinned process each
+    ref_counts = None
+    files = []
+    if os.path.exists(REF_BIN):
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+        except AttributeError:
+            allowed = list(range(os.cpu_count() or 1))
+        procs = len(allowed)
+        quota = cpu_quota()
+        if quota and quota < procs:
+            procs = max(1, int(quota))
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        per = (nrec + procs - 1) // procs
+        try:
+            for k in range(procs):
+                lo, hi = k * per, min(nrec, (k + 1) * per)
+                if lo >= hi:
+                    break
+                path = os.path.join(tmpdir, "seeq_bench_fq_%d_%d.txt" % (os.getpid(), k))
+                buf[lo:hi].reshape(-1).cpu().numpy().tofile(path)
+                files.append(path)
+            ref_counts = {}
+            for name, x in (("fail", "0"), ("convert", "1"), ("ignore", "2")):
+                ps = [subprocess.Popen([REF_BIN, "-c", "-d", str(tau), "-x", x, pattern, f], stdout=subprocess.PIPE, text=True,
+                                       preexec_fn=(lambda c=allowed[k % len(allowed)]: os.sched_setaffinity(0, {c}))) for k, f in enumerate(files)]
+                ref_counts[name] = sum(int(p_.communicate()[0].split()[0]) for p_ in ps)
+        finally:
+            for f in files:
+                if os.path.exists(f):
+                    os.unlink(f)
+    orc = Oracle()
+    kpre = 50_000                                            # records of the oracle prefix (200 k lines)
+    host = text[:kpre * REC].cpu().numpy()
+    for name, nd in (("fail", 0), ("convert", dev.SQ_CONVERT), ("ignore", dev.SQ_IGNORE)):
+        sc = dev.Scanner()
+        sc.set_profiling(True)
+        opt = dev.SQ_BEST | nd
+        for _ in range(2):
+            cnt = sc.scan_tensor(pat, text, opt, dev.WANT_RECORDS)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cnt = sc.scan_tensor(pat, text, opt, dev.WANT_RECORDS)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kern = sc.last_kernel()
+        exp = orc.buffer_scan(pattern, tau, host, opt)
+        s2 = dev.Scanner()
+        c2 = s2.scan_tensor(pat, text[:kpre * REC], opt, dev.WANT_RECORDS)
+        ok = c2["nmatchlines"] == exp["nmatchlines"] and c2["nlines"] == exp["nlines"] and \
+            np.array_equal(s2.records(c2["nrecords"]).astype(np.uint64), exp["records"])
+        s2.close()
+        row = {"lines_per_s": cnt["nlines"] / dt, "gb_per_s": text.numel() / dt / 1e9, "ms_per_step": dt * 1e3, "kernel": kern,
+               "matching_lines": int(cnt["nmatchlines"]), "oracle_prefix_records_identical": bool(ok)}
+        if ref_counts is not None:
+            row["reference_matching_lines"] = ref_counts[name]
+            row["identical_to_reference_count"] = ref_counts[name] == int(cnt["nmatchlines"])
+            assert row["identical_to_reference_count"], ("FASTQ shape, -x mode %s: GPU %d matching lines, reference %d" % (name, cnt["nmatchlines"], ref_counts[name]))
+        assert ok, "FASTQ shape, mode %s: records of the prefix differ from the oracle's" % name
+        res["modes"][name] = row
+        sc.close()
+    del buf, text
+    return res
+
+
 def oracle_check(text, ranges, read_len, pattern, tau, opt, want_records, rec, scan_block, procs):
     """Run the oracle over the given line ranges of the device text in `procs` child processes (the text of each
     range is copied from HBM to /dev/shm) and compare: records (line, start, end, dist) bit for bit, and per range
@@ -627,6 +718,7 @@ def main():
     ap.add_argument("--no-packed", action="store_true", help="skip the packed-batch scan of the same reads")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI wall-clock measurement (timed region iii)")
     ap.add_argument("--no-multi", action="store_true", help="skip the sixteen-barcode multi-pattern measurement")
+    ap.add_argument("--no-fastq", action="store_true", help="skip the FASTQ-shaped text section (shape Q of SURVEY 8d)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl = RCCL) even at world size 1 and run the step's collectives over it "
@@ -969,6 +1061,15 @@ def main():
                 del pb, pn
             except Exception as e:                      # (reported, not fatal: the ASCII line above is the graded one)
                 out["packed_scan"] = {"error": str(e)}
+        if world == 1 and not args.no_fastq and args.workload in ("best", "count", "all"):
+            # Shape Q (secondary): the first 5 M reads as four-line FASTQ records ("@r<id>", read, "+", 150 Phred+33
+            # bytes that alias onto the alphabet: libseeq.c:265-270), 20 M lines scanned as plain lines under the reference's three
+            # non-DNA modes (-x 0 / 1 / 2), --best with positions; the matching-line count of the WHOLE buffer against the reference
+            # binary's (seeq -c -x <mode>), and the records of a 200 k-line prefix against the oracle.
+            try:
+                out["fastq_shape"] = fastq_shape(text, min(n, 5_000_000), READ_LEN, PATTERN, TAU, pat)
+            except Exception as e:                      # (reported, not fatal)
+                out["fastq_shape"] = {"error": repr(e)}
         if world == 1 and not args.no_multi and args.workload in ("best", "count", "all"):
             # Sixteen barcodes over the first 10 M reads of the buffer (row f4b, seeq_multi.h): ONE walk for the set against a scan per
             # pattern (SEEQ_MULTI=sequential) -- the set holds three windows of the planted pattern and thirteen random 10-mers, d = 1;
