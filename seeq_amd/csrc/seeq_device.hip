@@ -777,6 +777,7 @@ struct ScanKnobs {
    bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
+   bool no_ll_filter;    /* SEEQ_NO_LL_FILTER=1: long lines never take a partition filter (k_stream's Myers mode instead), as before round 4 */
    bool no_skipcount;    /* SEEQ_NO_SKIPCOUNT=1: SQ_IGNORE, every chain with a skipped byte in its warm-up window makes up a candidate, as before round 4 */
    bool old_order;       /* SEEQ_ORDER=old: k_fused_post + k_scanset_* + k_stream_reorder + k_stream_bounds on read-length lines too, as before round 4 (A/B, tests) */
    bool old_verify;      /* SEEQ_VERIFY=old: k_exact1<COUNT> + the three-launch scan behind the filters, as before round 4 (A/B, tests) */
@@ -931,6 +932,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
       v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
       v = getenv("SEEQ_NO_SKIPCOUNT"); kn.no_skipcount = v && atoi(v) == 1;
+      v = getenv("SEEQ_NO_LL_FILTER"); kn.no_ll_filter = v && atoi(v) == 1;
       s->ncu = 256;
       s->lds_per_wg = 65536;
       int dev = 0;
@@ -1253,9 +1255,15 @@ static int run_segments(seeqdev_scan *s)
          if (__atomic_load_n(&mp->sdfa_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_stream(mp, kn.no_filter);
          use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
          if (use_stream && mp->sdfa_parts > 1) {
-            /* a filter: worth it while few lines are false candidates (each costs a whole-line exact scan), and only on
-               read-length lines (the window walk over long lines needs exact candidates) */
-            if (s->avg_line > 600.0 || s->force_ll || mp->sdfa_pacc * s->avg_line > 0.25) use_stream = false;
+            /* a filter: worth it while few lines are false candidates (each costs a whole-line exact scan).  On long lines (round 4)
+               the rate is judged per BYTE: a candidate costs the window walk ~170 columns, the Myers mode steps every byte -- the
+               filter wins below 1.4 (one-word column) / 3.2 (two words) candidates per KB; the walk runs on m + tau + 2 columns behind a candidate's chunk (walk_ext:
+               at most a block, so that a leader's fresh start still lies behind the walk before it) */
+            const bool ll = s->avg_line > 600.0 || s->force_ll;
+            /* (measured on the published sweep's shape, 3.2 GB: filter walk 1.2 ms + 3.3 ms per candidate-per-KB; the Myers mode 6 ms with a
+               one-word column, 11.5 - 13.5 ms with two words -- profiles/r04_chrom_sweep.txt) */
+            const double ll_pacc_max = fw == 1 ? 0.0014 : 0.0032;
+            if (ll ? (kn.no_ll_filter || mp->sdfa_pacc > ll_pacc_max || pat->wlen + pat->tau + 2 > 64) : mp->sdfa_pacc * s->avg_line > 0.25) use_stream = false;
          }
       }
    }
@@ -1449,6 +1457,7 @@ static int run_segments(seeqdev_scan *s)
          uint32_t pos_bias = 0;
          if (use_stream) {
             f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
+            f.ll_filter = (stream_ll && filter && !use_pair && !use_myers) ? 1u : 0u;
             f.skip_thr = (stream_sub == 2 && pat->sdfa_parts == 1 && !kn.no_skipcount) ? (uint32_t)(pat->wlen - pat->tau) : 0u;
             if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
             if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
@@ -1490,6 +1499,7 @@ static int run_segments(seeqdev_scan *s)
          /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
             read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
          a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;
+         a.walk_ext = (stream_ll && filter && !use_pair) ? (uint32_t)(pat->wlen + pat->tau + 2) : 0u;
       } else {
       /* ---- K0: newline index ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[0], st), EIO);

@@ -231,7 +231,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
          win = walk && (last_seg || (lastnl != 0 && (int64_t)hs - (int64_t)a.pos_bias < (int64_t)lastnl));
-         wend = (((hs + col) | (a.stream_ch - 1u)) + 1u) - hs;
+         wend = (((hs + col) | (a.stream_ch - 1u)) + 1u) - hs + a.walk_ext;
       }
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
                      break;
                   }
                   const uint32_t cpos = hit_col[knext++];                 /* position of the repeat's first hit */
-                  const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs;
+                  const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs + a.walk_ext;
                   if (ccol > pos + wback && exact1_clean(a, off + pos, off + ccol - wback)) {   /* jump: fresh column `wback` columns before it */
                      pos = ccol - wback; wend = cend;
                      st.init(m); streak = tau1; latch = false; lastsub = -0x40000000;

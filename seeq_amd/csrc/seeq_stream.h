@@ -317,6 +317,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
          if (LL && lane == 0) { a.tile_dirty[tile] = (flag || badlanes) ? 1u : 0u; a.tile_dmask[tile] = badlanes; }
       }
       uint32_t hmask[NM], nmask[NM];
+      uint32_t blind = 0;                                 /* LL, filter: bit 0 / 1 = chain A / B entered its bytes in the accepting state */
       if (MY) {
          /* ---- Myers mode: one chain per lane, warmed up over the previous lane's last WU words (lane 0: the words before
                  the tile -- one per lane 0..31 in `hal`, '\n' where the buffer starts) ---- */
@@ -365,6 +366,11 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
          stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].y, pb.y), sb, v[NQ / 2 - 1].y);
          stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].z, pb.z), sb, v[NQ / 2 - 1].z);
          stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 1].w, pb.w), sb, v[NQ / 2 - 1].w);
+         /* Long lines behind a partition FILTER (round 4): a chain that enters its own bytes in the accepting state -- a part occurrence
+            ended inside its warm-up window -- stays there until a newline that may be megabytes away and reports nothing.  Behind the
+            complete automaton the exact pass notices (a score <= tau in the columns before the chunk: it then scans the chunk whole);
+            a part occurrence it cannot see -- so the blind chain names its own first byte a candidate and its chunk is scanned. */
+         if (LL && a.ll_filter) blind = ((sa == 16u || sa == acc_new) ? 1u : 0u) | ((sb == 16u || sb == acc_new) ? 2u : 0u);
 #pragma unroll
          for (int r = 0; r < NM / 2; r++) {
             uint32_t hma = 0, hmb = 0;
@@ -381,6 +387,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
       /* ---- newline masks, apart from the walk: SWAR flags + dot products (stream_nl_mask32) ---- */
 #pragma unroll
       for (int r = 0; r < NM; r++) nmask[r] = stream_nl_mask32(v[2 * r], v[2 * r + 1], tile_clean);
+      if (LL && !MY) {
+         if (blind & 1u) hmask[0] |= 0x80000000u;
+         if (blind & 2u) hmask[NM / 2] |= 0x80000000u;
+      }
       if (SUB == 2) {                /* made-up first hits at the first byte of a chain (see SUB) */
          if (a.skip_thr && __ballot(fake != 0)) {
             /* Round 4: most made-up candidates can be ruled out by COUNTING.  An occurrence takes at least m - tau characters that

@@ -1418,12 +1418,13 @@ def test_multi_pattern_workspace_growth(gpu, capi, oracle):
             p.close()
 
 
-@pytest.mark.parametrize("m,k", [(42, 8), (42, 15), (34, 10), (27, 8), (20, 5), (20, 3)])
+@pytest.mark.parametrize("m,k", [(42, 8), (42, 15), (34, 10), (27, 8), (20, 5), (20, 3), (27, 4), (34, 6), (42, 10)])
 def test_published_sweep_cells_small(gpu, capi, oracle, m, k):
     """The reference's published sweep (doc/response.tex:209-232: chromosome lines, m = 20 / 27 / 34 / 42 x k) at a size the oracle
     finishes in seconds: six lines of 200-400 KB of random DNA with mutated copies of the pattern planted, `--all` with
-    positions and both counts against the oracle.  Patterns without an automaton that fits (all but m = 20, k = 3) take
-    k_stream's Myers mode; the full-size cells are profiles/r03_chrom_sweep.txt."""
+    positions and both counts against the oracle.  m = 20, k = 3 has a complete automaton; the other cells a partition filter
+    (taken on long lines when it flags fewer than ~3 positions per KB) or k_stream's Myers mode; the full-size cells are
+    profiles/r04_chrom_sweep.txt."""
     from seeq_amd import device as dev
     rng = random.Random(1000 * m + k)
     pattern = "".join(rng.choice("ACGT") for _ in range(m))
@@ -1443,7 +1444,16 @@ def test_published_sweep_cells_small(gpu, capi, oracle, m, k):
     sc = dev.Scanner()
     exp = oracle.buffer_scan(pattern, k, buf, SQ_ALL)
     got = sc.scan_host(pat, buf, SQ_ALL, dev.WANT_RECORDS)
-    assert sc.last_kernel() == ("k_stream" if (m, k) == (20, 3) else "k_myers"), sc.last_kernel()
+    # (20, 3): the complete automaton; cells whose partition filter makes fewer than ~3 candidates per KB (round 4: the filter on
+    # long lines, the window walk running on m + k + 2 columns behind a candidate's chunk); the rest: k_stream's Myers mode
+    if (m, k) == (20, 3):
+        assert sc.last_kernel() == "k_stream" and not sc.last_filter()
+    elif (m, k) in ((42, 8), (27, 4), (34, 6)):
+        assert sc.last_kernel() == "k_stream" and sc.last_filter(), (sc.last_kernel(), sc.last_filter())
+    elif (m, k) in ((42, 15), (34, 10), (27, 8)):
+        assert sc.last_kernel() == "k_myers", sc.last_kernel()
+    else:
+        assert sc.last_kernel() in ("k_stream", "k_myers")
     assert got["nlines"] == exp["nlines"] == 6 and got["nmatchlines"] == exp["nmatchlines"]
     assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (m, k)
     expb = oracle.buffer_scan(pattern, k, buf, SQ_BEST)
