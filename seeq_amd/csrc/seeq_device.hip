@@ -765,24 +765,7 @@ static MultiPlan *multi_plan_for(MultiPlan **slot, const seeqdev_pattern_t *cons
 /* ========================================================================== */
 /* Scan context                                                               */
 /* ========================================================================== */
-/* Experiment / test knobs, read from the environment ONCE per scan context (seeqdevScanNew). */
-struct ScanKnobs {
-   int  kernel;          /* SEEQ_FUSED_KERNEL: 0 auto, 1 "stream" (k_stream, never k_pair), 2 "direct", 3 "pair" (k_pair wherever the pattern has a pair automaton, selective or not) */
-   int  wgs_per_cu;      /* SEEQ_DFA_WGS: cap on k_stream workgroups per CU (0 = occupancy) */
-   int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
-   bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
-   bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
-   int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
-   int  pair_exp;        /* SEEQ_PAIR_EXP=2..4, builds with -DSEEQ_EXPERIMENTS only: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
-   bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
-   bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
-   bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
-   bool no_ll_filter;    /* SEEQ_NO_LL_FILTER=1: long lines never take a partition filter (k_stream's Myers mode instead), as before round 4 */
-   bool no_skipcount;    /* SEEQ_NO_SKIPCOUNT=1: SQ_IGNORE, every chain with a skipped byte in its warm-up window makes up a candidate, as before round 4 */
-   bool old_order;       /* SEEQ_ORDER=old: k_fused_post + k_scanset_* + k_stream_reorder + k_stream_bounds on read-length lines too, as before round 4 (A/B, tests) */
-   bool old_verify;      /* SEEQ_VERIFY=old: k_exact1<COUNT> + the three-launch scan behind the filters, as before round 4 (A/B, tests) */
-   bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
-};
+#include "seeq_plan.h"          /* ScanKnobs, seeq_plan_scan: which kernels serve a scan (pure host code) */
 
 struct OccMemo { const void *fn; size_t lds; int per_cu; };
 
@@ -933,6 +916,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
       v = getenv("SEEQ_NO_SKIPCOUNT"); kn.no_skipcount = v && atoi(v) == 1;
       v = getenv("SEEQ_NO_LL_FILTER"); kn.no_ll_filter = v && atoi(v) == 1;
+      v = getenv("SEEQ_EXPLAIN");      kn.explain = v && atoi(v) == 1;
       s->ncu = 256;
       s->lds_per_wg = 65536;
       int dev = 0;
@@ -1208,6 +1192,23 @@ static int occupancy_of(seeqdev_scan *s, const void *fn, int threads, size_t lds
 
 static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st);
 
+/* what the planner (seeq_plan.h) needs to know of the pattern's automata, and how it asks for one that has not been tried yet */
+static void pattern_automata(const seeqdev_pattern *p, PlanAutomata *au)
+{
+   au->sdfa_state = __atomic_load_n(&p->sdfa_state, __ATOMIC_ACQUIRE);
+   au->sdfa_parts = p->sdfa_parts; au->sdfa_warm = p->sdfa_warm; au->sdfa_pacc = p->sdfa_pacc;
+   au->pair_state = __atomic_load_n(&p->pair_state, __ATOMIC_ACQUIRE);
+   au->pair_warm = p->pair_warm; au->pair_pacc = p->pair_pacc;
+}
+
+static void plan_ensure(void *ctx, int which, int complete_only, PlanAutomata *au)
+{
+   seeqdev_pattern *mp = (seeqdev_pattern *)ctx;
+   if (which == 0) pattern_plan_stream(mp, complete_only != 0);
+   else pattern_plan_pair(mp);
+   pattern_automata(mp, au);
+}
+
 template <int W>
 static int run_segments(seeqdev_scan *s)
 {
@@ -1216,8 +1217,6 @@ static int run_segments(seeqdev_scan *s)
    const bool fasta = (options & SEEQDEV_FASTA) != 0;
    const bool single = (options & SEEQDEV_SINGLELINE) != 0;
    const int match_opt = options & 3;
-   bool need_nh = want == SEEQDEV_WANT_COUNTMATCH || (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
-   const bool nh_is_count = need_nh;                      /* nh[] = hits per line; else (superset filters) a 0/1 verdict per line */
    const size_t nbytes = s->nbytes;
    Counters *c = s->d_cnt;
 
@@ -1230,89 +1229,36 @@ static int run_segments(seeqdev_scan *s)
    unsigned grid_lines = (unsigned)(line_blocks < (size_t)ncu * 16 ? line_blocks : (size_t)ncu * 16);
    if (grid_lines == 0) grid_lines = 1;
 
-   /* Path selection.  Patterns of <= 62 positions (one or two Myers words with two spare flag bits) on line input
-      take a ONE-PASS scan kernel + the exact pass k_exact1; everything else the generic index + k_forward<W> path. */
-   /* fw = words of the one-pass kernels' column: 1 for <= 30 positions, 2 for 31..62 */
-   const int fw = pat->wlen <= FUSED_MAX_WLEN ? 1 : 2;
-   const bool fusable = !single && pat->wlen <= FUSED_MAX_WLEN2;
-   /* k_stream: line-agnostic table-driven scan (seeq_stream.h), the default whenever the pattern has an automaton that
-      fits LDS (seeq_dfa.h): the complete Levenshtein automaton (its verdicts are exact) or, for longer patterns /
-      larger distances, a partition FILTER automaton (its hit lines are candidates: the exact pass verifies them). */
-   bool use_stream = false, can_sub = false;
+   /* ---- the plan (seeq_plan.h: a pure function of the pattern, the options, the text's line length and this context's fall-back
+           flags); the rest of this function executes it ---- */
+   PlanIn pin;
+   memset(&pin, 0, sizeof pin);
+   pin.wlen = pat->wlen; pin.tau = pat->tau; pin.options = options; pin.want = want;
+   pin.avg_line = s->avg_line; pin.line_hint = s->line_hint; pin.force_path = s->force_path;
+   pin.no_stream = s->no_stream; pin.force_ll = s->force_ll; pin.no_stream_nd = s->no_stream_nd; pin.no_window = s->no_window;
+   pin.no_leaders = s->no_leaders; pin.sample_dirty = s->sample_dirty; pin.multi_active = s->multi_active;
+   pin.seg_bytes = s->seg_bytes; pin.kn = &kn;
+   PlanAutomata au;
+   pattern_automata(pat, &au);
+   const ScanPlan plan = seeq_plan_scan(pin, au, plan_ensure, const_cast<seeqdev_pattern *>(pat));
+   if (kn.explain) seeq_plan_print(stderr, pin, au, plan);
+   if (plan.rc) return plan.rc;
+   const int fw = plan.fw;
+   const bool use_stream = plan.use_stream, use_pair = plan.use_pair, use_myers = plan.use_myers, filter = plan.filter, use_fused = plan.use_fused;
    const int stream_ch = 128;                 /* bytes per lane of k_stream / k_pair */
-   {
-      /* SQ_FAIL: always.  SQ_CONVERT: exact through the SUB variant (non-DNA bytes replaced by 'N' in registers).
-         SQ_IGNORE on read-length lines: the SUB variant with skip bytes (its hit lines become candidates where a skipped
-         byte sits in a warm-up window).  Otherwise (SQ_IGNORE on long lines; without SUB) k_stream is exact on clean text
-         only: it runs until it meets a non-DNA byte (Counters.dirty -> overflow flag 16: the scan is re-run on the per-line
-         kernels, for good), and not on FASTA input (header lines are made of such bytes). */
-      const int nd = options & MASK_NONDNA;
-      const bool long_lines = s->avg_line > 600.0 || s->force_ll;
-      can_sub = (nd == SQ_CONVERT || (nd == SQ_IGNORE && !long_lines && !s->no_stream_nd)) && !fasta && !kn.no_sub;
-      const bool dfa_opts = (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || can_sub || (!s->no_stream_nd && !fasta));
-      if (fusable && s->force_path != 1 && dfa_opts && !s->no_stream && kn.kernel != 2) {
-         seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
-         if (__atomic_load_n(&mp->sdfa_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_stream(mp, kn.no_filter);
-         use_stream = mp->sdfa_state == 1 && s->seg_bytes % (64u * (unsigned)stream_ch) == 0;
-         if (use_stream && mp->sdfa_parts > 1) {
-            /* a filter: worth it while few lines are false candidates (each costs a whole-line exact scan).  On long lines (round 4)
-               the rate is judged per BYTE: a candidate costs the window walk ~170 columns, the Myers mode steps every byte -- the
-               filter wins below 1.4 (one-word column) / 3.2 (two words) candidates per KB; the walk runs on m + tau + 2 columns behind a candidate's chunk (walk_ext:
-               at most a block, so that a leader's fresh start still lies behind the walk before it) */
-            const bool ll = s->avg_line > 600.0 || s->force_ll;
-            /* (measured on the published sweep's shape, 3.2 GB: filter walk 1.2 ms + 3.3 ms per candidate-per-KB; the Myers mode 6 ms with a
-               one-word column, 11.5 - 13.5 ms with two words -- profiles/r04_chrom_sweep.txt) */
-            const double ll_pacc_max = fw == 1 ? 0.0014 : 0.0032;
-            if (ll ? (kn.no_ll_filter || mp->sdfa_pacc > ll_pacc_max || pat->wlen + pat->tau + 2 > 64) : mp->sdfa_pacc * s->avg_line > 0.25) use_stream = false;
-         }
-      }
-   }
-   /* k_pair (seeq_pair.h): the same walk, two text bytes per table step, over the pattern's pair automaton -- a prefix or a
-      partition filter, so every hit line of it is a candidate.  Read-length lines under SQ_FAIL / SQ_CONVERT (aliased bytes
-      keep a superset a superset; a skipped byte, SQ_IGNORE, does not), while it makes few false candidates. */
-   bool use_pair = false;
-   {
-      const int nd = options & MASK_NONDNA;
-      const bool long_lines = (s->avg_line > 600.0 && kn.kernel != 3) || s->force_ll;      /* (a candidate inside a line of a whole tile sets force_ll) */
-      if (fusable && s->force_path != 1 && (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || nd == SQ_CONVERT) && !long_lines && !s->no_stream &&
-          (kn.kernel == 3 || (kn.kernel == 0 && !(s->sample_dirty && s->line_hint <= 0))) && s->seg_bytes % (64u * 128u) == 0) {
-         seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
-         if (__atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
-         use_pair = mp->pair_state == 1 && (kn.kernel == 3 || s->multi_active || mp->pair_pacc * s->avg_line <= 0.25);
-      }
-      if (use_pair) { use_stream = true; can_sub = false; }
-      if (s->multi_active && !use_pair) return -2;       /* this text / these options are not k_pair's: a scan per pattern */
-   }
-   /* k_stream's Myers mode: no automaton fits (or only a filter, which serves read-length lines), the lines are too long for
-      the per-line kernels -- the same line-agnostic chunks, the bit-vector column instead of the table (seeq_stream.h) */
-   bool use_myers = false;
-   {
-      const int nd = options & MASK_NONDNA;
-      if (!use_stream && !use_pair && fusable && s->force_path != 1 && (options & MASK_INPUT) == 0 && (nd == SQ_FAIL || nd == SQ_CONVERT) &&
-          kn.kernel != 2 && !kn.no_myers && !s->no_stream && (s->avg_line > 260.0 || s->force_ll) && s->seg_bytes % (64u * 128u) == 0) {
-         use_myers = true; use_stream = true; can_sub = false;
-      }
-   }
-   const bool filter = use_pair || (use_stream && !use_myers && pat->sdfa_parts > 1);
-   bool use_fused = fusable && (s->avg_line <= 260.0 || use_stream) && s->force_path != 1;      /* k_direct regions are <= 16 KiB (~62 lines) */
+   const int stream_wu = plan.stream_wu;
    uint32_t tile_bytes = 0;
    unsigned fused_grid = 1;
    int nw = 4;
    unsigned nslices = 1;                      /* hit slices: one per wave */
-   int stream_wu = !use_stream ? 8 : pat->sdfa_warm <= 16 ? 4 : pat->sdfa_warm <= 24 ? 6 : 8;     /* warm-up dwords */
-   if (use_pair) stream_wu = pat->pair_warm <= 16 ? 4 : (pat->pair_warm + 3) / 4;
-   if (stream_wu < kn.min_wu) stream_wu = kn.min_wu >= 8 ? 8 : 6;
-   if (use_myers) stream_wu = pat->wlen + pat->tau - 1 <= 64 ? 16 : 32;        /* (an 8-word instance exists in principle; the one-word one the compiler makes of it spills 189 registers) */
    const void *stream_fn = nullptr;
-   bool stream_ll = false;
-   int stream_sub = 0;                        /* 0, 1: SQ_CONVERT ('N' for non-DNA bytes), 2: SQ_IGNORE (skip bytes) */
+   const bool stream_ll = plan.stream_ll;
+   const int stream_sub = plan.stream_sub;    /* 0, 1: SQ_CONVERT ('N' for non-DNA bytes), 2: SQ_IGNORE (skip bytes) */
    size_t dfa_lds = 0;
    if (use_fused) {
       if (use_stream) {
          nw = STREAM_NW;
          tile_bytes = 64u * (uint32_t)stream_ch;
-         stream_ll = s->avg_line > 600.0 || s->force_ll;      /* long lines: bookkeeping for the window walk */
-         stream_sub = can_sub ? ((options & MASK_NONDNA) == SQ_IGNORE ? 2 : 1) : 0;
          /* the k_stream instance of this scan: <warm-up dwords, FASTA, long lines, SUB> */
 #define SEEQ_STREAM_FN(...) (stream_wu == 4 ? (const void *)k_stream<4, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_stream<6, __VA_ARGS__> \
                                                                                                       : (const void *)k_stream<8, __VA_ARGS__>)
@@ -1323,14 +1269,12 @@ static int run_segments(seeqdev_scan *s)
 #undef SEEQ_STREAM_FN
          dfa_lds = ((size_t)pat->sdfa_rows * 16 + 15) & ~(size_t)15;
          if (use_myers) {
-            stream_ll = true; stream_sub = 0;               /* (the window walk of the exact pass serves every line length) */
 #define SEEQ_MYERS_FN(FA, MY) (stream_wu == 16 ? (const void *)k_stream<16, FA, true, 0, MY> : (const void *)k_stream<32, FA, true, 0, MY>)
             stream_fn = fw == 1 ? (fasta ? SEEQ_MYERS_FN(true, 1) : SEEQ_MYERS_FN(false, 1)) : (fasta ? SEEQ_MYERS_FN(true, 2) : SEEQ_MYERS_FN(false, 2));
 #undef SEEQ_MYERS_FN
             dfa_lds = (size_t)256 * fw * sizeof(uint32_t);
          }
          if (use_pair) {
-            stream_ll = false; stream_sub = 0;
 #define SEEQ_PAIR_FN(...) (stream_wu == 4 ? (const void *)k_pair<4, __VA_ARGS__> : stream_wu == 5 ? (const void *)k_pair<5, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_pair<6, __VA_ARGS__> \
                           : stream_wu == 7 ? (const void *)k_pair<7, __VA_ARGS__> : (const void *)k_pair<8, __VA_ARGS__>)
             stream_fn = fasta ? SEEQ_PAIR_FN(true) : SEEQ_PAIR_FN(false);
@@ -1390,12 +1334,12 @@ static int run_segments(seeqdev_scan *s)
          s->eq_options = options;
       }
    }
-   const bool use_direct = use_fused && !use_stream;
-   s->last_path = use_fused ? (use_pair ? 6 : use_myers ? 7 : use_stream ? 5 : 3) : 1;
+   const bool use_direct = plan.use_direct;
+   s->last_path = plan.path;
    s->last_filter = filter;
-   const bool superset = use_stream;                     /* the scan kernel's hit lines are candidates: nh[] decides */
-   if (superset) need_nh = true;
-   const bool generic_exact = !superset && kn.exact_generic;      /* A/B knob */
+   const bool superset = plan.superset;                  /* the scan kernel's hit lines are candidates: nh[] decides */
+   const bool need_nh = plan.need_nh, nh_is_count = plan.nh_is_count;
+   const bool generic_exact = plan.generic_exact;        /* A/B knob */
 
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
@@ -1435,8 +1379,8 @@ static int run_segments(seeqdev_scan *s)
       a.records = s->records; a.cap_records = s->cap_records; a.rec_off = s->rec_off;
       a.use_nh = need_nh ? (use_stream ? 3u : 1u) : 0u;
       a.filter = filter ? 1u : 0u;
-      a.skip_back = (uint32_t)(pat->wlen + pat->tau - 1) + (use_pair ? 1u : 0u);    /* (k_pair reports the second byte of a pair) */
-      a.window_ok = use_pair && !s->no_window && !kn.no_window ? 1u : 0u;
+      a.skip_back = plan.skip_back;
+      a.window_ok = plan.window_ok ? 1u : 0u;
       a.cnt = c;
 
       if (use_fused) {
@@ -1457,8 +1401,8 @@ static int run_segments(seeqdev_scan *s)
          uint32_t pos_bias = 0;
          if (use_stream) {
             f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
-            f.ll_filter = (stream_ll && filter && !use_pair && !use_myers) ? 1u : 0u;
-            f.skip_thr = (stream_sub == 2 && pat->sdfa_parts == 1 && !kn.no_skipcount) ? (uint32_t)(pat->wlen - pat->tau) : 0u;
+            f.ll_filter = plan.ll_filter ? 1u : 0u;
+            f.skip_thr = plan.skip_thr;
             if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
             if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
             /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
@@ -1480,7 +1424,7 @@ static int run_segments(seeqdev_scan *s)
          if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
          /* read-length lines behind k_pair / k_stream: the three launches of seeq_order.h; else (long lines, k_direct) the seven of before */
          const uint32_t order_nb = (f.ntiles + SEEQ_ORDER_BLOCK - 1) / SEEQ_ORDER_BLOCK;
-         order2 = use_stream && !f.tile_dirty && !kn.old_order && order_nb <= SEEQ_ORDER_MAX_BLOCKS && 2 * (size_t)order_nb <= s->cap_scan_ws;
+         order2 = plan.order2 && order_nb <= SEEQ_ORDER_MAX_BLOCKS && 2 * (size_t)order_nb <= s->cap_scan_ws;
          if (order2) {
             const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
             seeq_launch_tiles_post(st, f, (uint32_t)nsl, s->scan_ws, order_nb);
@@ -1499,7 +1443,7 @@ static int run_segments(seeqdev_scan *s)
          /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
             read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
          a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;
-         a.walk_ext = (stream_ll && filter && !use_pair) ? (uint32_t)(pat->wlen + pat->tau + 2) : 0u;
+         a.walk_ext = plan.walk_ext;
       } else {
       /* ---- K0: newline index ---- */
       if (ev) HIP_TRY(hipEventRecord(ev[0], st), EIO);
@@ -1538,8 +1482,7 @@ static int run_segments(seeqdev_scan *s)
             continue;
          }
          /* long lines, every hit counted: candidates far behind the one before them get a lane of their own (seeq_stream.h, leaders) */
-         const bool lead_best = want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST;      /* (one record per line: the groups' best hits are reduced per line) */
-         const bool leaders = use_stream && stream_ll && (nh_is_count || lead_best) && use_fused && !generic_exact && !kn.no_leaders && !s->no_leaders;
+         const bool lead_best = plan.lead_best, leaders = plan.leaders;
          const uint32_t lead_wback = a.skip_back > 32u ? a.skip_back : 32u;
          if (leaders) {
             if (s->cap_hitlines > s->cap_lead) {
@@ -1569,8 +1512,7 @@ static int run_segments(seeqdev_scan *s)
          /* behind the filters (every hit line is a candidate) on text where no byte is skipped: k_verify (seeq_verify.h) -- the lean
             two-phase exact pass with the scan of its counts inside; the EMIT pass behind it ends the segment */
          bool emitted = false;                                /* the records are out (k_emit1) */
-         const bool verify = need_nh && use_fused && !generic_exact && filter && !a.stream_ch && !kn.old_verify &&
-                             (options & (SQ_IGNORE | SQ_STREAM)) == 0 && !a.tile_dirty;
+         const bool verify = plan.verify;
          const int seg_flags = (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0);
          if (verify) {
             const bool count_any = want != SEEQDEV_WANT_COUNTMATCH && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);

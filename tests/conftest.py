@@ -39,7 +39,8 @@ def harness():
     src = os.path.join(ROOT, "tests", "host_harness.cpp")
     core = os.path.join(ROOT, "seeq_amd", "csrc", "seeq_kernel_core.h")
     dfa = os.path.join(ROOT, "seeq_amd", "csrc", "seeq_dfa.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core), os.path.getmtime(dfa)):
+    plan = os.path.join(ROOT, "seeq_amd", "csrc", "seeq_plan.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core), os.path.getmtime(dfa), os.path.getmtime(plan)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", src, "-o", so])
     H = C.CDLL(so)
     H.harness_scan.restype = C.c_long

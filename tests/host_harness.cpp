@@ -285,3 +285,50 @@ extern "C" int harness_multi_resolve(const uint8_t *text, const char *keys, cons
    seeq_multi_free(d);
    return 0;
 }
+
+
+// ---- the scan planner (seeq_amd/csrc/seeq_plan.h): the same pure function run_segments executes, with the automata built on the
+//      host alone (seeq_dfa.h) -- which kernels would serve this pattern / these options / this line length? ----
+#include "../seeq_amd/csrc/seeq_plan.h"
+
+namespace {
+struct plan_ctx { const char *keys; int m, tau; };
+void plan_ensure_host(void *ctx, int which, int complete_only, PlanAutomata *au)
+{
+   const plan_ctx *c = (const plan_ctx *)ctx;
+   if (which == 0) {
+      seeq_dfa_t *d = c->m <= 62 ? seeq_dfa_plan_stream(c->keys, c->m, c->tau, complete_only) : NULL;
+      au->sdfa_state = d ? 1 : -1;
+      if (d) { au->sdfa_parts = d->nparts; au->sdfa_warm = d->warm; au->sdfa_pacc = d->p_accept; seeq_dfa_free(d); }
+   } else {
+      seeq_pair_t *d = c->m <= 62 ? seeq_pair_plan(c->keys, c->m, c->tau) : NULL;
+      au->pair_state = d ? 1 : -1;
+      if (d) { au->pair_warm = d->warm; au->pair_pacc = d->p_accept; seeq_pair_free(d); }
+   }
+}
+}  // namespace
+
+// flags: bit 0 force_ll, 1 no_stream, 2 no_stream_nd, 3 no_window, 4 sample_dirty, 5 multi_active; knob_kernel: SEEQ_FUSED_KERNEL (0 auto).
+// out[16]: rc, path, fw, use_stream, use_pair, use_myers, filter, stream_ll, stream_sub, stream_wu, verify, order2, leaders, window_ok,
+//          ll_filter, skip_back.  Returns 0.
+extern "C" int harness_plan(const char *keys, int m, int tau, int options, int want, double avg_line, int flags, int knob_kernel, int *out)
+{
+   ScanKnobs kn;
+   std::memset(&kn, 0, sizeof kn);
+   kn.kernel = knob_kernel;
+   PlanIn in;
+   std::memset(&in, 0, sizeof in);
+   in.wlen = m; in.tau = tau; in.options = options; in.want = want; in.avg_line = avg_line;
+   in.force_ll = flags & 1; in.no_stream = (flags >> 1) & 1; in.no_stream_nd = (flags >> 2) & 1; in.no_window = (flags >> 3) & 1;
+   in.sample_dirty = (flags >> 4) & 1; in.multi_active = (flags >> 5) & 1;
+   in.seg_bytes = (size_t)0xF0000000u;
+   in.kn = &kn;
+   PlanAutomata au;
+   std::memset(&au, 0, sizeof au);
+   plan_ctx ctx = {keys, m, tau};
+   const ScanPlan p = seeq_plan_scan(in, au, plan_ensure_host, &ctx);
+   const int v[16] = {p.rc, p.path, p.fw, p.use_stream, p.use_pair, p.use_myers, p.filter, p.stream_ll, p.stream_sub, p.stream_wu, p.verify, p.order2,
+                      p.leaders, p.window_ok, p.ll_filter, (int)p.skip_back};
+   for (int i = 0; i < 16; i++) out[i] = v[i];
+   return 0;
+}

@@ -398,3 +398,54 @@ def test_multi_pattern_automata_cover_every_pattern_of_every_line(harness, oracl
                     sub = oracle.string_match(pats[k], taus[k], lines[ln - 1][a:b], SQ_ALL)[::-1]
                     assert [(s + a, e + a, d) for s, e, d in sub] == want[k][ln], (pats[k], ln, a, b)
     assert nsets == len(sets)
+
+
+def test_scan_plans_of_the_baseline_configurations(harness):
+    """The planner (seeq_amd/csrc/seeq_plan.h) is a pure host function -- run_segments only executes what it returns -- so which
+    kernels serve the BASELINE configurations, the published sweep's cells and the FASTQ shape can be pinned without a GPU."""
+    import ctypes as C
+    H = harness
+    H.harness_plan.restype = C.c_int
+    H.harness_plan.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    names = ["rc", "path", "fw", "use_stream", "use_pair", "use_myers", "filter", "stream_ll", "stream_sub", "stream_wu", "verify", "order2",
+             "leaders", "window_ok", "ll_filter", "skip_back"]
+
+    def plan(expr, tau, options, want, avg_line, flags=0, kernel=0):
+        keys = C.create_string_buffer(2048)
+        err = C.c_int(0)
+        m = H.harness_compile(expr.encode(), keys, C.byref(err))
+        assert m > 0
+        out = (C.c_int * 16)()
+        assert H.harness_plan(keys, m, tau, options, want, avg_line, flags, kernel, out) == 0
+        return dict(zip(names, list(out)))
+    SQ_BEST, SQ_ALL, SQ_CONVERT, SQ_IGNORE, FASTA = 1, 2, 4, 8, 0x100
+    COUNTLINES, COUNTMATCH, RECORDS = 0, 1, 2
+    head = "GATGTAGCGCGATTAGCCTG"
+    # configs[1] / [2]: 150 bp reads, 20-mer, d = 3 -- k_pair over the prefix automaton, candidate windows, k_verify, three-launch ordering
+    for opt, want in ((0, COUNTLINES), (SQ_BEST, RECORDS), (SQ_ALL, RECORDS), (0, COUNTMATCH)):
+        p = plan(head, 3, opt, want, 151.0)
+        assert (p["rc"], p["path"], p["fw"], p["use_pair"], p["filter"], p["stream_ll"]) == (0, 6, 1, 1, 1, 0), p
+        assert p["verify"] == 1 and p["order2"] == 1 and p["window_ok"] == 1 and p["leaders"] == 0 and p["skip_back"] == 23, p
+    # configs[4]: 40 positions, d = 5, 250 bp reads, --all: two-word column, a partition filter on k_pair
+    p = plan("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5, SQ_ALL, RECORDS, 251.0)
+    assert (p["path"], p["fw"], p["use_pair"], p["filter"], p["verify"], p["order2"]) == (6, 2, 1, 1, 1, 1), p
+    # SQ_IGNORE is not k_pair's (a skipped byte stretches a match): k_stream over the complete automaton with skip bytes, k_exact1 behind it
+    p = plan(head, 3, SQ_BEST | SQ_IGNORE, RECORDS, 79.0)
+    assert (p["path"], p["use_pair"], p["stream_sub"], p["filter"], p["verify"], p["order2"]) == (5, 0, 2, 0, 0, 1), p
+    p = plan(head, 3, SQ_BEST | SQ_CONVERT, RECORDS, 79.0, flags=16)      # FASTQ-shaped sample (foreign bytes): k_stream, substituting variant
+    assert (p["path"], p["use_pair"], p["stream_sub"]) == (5, 0, 1), p
+    # the published sweep (chromosome lines): complete automaton / partition filter on long lines / Myers mode
+    p = plan(head, 3, SQ_ALL, RECORDS, 1.3e8)
+    assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"], p["verify"], p["order2"]) == (5, 1, 0, 0, 1, 0, 0), p
+    full = "GATGTAGCGCGATTAGCCTGAAAATGCGAGTACGGCGCGAAT"
+    p = plan(full[:27], 4, SQ_ALL, RECORDS, 1.3e8)
+    assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (5, 1, 1, 1, 1), p
+    p = plan(full, 15, SQ_ALL, RECORDS, 1.3e8)
+    assert (p["path"], p["use_myers"], p["fw"], p["stream_ll"], p["filter"]) == (7, 1, 2, 1, 0), p
+    # patterns beyond the two-word column, SQ_STREAM input: the generic path; a multi-pattern scan that is not k_pair's: a scan per pattern
+    assert plan("ACGT" * 20, 4, 0, COUNTLINES, 151.0)["path"] == 1
+    assert plan(head, 3, 0x10, COUNTLINES, 151.0)["path"] in (1, 3)
+    assert plan(head, 3, SQ_IGNORE, COUNTLINES, 151.0, flags=32)["rc"] == -2
+    # a context that has met a line of a whole tile (force_ll) leaves k_pair for k_stream's long-line variant
+    p = plan(head, 3, SQ_BEST, RECORDS, 151.0, flags=1)
+    assert (p["path"], p["use_pair"], p["stream_ll"]) == (5, 0, 1), p
