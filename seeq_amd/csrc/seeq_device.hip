@@ -1689,7 +1689,7 @@ static int run_packed(seeqdev_scan *s)
       /* candidates before every block of 64 reads, their number */
       launch_scanset(s, st, s->pk_coff, nullptr, nullptr, (p.nreads + 63u) >> 6, &c->seg_nhitlines, nullptr, nullptr);
       hipLaunchKernelGGL(k_packed_counts, dim3(1), dim3(1), 0, st, p);
-      hipLaunchKernelGGL(k_packed_list, dim3((unsigned)(((size_t)p.nreads / 64 + 256) / 256)), dim3(256), 0, st, p);
+      hipLaunchKernelGGL(k_packed_list, dim3((unsigned)(((size_t)p.nreads / 1024 + 4) / 4)), dim3(256), 0, st, p);      /* a wave per 16 blocks of 64 reads */
       /* from here: the exact pass over the staging text, as behind k_pair */
       ScanArgs a;
       memset(&a, 0, sizeof a);

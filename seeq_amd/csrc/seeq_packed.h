@@ -198,27 +198,46 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
    }
 }
 
-/* The hit list of the candidate reads: one lane per BLOCK of 64 reads walks the set bits of the block's mask (three of them
-   on a read set with planted hits; a lane per read spent 55 us per 16 Mi reads looking at 95 % empty positions). */
+/* The hit list of the candidate reads.  A wave takes sixteen blocks of 64 reads at a time: sixteen lanes spread their block's mask
+   into read numbers in LDS (three bits each on a read set with planted hits), then all 64 lanes fetch {candidate columns, staging
+   line} of one candidate each and store the entries side by side.  (One lane per block walking its own bits -- dependent loads,
+   scattered stores -- took 60 us per 16 Mi reads; one lane per read 55 us, 95 % of them looking at nothing.) */
 __global__ __launch_bounds__(256) void k_packed_list(PackedArgs a)
 {
-   const uint32_t stride = gridDim.x * 256;
+   __shared__ uint32_t s_r[4][1024];
+   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
    const uint32_t nblocks = (a.nreads + 63u) >> 6;
-   for (uint32_t blk = blockIdx.x * 256 + threadIdx.x; blk < nblocks; blk += stride) {
-      uint64_t mask = a.bmask[blk];
-      uint32_t k = a.boff[blk];
+   const uint32_t ngroups = (nblocks + 15u) >> 4;
+   for (uint32_t g = blockIdx.x * 4u + wave; g < ngroups; g += gridDim.x * 4u) {
+      const uint32_t blk = g * 16u + lane;
+      const bool own = lane < 16u && blk < nblocks;
+      uint64_t mask = own ? a.bmask[blk] : 0ull;
+      const uint32_t off = own ? a.boff[blk] : 0u;
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      const uint32_t incl = wave_incl_scan_u32(cnt);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);      /* (boff is the exclusive scan of the blocks' counts: lane i's first entry is k0 + the counts before it) */
+      uint32_t e = incl - cnt;
       while (mask) {
-         const uint32_t r = blk * 64u + (uint32_t)__builtin_ctzll(mask);
+         s_r[wave][e++] = blk * 64u + (uint32_t)__builtin_ctzll(mask);
          mask &= mask - 1ull;
-         if (k >= a.cap) break;                            /* (the overflow is reported by k_packed_counts) */
-         const uint32_t cd = a.cand[r];
-         a.hit_start[k] = a.cslot[r] * a.pitch;
-         a.hit_line[k] = (uint32_t)(a.line_base + r + 1u);
-         a.hit_col[k] = cd >> 16;
-         a.hit_last[k] = cd & 0xFFFFu;
-         a.nh[k] = 0u;
-         k++;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+         const uint32_t ei = e0 + lane, k = k0 + ei;
+         if (ei < total && k < a.cap) {                     /* (k >= cap: the overflow is reported by k_packed_counts) */
+            const uint32_t r = s_r[wave][ei];
+            const uint32_t cd = a.cand[r], sl = a.cslot[r];
+            a.hit_start[k] = sl * a.pitch;
+            a.hit_line[k] = (uint32_t)(a.line_base + r + 1u);
+            a.hit_col[k] = cd >> 16;
+            a.hit_last[k] = cd & 0xFFFFu;
+            a.nh[k] = 0u;
+         }
+      }
+      __builtin_amdgcn_wave_barrier();                     /* (the next group's writes behind this group's reads) */
    }
 }
 
