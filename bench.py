@@ -844,7 +844,7 @@ def main():
     fwd_ms = 0.0
     fwd_launches = 0
     idx_ms = ex_ms = 0.0
-    step_wall, step_fwd, step_post, launch_ms = [], [], [], []
+    step_wall, step_fwd, step_post, launch_ms, step_clk = [], [], [], [], []
     for _ in range(args.steps):
         ts = time.perf_counter()
         total, local = step()
@@ -856,6 +856,9 @@ def main():
         ex_ms += tm["exact"]
         step_fwd.append(tm["forward"]); step_post.append(tm["exact"])
         launch_ms.extend(sc.last_launch_times_ms())
+        clk = sc.last_clock_mhz()
+        if clk > 0:
+            step_clk.append(clk)
     if clocks:
         clocks.stop()
     if force_dist:      # the all-gather of the global line numbering (seeq.c:377) through the shard layer, over RCCL
@@ -965,6 +968,8 @@ def main():
             "per_step": {"ms": stats3(step_wall), "forward_scan_ms": stats3(step_fwd), "post_pass_ms": stats3(step_post),
                          "scan_launch_ms_full_segments": stats3([x for i, x in enumerate(launch_ms) if (i + 1) % max(1, int(launches_per_step)) != 0 or launches_per_step == 1]),
                          "scan_launch_ms_all": [round(x, 4) for x in launch_ms[:64]],
+                         # the scan kernel's own reading of the clock it ran at: shader clock / constant 100 MHz counter around its first wave's work
+                         "scan_kernel_core_clock_mhz": stats3(step_clk),
                          "gpu_clock_power_during_steps": clocks.summary() if clocks else None},
             "roofline": {"bound": "hbm", "kernel": kern + (" (partition filter automaton)" if filt else ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,

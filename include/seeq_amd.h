@@ -216,6 +216,9 @@ int seeqdevScanLastLaunches(const seeqdev_scan_t * scan);
 /* The same per launch: the duration (ms) of each of the last run's forward-scan
  * launches, in launch order, up to `cap` of them; returns how many there were. */
 int seeqdevScanLastLaunchTimes(const seeqdev_scan_t * scan, float * ms, int cap);
+/* The core clock (MHz) the last run's scan launches actually ran at: the kernel's first wave reads the shader clock
+ * and the constant 100 MHz counter before and after its tiles (k_pair, profiling on); 0 when not measured. */
+float seeqdevScanLastClockMHz(const seeqdev_scan_t * scan);
 
 /* Synthetic shape-R reads written straight into HBM (bench/test input; spec
  * in SURVEY.md section 8d, CPU twin in oracle/seeq_oracle.c): n lines of

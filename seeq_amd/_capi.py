@@ -64,7 +64,7 @@ EXPORTS = [
     "seeqdevDeviceCount", "seeqdevSetDevice", "seeqdevLastError", "seeqdevPatternNew", "seeqdevPatternFree",
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
-    "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevScanLastLaunchTimes", "seeqdevSynthReads",
+    "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevScanLastLaunchTimes", "seeqdevScanLastClockMHz", "seeqdevSynthReads",
     "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
     "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanLastMulti", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
@@ -171,6 +171,8 @@ def lib():
     L.seeqdevScanLastLaunches.restype = C.c_int
     L.seeqdevScanLastLaunchTimes.argtypes = [C.c_void_p, P(C.c_float), C.c_int]
     L.seeqdevScanLastLaunchTimes.restype = C.c_int
+    L.seeqdevScanLastClockMHz.argtypes = [C.c_void_p]
+    L.seeqdevScanLastClockMHz.restype = C.c_float
     L.seeqdevScanSetLineHint.argtypes = [C.c_void_p, C.c_double]
     L.seeqdevScanSetLineHint.restype = C.c_int
     L.seeqdevScanLastPath.argtypes = [C.c_void_p]

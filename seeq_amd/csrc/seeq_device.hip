@@ -777,6 +777,9 @@ struct seeqdev_scan {
    bool        have_h2d_ev;
    float       h2d_ms;            /* ... of the last fetched scan */
    float      *launch_ms; size_t cap_launch_ms;      /* per forward-scan launch of the last fetched scan (profiling) */
+   unsigned long long *clk_probe;  /* page-locked, 4 words per segment: the scan kernel's own clock readings (profiling; k_pair) */
+   size_t      cap_clk_probe;
+   float       clk_mhz;           /* core clock the last run's scan launches ran at (mean over the launches; 0: not measured) */
    int         ncu;               /* compute units of the device (cached) */
    size_t      lds_per_wg;        /* LDS a workgroup may allocate on it */
    ScanKnobs   knobs;
@@ -959,6 +962,7 @@ extern "C" void seeqdevScanFree(seeqdev_scan_t *s)
    for (size_t i = 0; i < 4 * s->nev_seg; i++) (void)hipEventDestroy(s->ev[i]);
    free(s->ev);
    free(s->launch_ms);
+   if (s->clk_probe) (void)hipHostFree(s->clk_probe);
    free(s->multi_cnt); free(s->multi_first);
    if (s->multi_rec) (void)hipHostFree(s->multi_rec);
    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -1353,6 +1357,12 @@ static int run_segments(seeqdev_scan *s)
       s->nev_seg = nseg;
    }
    if (s->prof) s->prof_segs = nseg;
+   if (s->prof && nseg > s->cap_clk_probe) {
+      if (s->clk_probe) (void)hipHostFree(s->clk_probe);
+      s->clk_probe = nullptr; s->cap_clk_probe = 0;
+      if (hipHostMalloc((void **)&s->clk_probe, nseg * 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) s->cap_clk_probe = nseg;
+   }
+   if (s->prof && s->clk_probe) memset(s->clk_probe, 0, nseg * 4 * sizeof(unsigned long long));
    /* (Tried: the post-pass of segment k on a second stream under k_pair of segment k + 1, k_pair on one workgroup per CU --
       it is as fast there.  The post-pass kernels do run beside it, and take 3 to 14 times as long as alone: they are
       made of scattered loads and the memory system is what k_pair saturates.  Net: +2 % .. -3 % per step.  Not kept;
@@ -1398,6 +1408,7 @@ static int run_segments(seeqdev_scan *s)
          f.tile_dirty = f.wg_lastnl ? ow.tile_dirty : nullptr;
          f.tile_dmask = f.wg_lastnl ? ow.tile_dmask : nullptr;
          f.cnt = c;
+         f.clk_probe = (s->prof && s->clk_probe && use_pair) ? s->clk_probe + 4 * sg : nullptr;
          uint32_t pos_bias = 0;
          if (use_stream) {
             f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
@@ -2000,6 +2011,15 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
             s->acc_ms[0] += t01; s->acc_ms[1] += t12; s->acc_ms[2] += t23; s->acc_ms[3] += t01 + t12 + t23;
             if (sg < s->cap_launch_ms) s->launch_ms[sg] = t12;
          }
+         s->clk_mhz = 0.f;
+         if (s->prof_segs && s->clk_probe && s->cap_clk_probe >= s->prof_segs) {
+            double sum = 0; size_t nn = 0;
+            for (size_t sg = 0; sg < s->prof_segs; sg++) {
+               const unsigned long long *q = s->clk_probe + 4 * sg;
+               if (q[3] > q[1] && q[2] > q[0]) { sum += (double)(q[2] - q[0]) / (double)(q[3] - q[1]) * 100.0; nn++; }      /* s_memrealtime: 100 MHz */
+            }
+            if (nn) s->clk_mhz = (float)(sum / (double)nn);
+         }
          if (s->prof_segs) s->fwd_ms_avg = s->acc_ms[1] / (float)s->prof_segs;
          s->h2d_ms = 0.f;
          if (s->prof && s->have_h2d_ev) (void)hipEventElapsedTime(&s->h2d_ms, s->ev_h2d[0], s->ev_h2d[1]);
@@ -2412,6 +2432,8 @@ extern "C" int seeqdevScanLastCopyMs(const seeqdev_scan_t *s, float *h2d_ms)
 }
 
 extern "C" int seeqdevScanLastLaunches(const seeqdev_scan_t *s) { return s ? (int)s->prof_segs : 0; }
+
+extern "C" float seeqdevScanLastClockMHz(const seeqdev_scan_t *s) { return s ? s->clk_mhz : 0.f; }
 
 extern "C" int seeqdevScanLastLaunchTimes(const seeqdev_scan_t *s, float *ms, int cap)
 {

@@ -147,6 +147,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
    __syncthreads();                                       /* the only barrier: the table is read-only from here */
 
    const uint32_t gwave = blockIdx.x * NW + wave, nwaves = gridDim.x * NW;
+   /* round 4: the launch comes in two speeds box by box -- what clock does it run at?  Wave 0 of the grid reads the shader clock
+      and the constant 100 MHz counter before and after its tiles (it works from the first tile to one of the last) */
+   if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) { a.clk_probe[0] = __builtin_readcyclecounter(); a.clk_probe[1] = wall_clock64(); }
    uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0;    /* wave-uniform */
    bool wv_overflow = false;
    uint32_t wv_dirty = 0;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       a.wg_part[4 * gwave + 1] = wv_hdrs;
       a.wg_part[4 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
       a.wg_part[4 * gwave + 3] = wv_dirty;       /* 1: a byte outside the alphabet, 2: long-line input (k_fused_post acts on them) */
-   }
+   }   if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) { a.clk_probe[2] = __builtin_readcyclecounter(); a.clk_probe[3] = wall_clock64(); }
 }
 
 #undef PAIR_X2

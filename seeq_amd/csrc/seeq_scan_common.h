@@ -53,6 +53,8 @@ struct FusedArgs {
    const uint16_t *dfa;        /* k_stream: transition table, dfa_rows x 8 u16 (seeq_dfa.h) */
    uint32_t       dfa_rows;
    uint32_t       dfa_final_base;   /* k_stream: state value of ACC_NEW; k_pair: state values >= this are flagged rows */
+   unsigned long long *clk_probe;   /* NULL, or 4 words the scan kernel's first wave fills: shader clock (s_memtime) and the constant 100 MHz counter
+                                       (s_memrealtime) at its start and at its end -- their ratio is the core clock the kernel actually ran at */
    uint32_t       ll_filter;        /* k_stream's long-line variant walks a partition filter: a chain that starts blind (accepting state) reports its first byte */
    uint32_t       skip_thr;         /* k_stream under SQ_IGNORE: m - tau when the automaton is the complete one -- a chain whose line holds fewer characters that
                                        are not skipped makes up no candidate (0: every chain with a skipped byte in its warm-up window does) */

@@ -131,6 +131,10 @@ class Scanner:
         return dict(index=ms[0], forward=ms[1], exact=ms[2], total=ms[3],
                     forward_launches=self._lib.seeqdevScanLastLaunches(self._h))
 
+    def last_clock_mhz(self):
+        """Core clock the last run's scan launches ran at (k_pair's own clock readings; profiling on), 0 when not measured."""
+        return float(self._lib.seeqdevScanLastClockMHz(self._h))
+
     def last_launch_times_ms(self):
         """Duration of every forward-scan launch of the last fetched scan (profiling on), in launch order."""
         n = self._lib.seeqdevScanLastLaunches(self._h)
