@@ -971,7 +971,8 @@ def main():
                          # the scan kernel's own reading of the clock it ran at: shader clock / constant 100 MHz counter around its first wave's work
                          "scan_kernel_core_clock_mhz": stats3(step_clk),
                          "gpu_clock_power_during_steps": clocks.summary() if clocks else None},
-            "roofline": {"bound": "hbm", "kernel": kern + (" (partition filter automaton)" if filt else ""),
+            "roofline": {"bound": "hbm", "kernel": kern + (" (pair automaton: a prefix of the pattern or a partition filter; candidates, verified by the exact pass)" if kern == "k_pair"
+                                          else " (partition filter automaton)" if filt else ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": launches_per_step, "avg_launch_ms": fwd_avg_ms,
