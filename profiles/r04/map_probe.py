@@ -1,5 +1,8 @@
 """k_pair's tile -> wave map (SEEQ_PAIR_MAP = 0 interleaved over the grid / 1 a contiguous range per wave / 2 per workgroup) over three buffers
-of one process: per-launch durations and the records' checksum."""
+of one process: per-launch durations and the records' checksum.
+
+(SEEQ_PAIR_MAP existed in an experiment build of round 4 only -- three lines in k_pair's tile loop: `tile = gwave * per + i` / `blockIdx.x * per + i * NW + wave`
+instead of `gwave + i * nwaves` -- and was taken out again with this result, map_probe.txt; on HEAD the script measures map 0 four times.)"""
 import os, sys, zlib
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
