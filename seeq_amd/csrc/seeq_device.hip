@@ -920,6 +920,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_SKIPCOUNT"); kn.no_skipcount = v && atoi(v) == 1;
       v = getenv("SEEQ_NO_LL_FILTER"); kn.no_ll_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_EXPLAIN");      kn.explain = v && atoi(v) == 1;
+      v = getenv("SEEQ_PACKED_STAGE"); kn.packed_stage = v && atoi(v) == 1;
       s->ncu = 256;
       s->lds_per_wg = 65536;
       int dev = 0;
@@ -1664,6 +1665,9 @@ static int run_packed(seeqdev_scan *s)
    const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
    unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 16 ? hit_blocks : (size_t)s->ncu * 16);
    if (grid_hits == 0) grid_hits = 1;
+   /* the exact pass reads the candidates' windows from the batch itself (seeq_verify_packed.h) -- no staging text -- unless SQ_ALL records are
+      wanted (k_exact1<EMIT> recovers their starts from text) or the round-3 exact pass is asked for */
+   const bool direct = !s->knobs.old_verify && !s->knobs.packed_stage && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const size_t nseg = (size_t)((b.nreads + PACKED_SEG_READS - 1) / PACKED_SEG_READS);
    s->prof_segs = 0;
    if (s->prof && nseg > s->nev_seg) {
@@ -1684,7 +1688,7 @@ static int run_packed(seeqdev_scan *s)
       p.read_len = L; p.stride = b.stride; p.nstride = b.nstride;
       p.total_bytes = b.nreads * (uint64_t)b.stride;
       p.dfa = pat->d_pair; p.dfa_units = pat->pair_units;
-      p.cand = s->pk_cand; p.cslot = s->pk_slot; p.boff = s->pk_coff; p.bmask = s->pk_bmask; p.stage = s->pk_stage;
+      p.cand = s->pk_cand; p.cslot = s->pk_slot; p.boff = s->pk_coff; p.bmask = s->pk_bmask; p.stage = direct ? nullptr : s->pk_stage;
       p.wave_cap = (uint32_t)(s->cap_hitlines / ((size_t)wgrid * STREAM_NW_HOST));
       p.pitch = pitch;
       p.hit_start = s->hit_start; p.hit_line = s->hit_line; p.hit_col = s->hit_col; p.hit_last = s->pk_last; p.nh = s->nh;
@@ -1728,7 +1732,9 @@ static int run_packed(seeqdev_scan *s)
          a.nh_sum = s->nh_sum;
          a.nz_sum = nh_is_count ? s->nh_sum + (s->cap_hitlines / 256 + 2) : nullptr;
          a.fin = (want == SEEQDEV_WANT_RECORDS && var == VERIFY_ALL) ? 0u : 1u + (uint32_t)seg_flags;
-         seeq_launch_verify(fw, var, grid_hits, st, a, eqp, hcol, ecache);
+         if (direct) seeq_launch_verify_packed(fw, var, grid_hits, st, a, b.bases, b.nmask, b.stride, b.nstride, L, p.total_bytes,
+                                               b.nmask ? b.nreads * (uint64_t)b.nstride : 0ull, eqp, hcol, ecache);
+         else seeq_launch_verify(fw, var, grid_hits, st, a, eqp, hcol, ecache);
          if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
          else if (want == SEEQDEV_WANT_RECORDS) {
             if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);

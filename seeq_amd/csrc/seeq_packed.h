@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
          objects scattered over the batch (0.145 ms per 16 Mi reads) -- into lines of the staging text this WAVE owns (no
          atomics: a counter per wave, as the hit slices of k_pair); k_packed_list points the hit list at them. */
       const uint32_t nc = (uint32_t)__popcll(mask);
-      if (nc) {
+      if (nc && a.stage) {                                /* (no staging text: k_verify_packed reads the candidates' windows from the batch itself) */
          const uint32_t s0 = wslots;
          wslots += nc;
          if (wslots <= a.wave_cap) {

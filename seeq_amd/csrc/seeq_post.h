@@ -18,6 +18,10 @@
    a.fin != 0: k_nh_top ends the segment */
 void seeq_launch_verify(int fw, int var, unsigned grid, hipStream_t st, const ScanArgs &a, const uint32_t *eq, const uint32_t *hit_col,
                         uint4 *cache);
+/* k_verify_packed<W, VAR> (seeq_verify_packed.h) + k_nh_top: the same over the windows of a packed read batch, read from the batch itself */
+struct VerifyPacked;
+void seeq_launch_verify_packed(int fw, int var, unsigned grid, hipStream_t st, const ScanArgs &a, const void *bases, const void *nmask, uint32_t stride,
+                               uint32_t nstride, uint32_t read_len, uint64_t total_bytes, uint64_t ntotal_bytes, const uint32_t *eq, const uint32_t *hit_col, uint4 *cache);
 /* k_emit1: the records of a segment with one record per line at most, from k_verify's cache */
 void seeq_launch_emit1(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *cache);
 

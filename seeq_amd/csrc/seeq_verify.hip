@@ -13,6 +13,7 @@
 #include "seeq_direct.h"
 #include "seeq_exact1.h"
 #include "seeq_verify.h"
+#include "seeq_verify_packed.h"
 #include "seeq_order.h"
 #include "seeq_post.h"
 
@@ -50,4 +51,20 @@ void seeq_launch_order(unsigned grid, hipStream_t st, const FusedArgs &f, uint32
 void seeq_launch_bounds2(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *ent, uint32_t *hit_col)
 {
    hipLaunchKernelGGL(k_bounds2, dim3(grid), dim3(256), 0, st, a, ent, hit_col);
+}
+
+void seeq_launch_verify_packed(int fw, int var, unsigned grid, hipStream_t st, const ScanArgs &a, const void *bases, const void *nmask, uint32_t stride,
+                               uint32_t nstride, uint32_t read_len, uint64_t total_bytes, uint64_t ntotal_bytes, const uint32_t *eq, const uint32_t *hit_col, uint4 *cache)
+{
+   VerifyPacked pk;
+   pk.bases = (const uint8_t *)bases; pk.nmask = (const uint8_t *)nmask; pk.stride = stride; pk.nstride = nstride; pk.read_len = read_len;
+   pk.total_bytes = total_bytes; pk.ntotal_bytes = ntotal_bytes;
+#define SEEQ_VERIFYP(WW, VV) hipLaunchKernelGGL((k_verify_packed<WW, VV>), dim3(grid), dim3(256), 0, st, a, pk, eq, hit_col, cache)
+   if (fw == 1) {
+      if (var == VERIFY_BEST) SEEQ_VERIFYP(1, VERIFY_BEST); else if (var == VERIFY_ALL) SEEQ_VERIFYP(1, VERIFY_ALL); else SEEQ_VERIFYP(1, VERIFY_ANY);
+   } else {
+      if (var == VERIFY_BEST) SEEQ_VERIFYP(2, VERIFY_BEST); else if (var == VERIFY_ALL) SEEQ_VERIFYP(2, VERIFY_ALL); else SEEQ_VERIFYP(2, VERIFY_ANY);
+   }
+#undef SEEQ_VERIFYP
+   hipLaunchKernelGGL(k_nh_top, dim3(1), dim3(256), 0, st, a);
 }

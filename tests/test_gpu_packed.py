@@ -61,6 +61,16 @@ def test_packed_vs_oracle(gpu, capi, oracle):
             assert got["kernel"] == "k_packed"
             assert got["nlines"] == exp["nlines"] == len(lines) and got["nmatchlines"] == exp["nmatchlines"], (pattern, tau, L, mo)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, L, mo)
+        # the same through the staging text (SEEQ_PACKED_STAGE=1: candidates unpacked for the exact pass, as before k_verify_packed)
+        import os
+        os.environ["SEEQ_PACKED_STAGE"] = "1"
+        try:
+            for mo in (SQ_FIRST, SQ_BEST):
+                exp = oracle.buffer_scan(pattern, tau, text, mo)
+                got = _packed_scan(dev, torch, pat, text, L, mo, dev.WANT_RECORDS)
+                assert got["kernel"] == "k_packed" and np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, L, mo, "staged")
+        finally:
+            os.environ.pop("SEEQ_PACKED_STAGE", None)
         expa = oracle.buffer_scan(pattern, tau, text, SQ_ALL)
         c1 = _packed_scan(dev, torch, pat, text, L, 0, dev.WANT_COUNTLINES)
         c2 = _packed_scan(dev, torch, pat, text, L, 0, dev.WANT_COUNTMATCH)
