@@ -916,6 +916,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_WINDOW");    kn.no_window = v && atoi(v) == 1;
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
       v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
+      v = getenv("SEEQ_EMIT_ALL");     kn.old_emit_all = v && !strcmp(v, "old");
       v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
       v = getenv("SEEQ_NO_SKIPCOUNT"); kn.no_skipcount = v && atoi(v) == 1;
       v = getenv("SEEQ_NO_LL_FILTER"); kn.no_ll_filter = v && atoi(v) == 1;
@@ -1535,7 +1536,9 @@ static int run_segments(seeqdev_scan *s)
             a.fin = (want == SEEQDEV_WANT_RECORDS && var == VERIFY_ALL) ? 0u : 1u + (uint32_t)seg_flags;
             seeq_launch_verify(fw, var, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
             if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
-            emitted = want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL;
+            else if (want == SEEQDEV_WANT_RECORDS && ecache && !s->knobs.old_emit_all)      /* SQ_ALL: the first records from the cache, the others from the overflow lists */
+               seeq_launch_emit_all(fw, grid_hits, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
+            emitted = want == SEEQDEV_WANT_RECORDS && (var != VERIFY_ALL || (ecache && !s->knobs.old_emit_all));
          }
          else if (need_nh) {
             if (use_fused && !generic_exact) {
@@ -1737,7 +1740,8 @@ static int run_packed(seeqdev_scan *s)
          else seeq_launch_verify(fw, var, grid_hits, st, a, eqp, hcol, ecache);
          if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
          else if (want == SEEQDEV_WANT_RECORDS) {
-            if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+            if (!s->knobs.old_emit_all) seeq_launch_emit_all(fw, grid_hits, grid_hits, st, a, eqp, hcol, ecache);
+            else if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
             else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
             hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, seg_flags);
          }

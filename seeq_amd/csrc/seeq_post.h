@@ -24,6 +24,9 @@ void seeq_launch_verify_packed(int fw, int var, unsigned grid, hipStream_t st, c
                                uint32_t nstride, uint32_t read_len, uint64_t total_bytes, uint64_t ntotal_bytes, const uint32_t *eq, const uint32_t *hit_col, uint4 *cache);
 /* k_emit1: the records of a segment with one record per line at most, from k_verify's cache */
 void seeq_launch_emit1(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *cache);
+/* k_emit_all: SQ_ALL records behind k_verify<VERIFY_ALL> -- first records from the cache, the others from the overflow lists of the
+   `vgrid` workgroups k_verify ran with; when a list did not fit: k_exact1's EMIT pass over the same arguments */
+void seeq_launch_emit_all(int fw, unsigned grid, unsigned vgrid, hipStream_t st, const ScanArgs &a, const uint32_t *eq, const uint32_t *hit_col, uint4 *cache);
 
 /* seeq_order.h: per-wave hit slices -> ordered per-line arrays on read-length lines (three launches).  bsum: 2 * nb words of
    workspace, nb = blocks of 2 048 tiles (<= SEEQ_ORDER_MAX_BLOCKS); ent: one uint4 per hit-list entry */

@@ -310,9 +310,10 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
       }
       uint32_t nhits = r.nhits, ce0 = r.ce0, ce1 = r.ce1;
       if (VAR == VERIFY_BEST) { nhits = r.best_d < tau1 ? 1u : 0u; ce0 = r.best_end; ce1 = r.best_d; }
-      /* one record per line: its start is recovered here, EMIT only copies */
+      /* the start of the line's (first) record is recovered here: EMIT only copies it (SQ_ALL: k_emit_all recovers the starts of the
+         second and later records of a line from the overflow lists) */
       uint32_t ce2 = 0, ce3 = 0;
-      if (VAR != VERIFY_ALL && caching) {
+      if (caching) {
          const bool need = k < nhl && nhits != 0u;
          if (__any(need)) {
             const uint32_t s0 = verify_reverse<W>(a, need, off, ce0, ce1, eqr_base, sh, m, tau1);
@@ -407,6 +408,68 @@ __global__ __launch_bounds__(256) void k_emit1(ScanArgs a, const uint4 *cache)
       h.dist = ce.y;
       a.records[slot] = h;
       a.rec_off[slot] = rec_off_of(a, a.seg_base + a.hit_start[kk], h.line);       /* byte offset of the record's line (seeqdevScanCopyOffsets) */
+   }
+}
+
+/* SQ_ALL records behind k_verify<VERIFY_ALL>: the first record of every line is whole in the cache (as for k_emit1); the further
+ * emissions of a line sit in the overflow lists k_verify's waves filled ({hit-list entry, index in the line, end, dist}; `vgrid` =
+ * the workgroups k_verify ran with: one list per wave of that grid) -- their starts are recovered here, sixty-four entries of a list
+ * at a time (verify_reverse is wave-wide).  (Until round 4 k_exact1's EMIT pass did both, one lane per LINE with its own reverse
+ * loop: 124 us per segment of configs[4], 87 us of the headline reads' --all.)  A list that did not fit (Counters.seg_novf): that
+ * EMIT pass, which scans the lines with several records again. */
+template <int W>
+__global__ __launch_bounds__(256, 6) void k_emit_all(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache, uint32_t vgrid)
+{
+   const Counters *c = a.cnt;
+   if (c->overflow & 4u) return;
+   if (c->seg_novf) { exact1_body<SQ_MODE_EMIT, W, -1, false>(a, eq2, hit_col, cache); return; }      /* (kernel-uniform) */
+   __shared__ __align__(8) uint32_t s_eqr[256 * W];
+   for (int i = threadIdx.x; i < 256 * W; i += 256) s_eqr[i] = eq2[256 * W + i];
+   __syncthreads();
+   const uint32_t eqr_base = (uint32_t)(uintptr_t)(fused_lds_cu32 *)s_eqr;
+   const uint32_t nhl = c->seg_nhitlines;
+   const uint64_t base = c->records;
+   const uint32_t m = (uint32_t)a.m, tau1 = (uint32_t)a.tau + 1u;
+   uint32_t sh = W == 1 ? 2u : 3u;
+   asm volatile("" : "+v"(sh));
+   for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < nhl; k += gridDim.x * 256u) {
+      const uint4 ce = cache[k];                            /* {end, dist, start, has a record} */
+      if (!ce.w) continue;
+      const uint32_t kk = a.hit_idx ? a.hit_idx[k] : k;
+      const uint64_t slot = base + nh_at(a, k);
+      seeqdev_hit_t h;
+      h.line = a.hit_line[kk];
+      h.start = ce.z;
+      h.end = ce.x;
+      h.dist = ce.y;
+      a.records[slot] = h;
+      a.rec_off[slot] = rec_off_of(a, a.seg_base + a.hit_start[kk], h.line);
+   }
+   const uint32_t nlists = vgrid * 4u;
+   const uint32_t ovf_r = (a.cap_hitlines > nhl ? a.cap_hitlines - nhl : 0u) / nlists;      /* (k_verify's formula) */
+   if (!ovf_r) return;
+   const uint32_t lane = threadIdx.x & 63u;
+   for (uint32_t l = blockIdx.x * 4u + (threadIdx.x >> 6); l < nlists; l += gridDim.x * 4u) {
+      const uint4 *ovf = cache + nhl + (size_t)l * ovf_r;
+      const uint32_t novf = (uint32_t)__builtin_amdgcn_readfirstlane((int)ovf[0].x);
+      for (uint32_t e0 = 1u; e0 <= novf; e0 += 64u) {
+         const bool need = e0 + lane <= novf;
+         const uint4 o = need ? ovf[e0 + lane] : make_uint4(0u, 0u, 0u, 0u);
+         const uint32_t ox = (need && a.hit_idx) ? a.hit_idx[o.x] : o.x;
+         const uint32_t hs = need ? a.hit_start[ox] : 0u;
+         const uint64_t off = a.seg_base + hs;
+         const uint32_t s0 = verify_reverse<W>(a, need, off, o.z, o.w, eqr_base, sh, m, tau1);
+         if (need) {
+            const uint64_t slot = base + nh_at(a, o.x) + o.y;
+            seeqdev_hit_t h;
+            h.line = a.hit_line[ox];
+            h.start = s0;
+            h.end = o.z;
+            h.dist = o.w;
+            a.records[slot] = h;
+            a.rec_off[slot] = rec_off_of(a, off, h.line);
+         }
+      }
    }
 }
 

@@ -36,6 +36,12 @@ void seeq_launch_emit1(unsigned grid, hipStream_t st, const ScanArgs &a, const u
    hipLaunchKernelGGL(k_emit1, dim3(grid), dim3(256), 0, st, a, cache);
 }
 
+void seeq_launch_emit_all(int fw, unsigned grid, unsigned vgrid, hipStream_t st, const ScanArgs &a, const uint32_t *eq, const uint32_t *hit_col, uint4 *cache)
+{
+   if (fw == 1) hipLaunchKernelGGL(k_emit_all<1>, dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache, vgrid);
+   else hipLaunchKernelGGL(k_emit_all<2>, dim3(grid), dim3(256), 0, st, a, eq, hit_col, cache, vgrid);
+}
+
 static_assert(ORDER_MAX_BLOCKS == SEEQ_ORDER_MAX_BLOCKS && ORDER_SCAN_BLOCK == SEEQ_ORDER_BLOCK, "seeq_order.h / seeq_post.h");
 
 void seeq_launch_tiles_post(hipStream_t st, const FusedArgs &f, uint32_t nslices, uint32_t *bsum, uint32_t nb)
