@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_emit1(ScanArgs a, const uint4 *cache)
  * loop: 124 us per segment of configs[4], 87 us of the headline reads' --all.)  A list that did not fit (Counters.seg_novf): that
  * EMIT pass, which scans the lines with several records again. */
 template <int W>
-__global__ __launch_bounds__(256, 6) void k_emit_all(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache, uint32_t vgrid)
+__global__ __launch_bounds__(256, W == 1 ? 6 : 5) void k_emit_all(ScanArgs a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache, uint32_t vgrid)
 {
    const Counters *c = a.cnt;
    if (c->overflow & 4u) return;
