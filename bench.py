@@ -1038,6 +1038,7 @@ def main():
                                       "scan_kernel_ms_per_launch": pfwd / max(1, plaunch), "scan_kernel_launches_per_step": plaunch / psteps,
                                       "scan_kernel_hbm_frac": (pbytes / (plaunch / psteps)) / (pfwd / max(1, plaunch) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "identical_to_ascii_run": same,
+                                      "walk_table": "quad: four bases (one packed byte) per gather, two-part filter" if scp.last_packed_quad() else "pair: two bases per gather",
                                       "note": "2 bits per base + 1 bit per base N mask, one read per lane, no warm-up (seeq_packed.h); scan-only figure on "
                                               "pre-packed data, beside the headline (SURVEY 8d)"}
                 if not args.no_e2e:

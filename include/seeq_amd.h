@@ -109,6 +109,9 @@ int seeqdevScanLastPath(const seeqdev_scan_t * scan);
 /* 1 when the last run's k_stream walked a partition FILTER automaton (candidates verified by the exact pass)
  * instead of the pattern's complete automaton. */
 int seeqdevScanLastFilter(const seeqdev_scan_t * scan);
+/* 1 when the last packed run (path 8) walked the pattern's QUAD table -- four bases, one packed byte, per table step over a small
+ * partition-filter automaton (seeq_dfa.h section 3b) -- instead of the pair table (two bases per step). */
+int seeqdevScanLastPackedQuad(const seeqdev_scan_t * scan);
 
 /* Enqueue (asynchronously, on the context's stream) the whole hot path over
  * d_text[0..nbytes): newline index -> per-line forward scan -> hit-line

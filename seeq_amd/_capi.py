@@ -65,7 +65,7 @@ EXPORTS = [
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevScanLastLaunchTimes", "seeqdevScanLastClockMHz", "seeqdevSynthReads",
-    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
+    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanLastPackedQuad", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
     "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanLastMulti", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
 ]
@@ -179,6 +179,8 @@ def lib():
     L.seeqdevScanLastPath.restype = C.c_int
     L.seeqdevScanLastFilter.argtypes = [C.c_void_p]
     L.seeqdevScanLastFilter.restype = C.c_int
+    L.seeqdevScanLastPackedQuad.argtypes = [C.c_void_p]
+    L.seeqdevScanLastPackedQuad.restype = C.c_int
     L.seeqdevScanRunMulti.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     L.seeqdevScanRunMulti.restype = C.c_int
     L.seeqdevScanHostMulti.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]

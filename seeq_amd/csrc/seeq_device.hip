@@ -549,6 +549,12 @@ struct seeqdev_pattern {
    uint32_t  pair_states;
    int       pair_parts, pair_mp, pair_warm;
    double    pair_pacc;      /* probability that a random DNA character completes a candidate */
+   int       quad_state;     /* the quad automaton of the packed walk (seeq_dfa.h section 3b): 0 not tried, 1 built, -1 none fits */
+   uint16_t *d_quad;         /* its table in HBM (512-byte rows) */
+   uint32_t  quad_units;     /* 16-byte units of it */
+   uint32_t  quad_states;
+   int       quad_parts, quad_mp;
+   double    quad_pacc;
    pthread_mutex_t plan_lock;   /* the automata are built on first use; scan contexts on several threads may share a pattern */
 };
 
@@ -606,6 +612,7 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
    if (p->d_sdfa) (void)hipFree(p->d_sdfa);
    if (p->d_sdfa_skip) (void)hipFree(p->d_sdfa_skip);
    if (p->d_pair) (void)hipFree(p->d_pair);
+   if (p->d_quad) (void)hipFree(p->d_quad);
    pthread_mutex_destroy(&p->plan_lock);
    free(p->keys);
    free(p->h_peq);
@@ -668,6 +675,31 @@ static void pattern_plan_pair(seeqdev_pattern *mp)
          seeq_pair_free(d);
       }
       __atomic_store_n(&mp->pair_state, state, __ATOMIC_RELEASE);
+   }
+   pthread_mutex_unlock(&mp->plan_lock);
+}
+
+static void pattern_plan_quad(seeqdev_pattern *mp)
+{
+   pthread_mutex_lock(&mp->plan_lock);
+   if (mp->quad_state == 0 && mp->keys) {
+      int state = -1;
+      seeq_quad_t *d = seeq_quad_plan(mp->keys, mp->wlen, mp->tau);
+      if (d) {
+         uint16_t *t0 = nullptr;
+         if (hipMalloc((void **)&t0, d->table_bytes) == hipSuccess && hipMemcpy(t0, d->table, d->table_bytes, hipMemcpyHostToDevice) == hipSuccess) {
+            mp->d_quad = t0;
+            mp->quad_units = d->table_bytes / 16;
+            mp->quad_states = d->nstates;
+            mp->quad_parts = d->nparts; mp->quad_mp = d->mp;
+            mp->quad_pacc = d->p_accept;
+            state = 1;
+         } else if (t0) {
+            (void)hipFree(t0);
+         }
+         seeq_quad_free(d);
+      }
+      __atomic_store_n(&mp->quad_state, state, __ATOMIC_RELEASE);
    }
    pthread_mutex_unlock(&mp->plan_lock);
 }
@@ -769,6 +801,11 @@ static MultiPlan *multi_plan_for(MultiPlan **slot, const seeqdev_pattern_t *cons
 
 struct OccMemo { const void *fn; size_t lds; int per_cu; };
 
+/* Packed runs (seeq_packed.h), reads per segment: 64 Mi (16 Mi until the quad walk: the per-segment launches behind the walk -- the scan of the
+   candidate counts, the list, k_nh_top, k_emit1 -- are latency-bound and cost as much for a quarter of the reads: 100 M reads, 2.28 ms per step
+   in six segments, 2.11 in three, 2.07 in two; 8 bytes of workspace per read of a segment); SEEQ_PACKED_SEG_READS sets another size (tests) */
+static constexpr size_t PACKED_SEG_READS_DEFAULT = (size_t)1 << 26;
+
 struct seeqdev_scan {
    hipStream_t stream;
    bool        own_stream;
@@ -785,6 +822,8 @@ struct seeqdev_scan {
    ScanKnobs   knobs;
    OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
    bool        last_filter;       /* the last run walked a partition filter automaton */
+   bool        last_packed_quad;  /* the last packed run walked the quad table */
+   size_t      pk_seg_reads;      /* reads per segment of a packed run */
    /* workspace (device) */
    uint32_t *line_start;  size_t cap_lines;
    uint32_t *tile_cnt;    size_t cap_tiles;
@@ -922,6 +961,9 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_LL_FILTER"); kn.no_ll_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_EXPLAIN");      kn.explain = v && atoi(v) == 1;
       v = getenv("SEEQ_PACKED_STAGE"); kn.packed_stage = v && atoi(v) == 1;
+      v = getenv("SEEQ_PACKED_QUAD");  kn.no_packed_quad = v && atoi(v) == 0;
+      v = getenv("SEEQ_PACKED_SEG_READS");
+      s->pk_seg_reads = v && atol(v) >= 64 && (size_t)atol(v) <= ((size_t)1 << 26) ? (size_t)atol(v) & ~(size_t)63 : PACKED_SEG_READS_DEFAULT;
       s->ncu = 256;
       s->lds_per_wg = 65536;
       int dev = 0;
@@ -1055,6 +1097,7 @@ extern "C" int seeqdevScanSetLineHint(seeqdev_scan_t *s, double avg_bytes_per_li
 
 extern "C" int seeqdevScanLastPath(const seeqdev_scan_t *s) { return s ? s->last_path : 0; }
 extern "C" int seeqdevScanLastFilter(const seeqdev_scan_t *s) { return s && s->last_filter ? 1 : 0; }
+extern "C" int seeqdevScanLastPackedQuad(const seeqdev_scan_t *s) { return s && s->last_packed_quad ? 1 : 0; }
 
 extern "C" int seeqdevScanSetProfiling(seeqdev_scan_t *s, int on)
 {
@@ -1594,7 +1637,7 @@ static int run_segments(seeqdev_scan *s)
 /* ========================================================================== */
 /* Packed read batches (seeq_packed.h)                                        */
 /* ========================================================================== */
-static constexpr size_t PACKED_SEG_READS = (size_t)1 << 24;      /* reads per segment: 16 Mi */
+/* (reads per segment: seeqdev_scan.pk_seg_reads) */
 
 static int run_packed(seeqdev_scan *s)
 {
@@ -1608,6 +1651,7 @@ static int run_packed(seeqdev_scan *s)
    hipStream_t st = s->stream;
    const uint32_t L = b.read_len;
    /* workspace: per read of a segment, per candidate */
+   const size_t PACKED_SEG_READS = s->pk_seg_reads;
    const size_t seg_reads = b.nreads < PACKED_SEG_READS ? (size_t)b.nreads : PACKED_SEG_READS;
    if (seg_reads > s->cap_pk_reads) {
       if (ws_alloc((void **)&s->pk_cand, seg_reads * sizeof(uint32_t))) return -1;
@@ -1656,8 +1700,13 @@ static int run_packed(seeqdev_scan *s)
       s->eq_options = options;
    }
    HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), st), EIO);
-   const size_t dfa_lds = (size_t)pat->pair_units * 16;
-   int per_cu = occupancy_of(s, (const void *)k_packed_walk, 64 * STREAM_NW, dfa_lds);
+   /* four bases per gather over the quad table (seeq_dfa.h section 3b) when the pattern has one and the false candidates it adds
+      -- each an exact-pass window, ~13 walks' worth -- stay below the gathers it saves: 4 % of the reads */
+   const bool quad = pat->quad_state == 1 && !s->knobs.no_packed_quad && (pat->quad_pacc - pat->pair_pacc) * (double)L <= 0.04;
+   s->last_packed_quad = quad;
+   const size_t dfa_lds = quad ? (size_t)pat->quad_units * 16 : (size_t)pat->pair_units * 16;
+   const void *walk_fn = quad ? (const void *)k_packed_walk<true> : (const void *)k_packed_walk<false>;
+   int per_cu = occupancy_of(s, walk_fn, 64 * STREAM_NW, dfa_lds);
    if (per_cu < 0) return -1;
    /* persistent grid, but no more waves than blocks of 64 reads: every wave owns cap / waves lines of the staging text */
    unsigned wgrid = (unsigned)(s->ncu * per_cu);
@@ -1690,7 +1739,7 @@ static int run_packed(seeqdev_scan *s)
       p.nreads = (uint32_t)(b.nreads - p.first < PACKED_SEG_READS ? b.nreads - p.first : PACKED_SEG_READS);
       p.read_len = L; p.stride = b.stride; p.nstride = b.nstride;
       p.total_bytes = b.nreads * (uint64_t)b.stride;
-      p.dfa = pat->d_pair; p.dfa_units = pat->pair_units;
+      p.dfa = quad ? pat->d_quad : pat->d_pair; p.dfa_units = quad ? pat->quad_units : pat->pair_units;
       p.cand = s->pk_cand; p.cslot = s->pk_slot; p.boff = s->pk_coff; p.bmask = s->pk_bmask; p.stage = direct ? nullptr : s->pk_stage;
       p.wave_cap = (uint32_t)(s->cap_hitlines / ((size_t)wgrid * STREAM_NW_HOST));
       p.pitch = pitch;
@@ -1701,7 +1750,7 @@ static int run_packed(seeqdev_scan *s)
       if (ev) { HIP_TRY(hipEventRecord(ev[0], st), EIO); HIP_TRY(hipEventRecord(ev[1], st), EIO); }
       {
          void *kargs[] = {&p};
-         HIP_TRY(hipLaunchKernel((const void *)k_packed_walk, dim3(wgrid), dim3(64 * STREAM_NW), kargs, dfa_lds, st), EIO);
+         HIP_TRY(hipLaunchKernel(walk_fn, dim3(wgrid), dim3(64 * STREAM_NW), kargs, dfa_lds, st), EIO);
       }
       if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
       /* candidates before every block of 64 reads, their number */
@@ -2090,6 +2139,7 @@ extern "C" int seeqdevScanPacked(seeqdev_scan_t *s, const seeqdev_pattern_t *pat
    if (use_device(s->device)) return -1;
    seeqdev_pattern *mp = const_cast<seeqdev_pattern *>(pat);
    if (pat->wlen <= FUSED_MAX_WLEN2 && __atomic_load_n(&mp->pair_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_pair(mp);
+   if (pat->wlen <= FUSED_MAX_WLEN2 && mp->pair_state == 1 && __atomic_load_n(&mp->quad_state, __ATOMIC_ACQUIRE) == 0) pattern_plan_quad(mp);
    if (pat->wlen > FUSED_MAX_WLEN2 || mp->pair_state != 1) {
       /* not the packed walk's pattern (more than 62 positions, or no pair automaton): the batch is unpacked on the device and the
          ASCII scan runs over it -- the reference takes any pattern (libseeq.c:43-138), so does this entry */
@@ -2113,7 +2163,7 @@ extern "C" int seeqdevScanPacked(seeqdev_scan_t *s, const seeqdev_pattern_t *pat
    s->is_packed = true;
    s->packed = *batch;
    /* optimistic workspace: one read in eight is a candidate (grown by the re-run of seeqdevScanFetch when it is not) */
-   const size_t seg = batch->nreads < PACKED_SEG_READS ? (size_t)batch->nreads : PACKED_SEG_READS;
+   const size_t seg = batch->nreads < s->pk_seg_reads ? (size_t)batch->nreads : s->pk_seg_reads;
    size_t want_hl = s->cap_hitlines, want_rec = s->cap_records;
    if (!s->user_reserved) {
       if (seg / 8 + 1024 > want_hl) want_hl = seg / 8 + 1024;

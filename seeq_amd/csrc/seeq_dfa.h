@@ -511,6 +511,107 @@ static inline seeq_pair_t *seeq_pair_plan(const char *keys, int m, int tau)
    return best;
 }
 
+/* ======================================================================================================================
+ * (3b) The QUAD automaton (k_packed_walk<true>, seeq_packed.h): FOUR bases per table step -- one byte of a packed read.
+ *
+ * The packed walk is held by the LDS gather unit alone (no warm-up, no checks, no newlines: 2.25 VALU per gather), so only
+ * fewer gathers per base move it.  A table indexed by (state, packed byte) has 256 columns of u16 per state, 512 bytes a row:
+ * a small automaton only -- at most 127 rows (64 KB).  The longest prefix that fits in so few states is useless (8 positions
+ * of the headline pattern: a candidate in every read), but a PARTITION FILTER is small by nature: the headline 20-mer at
+ * distance 3 as two 10-mers with one error each has 95 states and completes by chance once in 8 600 positions (one read in
+ * 57 becomes a false candidate; the pair automaton's 17-position prefix: one in 700) -- the exact pass verifies 30 % more
+ * windows and the walk makes half the gathers.
+ *
+ * Same restart automaton as the pair table (accepting = back at the root, any part), composed four bases at a time.  An entry is
+ *    bits 9-15  the row of the state after the four bases (its byte offset: & 0xFE00)
+ *    bits 0-3   bit i: the walk accepted on base i of the four
+ * so one v_alignbit_b32(entry, mask, 4) per step shifts the four position flags into a per-base mask (exact positions: the pair
+ * table knows the pair only), and one v_bfi_b32 puts the next index under the row offset.
+ * ====================================================================================================================== */
+#define SEEQ_QUAD_MAX_ROWS 127
+
+typedef struct {
+   uint32_t  nstates;        /* rows: walk states after minimisation */
+   uint32_t  nstates_raw;
+   uint32_t  table_bytes;    /* nstates * 512 */
+   int       mp, nparts;     /* as seeq_pair_t */
+   double    p_accept;
+   uint16_t *table;          /* [nstates][256]: index = the packed byte (first base in bits 7-6; codes A 0, C 1, T 2, G 3) */
+} seeq_quad_t;
+
+static inline void seeq_quad_free(seeq_quad_t *d) { if (d) { free(d->table); free(d); } }
+
+/* The quad table of a restart automaton given as seeq_dfa_bfs_parts() output (consumed), or NULL when it has more than
+ * SEEQ_QUAD_MAX_ROWS states after minimisation. */
+static inline seeq_quad_t *seeq_quad_from_next(uint32_t *next, uint32_t n, int rounds)
+{
+   seeq_quad_t *d = NULL;
+   uint32_t *cls = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+   uint32_t *rep = NULL;
+   if (cls) {
+      const uint32_t k = seeq_dfa_minimise_restart(next, n, cls);
+      if (k <= SEEQ_QUAD_MAX_ROWS) {
+         d = (seeq_quad_t *)calloc(1, sizeof *d);
+         rep = (uint32_t *)malloc((size_t)k * sizeof(uint32_t));
+         if (d) { d->table_bytes = k * 512u; d->table = (uint16_t *)calloc(d->table_bytes, 1); }
+         if (!d || !rep || !d->table) { if (d) free(d->table); free(d); d = NULL; }
+      }
+      if (d) {
+         d->nstates = k; d->nstates_raw = n - 1;
+         d->p_accept = seeq_dfa_accept_rate(next, n, rounds);
+         for (uint32_t s = n; s-- > 0;) if (s != 1) rep[cls[s]] = s;
+         for (uint32_t r = 0; r < k; r++)
+            for (uint32_t b = 0; b < 256; b++) {
+               uint32_t q = r, flags = 0;
+               for (int i = 0; i < 4; i++) {
+                  const int c = (int)((b >> (6 - 2 * i)) & 3u);
+                  const uint32_t t = next[(size_t)rep[q] * 5 + seeq_pair_class_of_code[c]];
+                  if (t == 1) { flags |= 1u << i; q = 0; }     /* accepted: back at the root */
+                  else q = cls[t];
+               }
+               d->table[(size_t)r * 256 + b] = (uint16_t)((q << 9) | flags);
+            }
+      }
+   }
+   free(rep); free(cls); free(next);
+   return d;
+}
+
+/* What the quad walk should carry for this pattern: among the prefixes (>= tau + 2 positions) and the partition filters of
+ * 2 .. tau + 1 parts whose automata fit, the one that makes the fewest false candidates; NULL: none fits. */
+static inline seeq_quad_t *seeq_quad_plan(const char *keys, int m, int tau)
+{
+   seeq_quad_t *best = NULL;
+   if (m > 62) return NULL;
+   for (int mp = tau + 2; mp <= m; mp++) {
+      uint32_t *next = NULL;
+      const uint32_t n = seeq_dfa_bfs(keys, mp, tau, &next);
+      if (!n) break;
+      seeq_quad_t *d = seeq_quad_from_next(next, n, 4 * mp + 64);
+      if (!d) break;                                        /* (sizes grow with the prefix) */
+      d->mp = mp; d->nparts = 1;
+      seeq_quad_free(best);
+      best = d;
+   }
+   for (int k = 2; k <= SEEQ_DFA_MAX_PARTS && k <= tau + 1 && k <= m; k++) {
+      int cut[SEEQ_DFA_MAX_PARTS + 1];
+      for (int p = 0; p <= k; p++) cut[p] = (int)((long)p * m / k);
+      const int t = tau / k;
+      int shortest = m;
+      for (int p = 0; p < k; p++) if (cut[p + 1] - cut[p] < shortest) shortest = cut[p + 1] - cut[p];
+      if (shortest < t + 2) continue;
+      uint32_t *next = NULL;
+      const uint32_t n = seeq_dfa_bfs_parts(keys, cut, k, t, &next);
+      if (!n) continue;
+      seeq_quad_t *d = seeq_quad_from_next(next, n, 4 * m + 64);
+      if (!d) continue;
+      d->mp = m; d->nparts = k;
+      if (!best || d->p_accept < best->p_accept) { seeq_quad_free(best); best = d; }
+      else seeq_quad_free(d);
+   }
+   return best;
+}
+
 /* ==========================================================================================================================
  * (4) SEVERAL PATTERNS, ONE WALK (barcode sets; reference doc/response.tex:358-360 names the multi-pattern search as the
  *     place where parallel work exists).  Two automata over the same prefixes lp[p] <= m[p] of the patterns:

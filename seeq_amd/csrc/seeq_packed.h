@@ -16,6 +16,12 @@
  *                   pointing at those lines: from here on k_exact1 COUNT / EMIT run as behind k_pair -- windows, every
  *                   match option, bit-exact.
  *
+ *   k_packed_walk<true>   (round 4) the same walk over the QUAD table (seeq_dfa.h section 3b) where the pattern has one: a packed
+ *                   BYTE -- four bases -- per gather, half the gathers; per byte one SDWA shift (byte -> index << 1), one v_bfi
+ *                   (index under the state's row offset), the gather, one v_alignbit by 4 (the entry's four position flags into a
+ *                   per-base mask).  The small automaton behind it is a partition filter: more false candidates (one read in 57
+ *                   instead of one in 700 for the headline pattern), verified like the others.
+ *
  * Results are those of the ASCII scan of the same reads, one per line (tests/test_gpu_packed.py against the oracle).
  */
 #ifndef SEEQ_PACKED_H_
@@ -55,6 +61,19 @@ __device__ __forceinline__ void packed_word(uint32_t w, uint32_t &st, uint32_t &
    uint32_t ad;
    PACKED_STEP(thi, 0) PACKED_STEP(tlo, 0) PACKED_STEP(thi, 1) PACKED_STEP(tlo, 1)
    PACKED_STEP(thi, 2) PACKED_STEP(tlo, 2) PACKED_STEP(thi, 3) PACKED_STEP(tlo, 3)
+}
+
+/* the quad table: four gathers per word; entry = row offset (bits 9-15) | the four bases' accept flags (bits 0-3) */
+#define PACKED_STEP4(K) \
+   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K : "=v"(of) : "v"(one), "v"(w)); \
+   ad = (of & 0x1FFu) | (st & ~0x1FFu); \
+   st = *(stream_lds_cu16 *)(uintptr_t)ad; \
+   hm = __builtin_amdgcn_alignbit(st, hm, 4);
+
+__device__ __forceinline__ void packed_word4(uint32_t w, uint32_t one, uint32_t &st, uint32_t &hm)
+{
+   uint32_t of, ad;
+   PACKED_STEP4(0) PACKED_STEP4(1) PACKED_STEP4(2) PACKED_STEP4(3)
 }
 
 typedef uint32_t packed_u32_unaligned __attribute__((aligned(1)));
@@ -114,6 +133,7 @@ __device__ __forceinline__ void packed_stage_store(const PackedArgs &a, const pa
    if (L == 256u && i == 15u) out[256] = '\n';            /* (the one length whose newline has no lane of its own) */
 }
 
+template <bool QUAD>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
 {
    extern __shared__ __align__(16) uint8_t dsmem[];
@@ -136,6 +156,29 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
       const bool live = r < a.nreads;
       const uint64_t roff = (a.first + (live ? r : 0)) * (uint64_t)a.stride;
       uint32_t st = 0, first = 0xFFFFFFFFu, last = 0;
+      if (QUAD) {
+         /* 16 bytes at a time: four words, sixteen table steps, two masks of 32 bases (first base of a mask in bit 0 until reversed) */
+         uint32_t one = 1u;
+         asm volatile("" : "+v"(one));                     /* (SDWA takes the shift from a register) */
+#pragma unroll 1
+         for (uint32_t j = 0; j < nwords; j += 4) {
+            const fused_v4u v = dfa_load16(a.bases, roff + 4 * j, a.total_bytes);
+            uint32_t hm0 = 0, hm1 = 0;
+            packed_word4(v.x, one, st, hm0); packed_word4(v.y, one, st, hm0);
+            if (j + 2 < nwords) { packed_word4(v.z, one, st, hm1); packed_word4(v.w, one, st, hm1); }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+               uint32_t hm = __builtin_bitreverse32(h ? hm1 : hm0);          /* first base of the 32 in bit 31 */
+               const uint32_t lo = j * 16u + 32u * (uint32_t)h;               /* base index of bit 31 */
+               hm &= a.read_len <= lo ? 0u : (a.read_len - lo >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (a.read_len - lo)));
+               if (hm) {
+                  const uint32_t f = lo + (uint32_t)__builtin_clz(hm), l = lo + 31u - (uint32_t)__builtin_ctz(hm);
+                  first = first == 0xFFFFFFFFu ? f : first;
+                  last = l;
+               }
+            }
+         }
+      } else {
       /* 16 bytes at a time: four words, 32 pairs, one mask (bytes beyond the read belong to the next read or to the
          padding: their steps are walked and their flags dropped) */
 #pragma unroll 1
@@ -155,12 +198,14 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_packed_walk(PackedArgs a)
             last = l;
          }
       }
+      }
       const bool is_cand = live && first != 0xFFFFFFFFu;
       const uint64_t mask = __ballot(is_cand);
       if (lane == 0) { a.bmask[blk] = mask; a.boff[blk] = (uint32_t)__popcll(mask); }
       if (is_cand) {
-         /* candidate columns: the second base of the flagged pairs (the read's last base when it has no second) */
-         uint32_t fc = 2u * first + 1u, lc = 2u * last + 1u;
+         /* candidate columns: the second base of the flagged pairs (the read's last base when it has no second); the quad table
+            names the base itself */
+         uint32_t fc = QUAD ? first : 2u * first + 1u, lc = QUAD ? last : 2u * last + 1u;
          fc = fc < a.read_len ? fc : a.read_len - 1u;
          lc = lc < a.read_len ? lc : a.read_len - 1u;
          a.cand[r] = (fc << 16) | lc;
@@ -312,5 +357,6 @@ __global__ __launch_bounds__(256) void k_unpack_ascii(const uint8_t *bases, cons
 }
 
 #undef PACKED_STEP
+#undef PACKED_STEP4
 
 #endif

@@ -125,6 +125,10 @@ class Scanner:
         """True when the last k_stream run walked a partition filter automaton (candidates verified by the exact pass)."""
         return bool(self._lib.seeqdevScanLastFilter(self._h))
 
+    def last_packed_quad(self):
+        """True when the last packed run walked the quad table (four bases per table step)."""
+        return bool(self._lib.seeqdevScanLastPackedQuad(self._h))
+
     def last_times_ms(self):
         ms = (C.c_float * 4)()
         _check(self._lib.seeqdevScanLastTimes(self._h, ms))

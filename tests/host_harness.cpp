@@ -220,6 +220,36 @@ extern "C" long harness_pair_walk(const uint8_t *text, size_t n, const char *key
    return (long)ne;
 }
 
+// ---- the quad automaton of the packed walk (seeq_dfa.h section 3b, seeq_packed.h) ----
+// Emulates k_packed_walk<true> on the host: every line of the text is a read, walked from the root from its first base, four bases
+// per table step (2-bit codes = bits 1-2 of the byte, packed first base high as seeqdev_packed_t stores them; the last step of a
+// line is padded with code 0 and the flags of the padding are dropped).  Reports the absolute position of every base the walk
+// accepted on.  info[0..4] = states, states before minimisation, positions carried, parts, accept rate * 1e9.
+// Returns the number of events, -1 when no quad automaton fits.
+extern "C" long harness_quad_walk(const uint8_t *text, size_t n, const char *keys, int m, int tau, uint64_t *out, size_t cap, uint32_t *info)
+{
+   seeq_quad_t *d = seeq_quad_plan(keys, m, tau);
+   if (!d) return -1;
+   if (info) { info[0] = d->nstates; info[1] = d->nstates_raw; info[2] = (uint32_t)d->mp; info[3] = (uint32_t)d->nparts; info[4] = (uint32_t)(d->p_accept * 1e9); }
+   size_t ne = 0, p = 0;
+   while (p < n) {
+      size_t e = p;
+      while (e < n && text[e] != '\n') e++;
+      uint32_t state = 0;
+      for (size_t q = p; q < e; q += 4) {
+         uint32_t b = 0;
+         for (int i = 0; i < 4; i++) b |= (q + i < e ? (uint32_t)(text[q + i] >> 1) & 3u : 0u) << (6 - 2 * i);
+         const uint16_t ent = d->table[(size_t)(state >> 9) * 256 + b];
+         for (int i = 0; i < 4; i++)
+            if ((ent >> i) & 1u && q + i < e) { if (ne < cap) out[ne] = (uint64_t)(q + i); ne++; }
+         state = ent & 0xFE00u;
+      }
+      p = e + 1;
+   }
+   seeq_quad_free(d);
+   return (long)ne;
+}
+
 // ---- several patterns, one walk (seeq_dfa.h section 4) ----
 // keys: the patterns' key bytes concatenated (m[p] each).  harness_multi_walk: the union pair automaton walked as
 // harness_pair_walk walks a single one (chains of `chain` bytes, warm-up, restart, made-up candidates) -> candidate positions.

@@ -25,6 +25,7 @@ def _packed_scan(dev, torch, pat, text, read_len, opt, want, with_n=True):
     if want == dev.WANT_RECORDS:
         res["records"] = sc.records(cnt["nrecords"])
     res["kernel"] = sc.last_kernel()
+    res["quad"] = sc.last_packed_quad()
     sc.close()
     return res
 
@@ -38,6 +39,7 @@ def test_packed_vs_oracle(gpu, capi, oracle):
     cases = [("GATGTAGCGCGATTAGCCTG", 3, 150), ("GATGTAGCGCGATTAGCCTG", 3, 149), ("GATTAGC", 1, 37), ("CACAGAT", 3, 50), ("ACGT", 1, 7),
              ("AC", 0, 1), ("ACNNGT[AC]TTG", 2, 100), ("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5, 250), ("GATGTAGCGCGATTAGCCTGAAAA", 3, 256),
              ("AAAAAAAAAAAAAAAAAAAA", 3, 151), ("GATGTAGCGCGATTAG", 4, 63)]
+    nquad = 0
     for pattern, tau, L in cases:
         core = plain(pattern).replace("N", "A")
         lines = []
@@ -55,14 +57,25 @@ def test_packed_vs_oracle(gpu, capi, oracle):
             lines.append(t)
         text = ("\n".join(lines) + ("\n" if rng.random() < 0.5 else "")).encode()
         pat = dev.Pattern(pattern, tau)
+        import os
         for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
             exp = oracle.buffer_scan(pattern, tau, text, mo)
             got = _packed_scan(dev, torch, pat, text, L, mo, dev.WANT_RECORDS)
             assert got["kernel"] == "k_packed"
             assert got["nlines"] == exp["nlines"] == len(lines) and got["nmatchlines"] == exp["nmatchlines"], (pattern, tau, L, mo)
             assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, L, mo)
+            if got["quad"]:
+                # four bases per table step (the quad table of a small partition filter): the same through the pair table
+                nquad += mo == SQ_BEST
+                os.environ["SEEQ_PACKED_QUAD"] = "0"
+                try:
+                    g2 = _packed_scan(dev, torch, pat, text, L, mo, dev.WANT_RECORDS)
+                finally:
+                    os.environ.pop("SEEQ_PACKED_QUAD", None)
+                assert not g2["quad"] and np.array_equal(g2["records"].astype(np.uint64), exp["records"]), (pattern, tau, L, mo, "pair table")
+        if (pattern, tau) == ("GATGTAGCGCGATTAGCCTG", 3):
+            assert got["quad"], "the headline pattern has a 95-state two-part filter: the quad table serves it"
         # the same through the staging text (SEEQ_PACKED_STAGE=1: candidates unpacked for the exact pass, as before k_verify_packed)
-        import os
         os.environ["SEEQ_PACKED_STAGE"] = "1"
         try:
             for mo in (SQ_FIRST, SQ_BEST):
@@ -77,6 +90,7 @@ def test_packed_vs_oracle(gpu, capi, oracle):
         assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], (pattern, tau, L)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (pattern, tau, L)
         pat.close()
+    assert nquad >= 3, nquad
 
 
 def test_packed_every_read_a_candidate_and_no_nmask(gpu, capi, oracle):
@@ -153,11 +167,14 @@ def test_pack_on_device_equals_host_packer_and_padded_strides(gpu, capi, oracle)
 
 
 def test_packed_two_segments_equal_the_ascii_scan(gpu, capi):
-    """More reads than one packed segment holds (16 Mi): 20 M reads of 24 bases, the packed scan against the ASCII scan of the
-    same reads on the GPU (the ASCII path is the one the oracle pins at this size elsewhere) -- counts and every record."""
+    """More reads than one packed segment holds (64 Mi by default; 8 Mi here: three segments): 20 M reads of 24 bases, the packed
+    scan against the ASCII scan of the same reads on the GPU (the ASCII path is the one the oracle pins at this size elsewhere) --
+    counts and every record."""
+    import os
     import torch
     from seeq_amd import device as dev
     n, L = 20_000_000, 24
+    os.environ["SEEQ_PACKED_SEG_READS"] = str(1 << 23)
     pattern, tau = "GATTAGCC", 1
     stream = torch.cuda.current_stream().cuda_stream
     text = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda:0")
@@ -165,7 +182,10 @@ def test_packed_two_segments_equal_the_ascii_scan(gpu, capi):
     db = torch.empty(n * 6, dtype=torch.uint8, device="cuda:0"); dn = torch.empty(n * 3, dtype=torch.uint8, device="cuda:0")
     dev.pack_reads_device(text.data_ptr(), n, L, db.data_ptr(), dn.data_ptr(), stream=stream)
     pat = dev.Pattern(pattern, tau)
-    sc = dev.Scanner(stream)
+    try:
+        sc = dev.Scanner(stream)
+    finally:
+        os.environ.pop("SEEQ_PACKED_SEG_READS", None)
     sc.run(pat, text.data_ptr(), text.numel(), SQ_BEST, dev.WANT_RECORDS)
     a = sc.fetch(); ra = sc.records(a["nrecords"])
     sc.run_packed(pat, db.data_ptr(), dn.data_ptr(), n, L, options=SQ_BEST, want=dev.WANT_RECORDS)

@@ -315,6 +315,79 @@ def test_pair_automaton_is_a_superset_and_its_first_candidate_bounds_the_scan(ha
     assert nwalked >= 40
 
 
+def test_quad_automaton_flags_every_hit_read_and_bounds_its_window(harness, oracle):
+    """Host side of the packed walk's four-bases-per-step table (seeq_dfa.h section 3b): every line is a read walked from the root,
+    a packed byte per step.  (1) Every read the oracle finds a hit in gets a candidate; (2) the exact pass over the window
+    [first candidate - (m + tau), last candidate + m + tau + 2) of the read reports the read's own hits (SQ_ALL, hence every
+    option) -- what k_verify_packed scans; (3) the headline pattern is served by its two-part filter: 95 states."""
+    import ctypes as C
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(4242)
+    harness.harness_quad_walk.restype = C.c_long
+    harness.harness_quad_walk.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    cases = [("GATGTAGCGCGATTAGCCTG", 3), ("GATTAGC", 1), ("CACAGAT", 3), ("ACGT", 1), ("ACNNGT[AC]TTG", 2), ("GATGTAGCGCGATTAGCCTGAAAATG", 2),
+             ("TTTTTTTT", 2), ("GATGTAGCGCGATTAG", 4), ("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5), ("AAAAAAAAAAAAAAAAAAAA", 3),
+             ("ACGTACGTACGTACGT", 2), ("GATGTAGCGCGATTAGCCTG", 1), ("GATGTAGCGCGATTAGCCTG", 5)]
+    for _ in range(8):
+        m = rng.choice([6, 12, 20, 31, 45])
+        pat = "".join("N" if rng.random() < 0.05 else "[" + "".join(rng.sample("ACGT", 2)) + "]" if rng.random() < 0.08
+                      else rng.choice("ACGT") for _ in range(m))
+        cases.append((pat, rng.randint(0, min(5, m - 2))))
+    nwalked = 0
+    for pat, tau in cases:
+        keys, _ = oracle.parse(pat)
+        m = len(keys)
+        core = plain(pat)
+        lines = []
+        for i in range(600):
+            n = rng.choice([1, 3, 20, 60, 150, 151, 250])
+            t = "".join(rng.choice("ACGT") for _ in range(n))
+            if i % 2 == 0 and n >= m:
+                cp = mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
+                q = rng.choice([0, 0, max(0, n - len(cp)), rng.randrange(max(1, n - len(cp) + 1))])
+                t = (t[:q] + cp + t[q + len(cp):])[:n]
+            if len(set(core)) <= 2 and i % 3 == 0:
+                unit = core[:2] if len(set(core)) == 2 else core[:1]
+                t = ((unit * m)[:rng.randint(max(1, m - tau - 1), m + 2)] + t)[:max(n, 1)]
+            if i % 17 == 0:
+                q = rng.randrange(n)
+                t = t[:q] + "N" + t[q + 1:]                  # (an N aliases onto G in the walk: a superset)
+            lines.append(t)
+        buf = ("\n".join(lines) + "\n").encode()
+        exp = oracle.buffer_scan(pat, tau, buf, SQ_ALL)
+        want = {}
+        for ln, st, en, di in exp["records"]:
+            want.setdefault(int(ln), []).append((int(st), int(en), int(di)))
+        out = np.zeros(1 << 18, dtype=np.uint64)
+        info = (C.c_uint32 * 5)()
+        ne = harness.harness_quad_walk(buf, len(buf), bytes(keys), m, tau, out.ctypes.data, out.size, info)
+        if ne < 0:
+            continue
+        assert ne <= out.size
+        nwalked += 1
+        assert 1 <= info[0] <= 127 and info[0] <= info[1], list(info)
+        starts = np.cumsum([0] + [len(x) + 1 for x in lines])
+        first, last = {}, {}
+        for p in out[:ne]:
+            p = int(p)
+            ln = int(np.searchsorted(starts, p, side="right"))
+            col = p - int(starts[ln - 1])
+            first.setdefault(ln, col)
+            last[ln] = col
+        missing = sorted(set(want) - set(first))
+        assert not missing, (pat, tau, missing[:5])
+        for ln, hits in want.items():
+            line = lines[ln - 1]
+            pos = max(0, first[ln] - (m + tau))
+            stop = min(len(line), last[ln] + m + tau + 2)
+            sub = oracle.string_match(pat, tau, line[pos:stop], SQ_ALL)[::-1]
+            assert [(s + pos, e + pos, d) for s, e, d in sub] == hits, (pat, tau, ln, first[ln], last[ln])
+        if (pat, tau) == ("GATGTAGCGCGATTAGCCTG", 3):
+            assert info[0] == 95 and info[3] == 2, list(info)
+    assert nwalked >= 12, nwalked
+
+
 def test_multi_pattern_automata_cover_every_pattern_of_every_line(harness, oracle):
     """Host side of the one-pass multi-pattern scan (seeq_dfa.h section 4): the UNION pair automaton of a barcode set walked
     in 64-byte chains as k_pair walks it, then the resolve automaton over each candidate line's window
