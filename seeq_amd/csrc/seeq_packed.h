@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_packed_list(PackedArgs a)
          const uint32_t ei = e0 + lane, k = k0 + ei;
          if (ei < total && k < a.cap) {                     /* (k >= cap: the overflow is reported by k_packed_counts) */
             const uint32_t r = s_r[wave][ei];
-            const uint32_t cd = a.cand[r], sl = a.cslot[r];
+            const uint32_t cd = a.cand[r], sl = a.stage ? a.cslot[r] : 0u;      /* (no staging text: the exact pass finds the read through its line number) */
             a.hit_start[k] = sl * a.pitch;
             a.hit_line[k] = (uint32_t)(a.line_base + r + 1u);
             a.hit_col[k] = cd >> 16;
