@@ -726,6 +726,11 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="allocate ONE rank's text, workspace and record buffers, print what it needs of the GPU's memory "
                          "(per rank of --gpus N: every rank holds the same) and exit -- no scan, no launcher")
+    ap.add_argument("--placement-candidates", type=int, default=4,
+                    help="hold the text in N device buffers (the plain allocation, then blocks of 16, 32, ... GiB), scan each before the "
+                         "warm-up and run the steps over the one whose scan kernel is fastest: k_pair's launch time follows the physical "
+                         "pages a buffer gets from the driver, 0.77 or 0.92 ms per 3.75 GiB segment (DESIGN.md section 5); every "
+                         "candidate's times are reported in `placement`; 1 = the plain allocation only")
     ap.add_argument("--log-clocks", action="store_true", help="sample the GPU's clock / power from sysfs during the timed steps (a thread)")
     ap.add_argument("--check", choices=["full", "sample"], default="full",
                     help="full (default when oracle/_ref/seeq_ref exists): besides the oracle sample, EVERY line of the run is compared with the "
@@ -827,6 +832,48 @@ def main():
         print(json.dumps({"dry_run": True, "workload": wl[5] % n, "hbm_per_rank": hbm}))
         return
 
+    placement = None
+    spare = []
+    if args.placement_candidates > 1:
+        cands = [text]
+        keep, alloc_bytes = [], [nbytes]
+        # the extra candidates are cut from power-of-two blocks, 16 GiB and up for the headline text (the driver's VRAM allocator hands such
+        # a request one aligned block when it has one: in profiles/r04/placement_candidates.txt these were the fast ones); SEEQ_BENCH_CAND_BYTES
+        # sets other sizes (experiments); a candidate that does not fit is skipped
+        sizes = [int(x) for x in os.environ.get("SEEQ_BENCH_CAND_BYTES", "").split(",") if x]
+        p2 = 1 << max(20, (nbytes - 1).bit_length())
+        for ci in range(args.placement_candidates - 1):
+            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else p2 << ci)
+            free_now, _ = torch.cuda.mem_get_info(dev_index)
+            if want_bytes + (24 << 30) > free_now:             # (room for the later sections' own buffers)
+                want_bytes = nbytes
+                if want_bytes + (24 << 30) > free_now:
+                    break
+            big = torch.empty(want_bytes, dtype=torch.uint8, device=device)
+            t2 = big[:nbytes]
+            t2.copy_(text)
+            cands.append(t2)
+            keep.append(big)
+            alloc_bytes.append(want_bytes)
+        torch.cuda.synchronize()
+        rows = []
+        for rnd in range(2):                                   # two rounds over the candidates: the second one counts (the first also warms the device up)
+            for i, t2 in enumerate(cands):
+                for _ in range(2):
+                    sc.run(pat, t2.data_ptr(), nbytes, opt, want)
+                    sc.fetch()
+                row = {"forward_ms": round(sc.last_times_ms()["forward"], 4), "launch_ms": [round(x, 4) for x in sc.last_launch_times_ms()]}
+                if rnd == 0:
+                    rows.append({"allocated_bytes": alloc_bytes[i], "first_round": row})
+                else:
+                    rows[i].update(row)
+        best = min(range(len(cands)), key=lambda i: rows[i]["forward_ms"])
+        text = cands[best]
+        spare = [t2 for i, t2 in enumerate(cands) if i != best] + keep     # (kept until the timed steps are over: freeing neighbours changed a buffer's speed in profiles/r04_placement.txt)
+        placement = {"candidates": rows, "chosen": best,
+                     "note": "the same text in N device buffers, each scanned twice before the warm-up; the steps run over the buffer whose scan kernel "
+                             "was fastest (the launch time follows the physical pages a buffer gets from the driver, DESIGN.md section 5)"}
+
     def step():
         sc.run(pat, text.data_ptr(), nbytes, opt, want)
         cnt = sc.fetch()
@@ -868,6 +915,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    del spare[:]                                               # (the other placement candidates: the later sections need the room)
     rank_rows = None
     if world > 1:
         # per rank, for the line: its own clock, its read range, what it counted there (the step's value uses the MAX clock)
@@ -971,6 +1019,7 @@ def main():
                          # the scan kernel's own reading of the clock it ran at: shader clock / constant 100 MHz counter around its first wave's work
                          "scan_kernel_core_clock_mhz": stats3(step_clk),
                          "gpu_clock_power_during_steps": clocks.summary() if clocks else None},
+            "placement": placement,
             "roofline": {"bound": "hbm", "kernel": kern + (" (pair automaton: a prefix of the pattern or a partition filter; candidates, verified by the exact pass)" if kern == "k_pair"
                                           else " (partition filter automaton)" if filt else ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
