@@ -24,6 +24,25 @@ for f in find("trace", "*kernel_stats.csv"):
         print("%-60s %8s %12.1f %12.2f %7s" % (name, r.get("Calls"), float(r.get("TotalDurationNs", 0)) / 1e3,
                                               float(r.get("AverageNs", 0)) / 1e3, r.get("Percentage")))
 
+# bench.py scans every placement candidate before its warm-up (k_pair's speed follows the buffer's pages: DESIGN.md section 5), so the
+# table above averages the scan kernel over buffers of different speeds.  TIMED_SCAN_DISPATCHES = steps x launches per step: the scan kernel's
+# average over the LAST that many dispatches -- the timed steps, all over the chosen buffer: the figure bench.py's roofline.avg_launch_ms is.
+nlast = int(os.environ.get("TIMED_SCAN_DISPATCHES", "0"))
+if nlast > 0:
+    for f in find("trace", "*kernel_trace.csv"):
+        rows = [r for r in csv.DictReader(open(f)) if any(s_ in r["Kernel_Name"] for s_ in ("k_pair<", "k_stream<"))]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        last = rows[-nlast:]
+        if last:
+            us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last]
+            print()
+            print("== scan kernel over the timed steps (last %d of %d dispatches: %s) ==" % (len(last), len(rows), last[0]["Kernel_Name"].split("(")[0]))
+            print("avg_us %.2f  min %.2f  max %.2f" % (sum(us) / len(us), min(us), max(us)))
+            before = rows[:-nlast]
+            if before:
+                ub = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in before]
+                print("the dispatches before them (placement candidates, warm-up): avg_us %.2f  min %.2f  max %.2f" % (sum(ub) / len(ub), min(ub), max(ub)))
+
 print()
 print("== PMC counters: mean per dispatch, per kernel ==")
 agg = defaultdict(lambda: defaultdict(list))
