@@ -257,3 +257,67 @@ def test_packed_record_offsets_are_those_of_the_ascii_form(gpu, capi):
         assert np.array_equal(oa, ob), mo
         assert np.array_equal(ob, (rb[:, 0].astype(np.uint64) - 1) * (L + 1))
     sc.close(); pat.close()
+
+
+def _packed_fuzz(dev, torch, oracle, seed, ncases, nreads=1500):
+    """Random patterns (classes, N, 4 .. 44 positions, distance 0 .. 5), random read lengths, reads with planted mutated copies, N and lower
+    case: the packed scan against the oracle for every match option and both counts.  Returns how many cases walked the quad table."""
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(seed)
+    nquad = 0
+    for case in range(ncases):
+        m = rng.choice([4, 6, 8, 10, 12, 16, 20, 20, 20, 24, 31, 36, 44])
+        pattern = "".join("N" if rng.random() < 0.04 else "[" + "".join(sorted(rng.sample("ACGT", 2))) + "]" if rng.random() < 0.06
+                          else rng.choice("ACGT") for _ in range(m))
+        if rng.random() < 0.15:
+            unit = "".join(rng.choice("ACGT") for _ in range(rng.choice([1, 2, 3])))
+            pattern = (unit * m)[:m]                         # periodic patterns: occurrences overlap, walks restart inside occurrences
+        tau = rng.randint(0, min(5, m - 2))
+        L = rng.choice([m, m + 1, 37, 50, 75, 100, 149, 150, 151, 200, 250, 256])
+        L = max(L, 1)
+        core = plain(pattern).replace("N", "A")
+        lines = []
+        for i in range(nreads):
+            t = "".join(rng.choice("ACGT") for _ in range(L))
+            if i % 3 == 0 and L >= len(core):
+                cp = mutate(rng, core, rng.randint(0, tau + 2))
+                q = rng.choice([0, max(0, L - len(cp)), rng.randrange(max(1, L - len(cp) + 1))])
+                t = (t[:q] + cp + t[q + len(cp):])[:L]
+                if rng.random() < 0.2 and L >= 2 * len(core):     # a second copy: several candidates per read
+                    q2 = rng.randrange(L - len(core) + 1)
+                    t = (t[:q2] + core + t[q2 + len(core):])[:L]
+            if i % 13 == 0:
+                q = rng.randrange(L)
+                t = t[:q] + "N" + t[q + 1:]
+            if i % 41 == 0:
+                t = t.lower()
+            lines.append(t)
+        text = ("\n".join(lines) + "\n").encode()
+        pat = dev.Pattern(pattern, tau)
+        for mo in (SQ_FIRST, SQ_BEST, SQ_ALL):
+            exp = oracle.buffer_scan(pattern, tau, text, mo)
+            got = _packed_scan(dev, torch, pat, text, L, mo, dev.WANT_RECORDS)
+            assert got["nmatchlines"] == exp["nmatchlines"], (seed, case, pattern, tau, L, mo, got["kernel"], got["quad"])
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (seed, case, pattern, tau, L, mo, got["kernel"], got["quad"])
+        nquad += bool(got["quad"])
+        expa = oracle.buffer_scan(pattern, tau, text, SQ_ALL)
+        c2 = _packed_scan(dev, torch, pat, text, L, 0, dev.WANT_COUNTMATCH)
+        assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (seed, case, pattern, tau, L)
+        pat.close()
+    return nquad
+
+
+def test_packed_fuzz(gpu, capi, oracle):
+    """The packed paths (pair table, quad table, device unpack for patterns neither serves) on random patterns and read lengths: one fixed
+    seed and one fresh one per run (SEEQ_FUZZ_SEED replays it)."""
+    import os
+    import time
+    import torch
+    from seeq_amd import device as dev
+    nq = _packed_fuzz(dev, torch, oracle, 20261004, 30)
+    assert nq >= 4, nq                                       # (the quad table serves a share of them)
+    env = os.environ.get("SEEQ_FUZZ_SEED")
+    seed = int(env) if env else (int(time.time() * 1000) ^ os.getpid()) % 1_000_000_007
+    print("SEEQ_FUZZ_SEED=%d" % seed)
+    _packed_fuzz(dev, torch, oracle, seed, 40)
