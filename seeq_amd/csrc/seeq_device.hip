@@ -954,6 +954,7 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       v = getenv("SEEQ_NO_MYERS");     kn.no_myers = v && atoi(v) == 1;
       v = getenv("SEEQ_NO_WINDOW");    kn.no_window = v && atoi(v) == 1;
       v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
+      v = getenv("SEEQ_PAIR_PF");      kn.pair_pf = v && atoi(v) == 1;
       v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
       v = getenv("SEEQ_EMIT_ALL");     kn.old_emit_all = v && !strcmp(v, "old");
       v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
@@ -1327,12 +1328,19 @@ static int run_segments(seeqdev_scan *s)
 #define SEEQ_PAIR_FN(...) (stream_wu == 4 ? (const void *)k_pair<4, __VA_ARGS__> : stream_wu == 5 ? (const void *)k_pair<5, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_pair<6, __VA_ARGS__> \
                           : stream_wu == 7 ? (const void *)k_pair<7, __VA_ARGS__> : (const void *)k_pair<8, __VA_ARGS__>)
             stream_fn = fasta ? SEEQ_PAIR_FN(true) : SEEQ_PAIR_FN(false);
+            dfa_lds = (size_t)pat->pair_units * 16;
+            /* SEEQ_PAIR_PF=1: the variant that requests the next tile into LDS before it walks this one (seeq_pair.h, PF): twelve waves per
+               workgroup, their staging rows above the table */
+            if (kn.pair_pf && !fasta && dfa_lds + 12 * (size_t)PAIR_STAGE_BYTES <= (size_t)163840) {      /* (160 KB of LDS per CU on gfx950) */
+               stream_fn = SEEQ_PAIR_FN(false, 0, true);
+               nw = 12;
+               dfa_lds += 12 * (size_t)PAIR_STAGE_BYTES;
+            }
 #ifdef SEEQ_EXPERIMENTS                                   /* (builds of profiles/ only: the shipped library holds no kernel whose results are void) */
             if (!fasta && stream_wu == 5 && kn.pair_exp >= 2 && kn.pair_exp <= 4)       /* experiments (profiles/r03): timing only */
                stream_fn = kn.pair_exp == 2 ? (const void *)k_pair<5, false, 2> : kn.pair_exp == 3 ? (const void *)k_pair<5, false, 3> : (const void *)k_pair<5, false, 4>;
 #endif
 #undef SEEQ_PAIR_FN
-            dfa_lds = (size_t)pat->pair_units * 16;
          }
          int per_cu = occupancy_of(s, stream_fn, 64 * nw, dfa_lds);
          if (per_cu < 0) return -1;
@@ -1473,7 +1481,7 @@ static int run_segments(seeqdev_scan *s)
          f.slice_cap = f.cap_tmp / nsl;
          if (use_stream) {
             void *kargs[] = {&f};
-            HIP_TRY(hipLaunchKernel(stream_fn, dim3(fgrid), dim3(64 * STREAM_NW), kargs, dfa_lds, st), EIO);
+            HIP_TRY(hipLaunchKernel(stream_fn, dim3(fgrid), dim3(64 * (unsigned)nw), kargs, dfa_lds, st), EIO);
          }
          else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st, f);
          else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st, f);

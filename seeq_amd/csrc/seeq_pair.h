@@ -125,13 +125,52 @@ __device__ __forceinline__ fused_v4u pair_load16(const FusedArgs &a, uint64_t of
 
 typedef uint32_t pair_u32_unaligned __attribute__((aligned(1)));
 
+/* PF (round 4, the experiment the round-3 review asked for; SEEQ_PAIR_PF=1): the NEXT tile's text requested before the walk of this one,
+ * straight into LDS (global_load_lds_dwordx4: no registers, the wave's eight 1 KiB rows + a row for the words before the tile), read back
+ * into the text registers when its turn comes.  The staging rows sit above the table: 55 KB + 12 waves x 8.25 KB = 154 KB, one workgroup of
+ * 12 waves per CU -- 24 walks per CU where the register kernel holds 64.
+ * Measured (100 M x 150 bp, ms per 3.75 GiB launch, the buffer's fast / slow pages -- DESIGN.md section 5 (i)):
+ *    the register kernel                                                0.77 / 0.92
+ *    PF, every lane requesting the pieces of ITS 128-byte line          0.95 / 1.06   (the register loads' pattern: there the eight requests
+ *                                                                                      of a lane are merged into one fetch of its line, a DMA's are not)
+ *    PF, coalesced requests (1 KiB per instruction, source swizzle)     0.78 / 0.875
+ * So with full overlap of the loads and 3/8 of the walks in flight it ties the register kernel on fast pages and is 5 % ahead on slow ones:
+ * not adopted (the default stays the register kernel), kept as a tested variant. */
+#define PAIR_STAGE_BYTES 8448u
+typedef __attribute__((address_space(3))) const fused_v4u pair_lds_cv4u;
+__device__ __forceinline__ void pair_glds16(const void *gsrc, uint32_t lds_dst)
+{
+   uint32_t keep;
+   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void pair_glds4(const void *gsrc, uint32_t lds_dst)
+{
+   uint32_t keep;
+   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+/* the whole tile at t0 (not the segment's cut-short last one) on its way into the wave's staging rows */
+__device__ __forceinline__ void pair_prefetch_tile(const FusedArgs &a, uint64_t t0, uint32_t sbase)
+{
+   uint32_t lid;
+   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+   /* COALESCED requests: instruction q moves the tile's q-th KiB, lane l the 16 bytes at slot l of it -- but inside every 128-byte line
+      (eight slots) the pieces are rotated by the line's number (slot = 8 * line + (piece ^ line)), so that the read-back of piece r by the
+      eight lanes of a row group -- one line each -- touches eight different bank groups (the swizzle sits on the SOURCE address: the
+      LDS image of an LDS-DMA is lane-linear) */
+   const uint8_t *p = a.text + t0 + (uint64_t)((lid >> 3) * 128u + (((lid & 7u) ^ (lid >> 3)) & 7u) * 16u);
+#pragma unroll
+   for (int q = 0; q < 8; q++) pair_glds16(p + 1024 * q, sbase + 1024u * (uint32_t)q);
+   pair_glds4(a.text + (t0 >= 32 ? t0 - 32 : 0) + ((lid & 7u) << 2), sbase + 8192u);
+}
+
 /* WU: warm-up dwords (4 .. 8); FA: FASTA input (header lines: see k_stream) */
 /* EXP (profiles/r03, SEEQ_PAIR_EXP: timing only, the results are void): 0 the kernel; 2 no LDS gathers; 3 no bookkeeping;
  * 4 no per-word checks -- what each part of the kernel costs */
-template <int WU, bool FA, int EXP = 0>
-__global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
+template <int WU, bool FA, int EXP = 0, bool PF = false>
+__global__ __launch_bounds__(64 * (PF ? 12 : STREAM_NW), PF ? 3 : 8) void k_pair(FusedArgs a)
 {
-   constexpr int NW = STREAM_NW;
+   constexpr int NW = PF ? 12 : STREAM_NW;
+   static_assert(!PF || !FA, "the FASTA variant reads text inside its loop: no prefetch variant of it");
    constexpr int CH = 128;
    constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
    constexpr int NM = CH / 32;                            /* newline mask registers per lane */
@@ -167,6 +206,9 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
    fused_v4u v[NQ];
    uint32_t halo = 0;                                     /* lanes 0..7: the eight words before the tile (lane 0's warm-up comes from them) */
    uint32_t tile = gwave;
+   const uint32_t sbase = PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.dfa_rows * 16u + (uint32_t)wave * PAIR_STAGE_BYTES)) : 0u;      /* my staging rows (LDS byte address: the table starts at 0) */
+   const bool cut_short = (a.seg_len % TB) != 0;
+   if (PF && tile < a.ntiles && !(tile + 1 == a.ntiles && cut_short)) pair_prefetch_tile(a, a.seg_base + (uint64_t)tile * TB, sbase);
    while (tile < a.ntiles) {
       const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;
       const bool partial = tile + 1 == a.ntiles && (a.seg_len % TB) != 0;
@@ -174,6 +216,17 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       uint32_t lane_off = (uint32_t)lane * CH;
       asm volatile("" : "+v"(lane_off));                  /* (see k_stream: keeps the per-lane 64-bit addresses out of the loop-invariant set) */
       const uint64_t my = t0 + lane_off;
+      if (PF && !partial) {
+         /* my tile has been on its way since before the last walk: wait for it, take it into the registers, send for the next one */
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         uint32_t lid;
+         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+#pragma unroll
+         for (int q = 0; q < NQ; q++) v[q] = *(pair_lds_cv4u *)(uintptr_t)(sbase + (lid >> 3) * 1024u + (lid & 7u) * 128u + ((((uint32_t)q ^ lid) & 7u) << 4));
+         halo = *(fused_lds_cu32 *)(uintptr_t)(sbase + 8192u + (lid << 2));
+         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(halo), "+v"(v[0].x), "+v"(v[NQ - 1].w) :: "memory");
+         if (next < a.ntiles && !(next + 1 == a.ntiles && cut_short)) pair_prefetch_tile(a, a.seg_base + (uint64_t)next * TB, sbase);
+      } else
       {
          if (!partial) {                                  /* (all nine in one block, back to back: the eight pieces are merged into one fetch of each 128-byte line) */
             const uint8_t *p = a.text + my;

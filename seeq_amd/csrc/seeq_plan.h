@@ -33,6 +33,7 @@ struct ScanKnobs {
    bool no_skipcount;    /* SEEQ_NO_SKIPCOUNT=1: SQ_IGNORE, every chain with a skipped byte in its warm-up window makes up a candidate, as before round 4 */
    bool old_order;       /* SEEQ_ORDER=old: k_fused_post + k_scanset_* + k_stream_reorder + k_stream_bounds on read-length lines too, as before round 4 (A/B, tests) */
    bool old_verify;      /* SEEQ_VERIFY=old: k_exact1<COUNT> + the three-launch scan behind the filters, as before round 4 (A/B, tests) */
+   bool pair_pf;         /* SEEQ_PAIR_PF=1: k_pair's variant that prefetches the next tile into LDS (experiment) */
    bool no_packed_quad;  /* SEEQ_PACKED_QUAD=0: the packed walk over the pair table even where the pattern has a quad table (A/B, tests) */
    bool old_emit_all;    /* SEEQ_EMIT_ALL=old: SQ_ALL records behind k_verify through k_exact1's EMIT pass, one lane per line (A/B, tests) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */

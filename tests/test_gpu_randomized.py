@@ -122,7 +122,8 @@ VARIANTS = [{"SEEQ_FUSED_KERNEL": "pair"}, {"SEEQ_FUSED_KERNEL": "stream"}, {"SE
             {"SEEQ_NO_FILTER": "1"}, {"SEEQ_STREAM_SUB": "0"}, {"SEEQ_SEGMENT_BYTES": "65536"}, {"SEEQ_STREAM_WU": "8"},
             {"SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"}, {"SEEQ_EXACT": "generic"}, {"SEEQ_NO_LEADERS": "1"}, {"SEEQ_NO_WINDOW": "1"},
             {"SEEQ_NO_MYERS": "1"}, {"SEEQ_VERIFY": "old"}, {"SEEQ_VERIFY": "old", "SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"},
-            {"SEEQ_ORDER": "old"}, {"SEEQ_ORDER": "old", "SEEQ_VERIFY": "old"}, {"SEEQ_NO_SKIPCOUNT": "1"}, {"SEEQ_NO_LL_FILTER": "1"}, {"SEEQ_EMIT_ALL": "old"}]
+            {"SEEQ_ORDER": "old"}, {"SEEQ_ORDER": "old", "SEEQ_VERIFY": "old"}, {"SEEQ_NO_SKIPCOUNT": "1"}, {"SEEQ_NO_LL_FILTER": "1"}, {"SEEQ_EMIT_ALL": "old"}, {"SEEQ_PAIR_PF": "1", "SEEQ_FUSED_KERNEL": "pair"},
+            {"SEEQ_PAIR_PF": "1", "SEEQ_FUSED_KERNEL": "pair", "SEEQ_SEGMENT_BYTES": "65536"}]
 
 
 @pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in sorted(v.items())))

@@ -256,6 +256,10 @@ def test_two_real_segments_full_size_parity(gpu, workload, reads):
     assert line["results"]["lines"] == reads and chk["result"] == "bit-exact"
     assert chk["oracle_lines_checked"] >= 1_000_000 and chk["segment_seams_checked"] >= 1
     assert line["roofline"]["launches_per_step"] >= 2
+    # the text was held in several candidate buffers and the steps ran over the one whose scan kernel was fastest
+    pl = line["placement"]
+    assert len(pl["candidates"]) >= 2 and all(len(c["launch_ms"]) == line["roofline"]["launches_per_step"] for c in pl["candidates"])
+    assert pl["candidates"][pl["chosen"]]["forward_ms"] == min(c["forward_ms"] for c in pl["candidates"])
     # ... and EVERY line against the reference binary itself (bench.py --check full, the default when oracle/_ref travelled)
     from oracle.pyoracle import REF_BIN
     if os.path.exists(REF_BIN):
