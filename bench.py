@@ -705,7 +705,7 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["chrom"], default="best")
@@ -726,8 +726,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="allocate ONE rank's text, workspace and record buffers, print what it needs of the GPU's memory "
                          "(per rank of --gpus N: every rank holds the same) and exit -- no scan, no launcher")
-    ap.add_argument("--placement-candidates", type=int, default=4,
-                    help="hold the text in N device buffers (the plain allocation, then blocks of 16, 32, ... GiB), scan each before the "
+    ap.add_argument("--placement-candidates", type=int, default=8,
+                    help="hold the text in N device buffers (the plain allocation, blocks of 16, 32 and 64 GiB, then plain ones), scan each before the "
                          "warm-up and run the steps over the one whose scan kernel is fastest: k_pair's launch time follows the physical "
                          "pages a buffer gets from the driver, 0.77 or 0.92 ms per 3.75 GiB segment (DESIGN.md section 5); every "
                          "candidate's times are reported in `placement`; 1 = the plain allocation only")
@@ -843,7 +843,7 @@ def main():
         sizes = [int(x) for x in os.environ.get("SEEQ_BENCH_CAND_BYTES", "").split(",") if x]
         p2 = 1 << max(20, (nbytes - 1).bit_length())
         for ci in range(args.placement_candidates - 1):
-            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else p2 << ci)
+            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else (min(p2 << ci, 64 << 30) if ci < 3 else nbytes))      # (blocks of 16 / 32 / 64 GiB, then plain ones)
             free_now, _ = torch.cuda.mem_get_info(dev_index)
             if want_bytes + (24 << 30) > free_now:             # (room for the later sections' own buffers)
                 want_bytes = nbytes
@@ -887,6 +887,8 @@ def main():
     clocks = ClockSampler(dev_index) if (rank == 0 and args.log_clocks) else None
     if clocks:
         clocks.start()
+    import gc
+    gc.disable()                                               # (no collector pause inside the timed region; enabled again behind it)
     t0 = time.perf_counter()
     fwd_ms = 0.0
     fwd_launches = 0
@@ -915,6 +917,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     del spare[:]                                               # (the other placement candidates: the later sections need the room)
     rank_rows = None
     if world > 1:
@@ -1013,7 +1016,7 @@ def main():
                                    "compaction_exact_records": ex_ms / args.steps},
             # the spread behind the means: per step (host clock around run + fetch; device events of its two parts) and per launch of
             # the scan kernel (full-size launches only: the last segment of a buffer is shorter)
-            "per_step": {"ms": stats3(step_wall), "forward_scan_ms": stats3(step_fwd), "post_pass_ms": stats3(step_post),
+            "per_step": {"ms": stats3(step_wall), "ms_all": [round(x, 3) for x in step_wall[:64]], "forward_scan_ms": stats3(step_fwd), "post_pass_ms": stats3(step_post),
                          "scan_launch_ms_full_segments": stats3([x for i, x in enumerate(launch_ms) if (i + 1) % max(1, int(launches_per_step)) != 0 or launches_per_step == 1]),
                          "scan_launch_ms_all": [round(x, 4) for x in launch_ms[:64]],
                          # the scan kernel's own reading of the clock it ran at: shader clock / constant 100 MHz counter around its first wave's work

@@ -23,9 +23,9 @@ done
 timeout -k 10 600 python3 profiles/multi_bench.py 10000000 > $O/multi.jsonl 2> $O/multi.err; echo "multi exit $?"
 fi
 if [ $PART = profile ]; then
-# (bench.py scans its 4 placement candidates 2 x 2 times before the warm-up: 16 + 1 + 3 = 20 scans of the text per profiled run)
-TIMED_SCAN_DISPATCHES=12 TEXT_BYTES_TOTAL=302000000000 timeout -k 10 500 bash profiles/gpu_profile.sh r04_final_best --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi --no-fastq --check-lines 0 > $O/profile_best.log 2>&1; echo "profile best exit $?"
-TIMED_SCAN_DISPATCHES=21 TEXT_BYTES_TOTAL=502000000000 timeout -k 10 500 bash profiles/gpu_profile.sh r04_final_cfg5 --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi --no-fastq --check-lines 0 > $O/profile_cfg5.log 2>&1; echo "profile cfg5 exit $?"
+# (profiled with four placement candidates instead of the default eight: bench.py scans each 2 x 2 times before the warm-up, 16 + 1 + 3 = 20 scans of the text per run)
+TIMED_SCAN_DISPATCHES=12 TEXT_BYTES_TOTAL=302000000000 timeout -k 10 500 bash profiles/gpu_profile.sh r04_final_best --placement-candidates 4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi --no-fastq --check-lines 0 > $O/profile_best.log 2>&1; echo "profile best exit $?"
+TIMED_SCAN_DISPATCHES=21 TEXT_BYTES_TOTAL=502000000000 timeout -k 10 500 bash profiles/gpu_profile.sh r04_final_cfg5 --placement-candidates 4 --workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi --no-fastq --check-lines 0 > $O/profile_cfg5.log 2>&1; echo "profile cfg5 exit $?"
 find gpurun_out/prof_r04_final_best gpurun_out/prof_r04_final_cfg5 -name "*.csv" -size +2M -delete
 head -40 gpurun_out/prof_r04_final_best/summary.txt
 fi
