@@ -819,6 +819,7 @@ struct seeqdev_scan {
    float       clk_mhz;           /* core clock the last run's scan launches ran at (mean over the launches; 0: not measured) */
    int         ncu;               /* compute units of the device (cached) */
    size_t      lds_per_wg;        /* LDS a workgroup may allocate on it */
+   size_t      lds_per_cu;        /* LDS of a compute unit (what a workgroup gets when it asks for it: hipFuncAttributeMaxDynamicSharedMemorySize) */
    ScanKnobs   knobs;
    OccMemo     occ[8]; int nocc;  /* hipOccupancyMaxActiveBlocksPerMultiprocessor results */
    bool        last_filter;       /* the last run walked a partition filter automaton */
@@ -967,10 +968,11 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       s->pk_seg_reads = v && atol(v) >= 64 && (size_t)atol(v) <= ((size_t)1 << 26) ? (size_t)atol(v) & ~(size_t)63 : PACKED_SEG_READS_DEFAULT;
       s->ncu = 256;
       s->lds_per_wg = 65536;
+      s->lds_per_cu = 65536;
       int dev = 0;
       hipDeviceProp_t prop;
       if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      { s->ncu = prop.multiProcessorCount; s->lds_per_wg = prop.sharedMemPerBlock; }
+      { s->ncu = prop.multiProcessorCount; s->lds_per_wg = prop.sharedMemPerBlock; s->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor; }
    }
    if (e != hipSuccess) {
       hip_fail(e, "seeqdevScanNew", EIO);
@@ -1331,7 +1333,7 @@ static int run_segments(seeqdev_scan *s)
             dfa_lds = (size_t)pat->pair_units * 16;
             /* SEEQ_PAIR_PF=1: the variant that requests the next tile into LDS before it walks this one (seeq_pair.h, PF): twelve waves per
                workgroup, their staging rows above the table */
-            if (kn.pair_pf && !fasta && dfa_lds + 12 * (size_t)PAIR_STAGE_BYTES <= (size_t)163840) {      /* (160 KB of LDS per CU on gfx950) */
+            if (kn.pair_pf && !fasta && dfa_lds + 12 * (size_t)PAIR_STAGE_BYTES <= s->lds_per_cu) {      /* (160 KB of LDS per CU on gfx950) */
                stream_fn = SEEQ_PAIR_FN(false, 0, true);
                nw = 12;
                dfa_lds += 12 * (size_t)PAIR_STAGE_BYTES;

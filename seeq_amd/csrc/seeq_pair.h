@@ -135,7 +135,8 @@ typedef uint32_t pair_u32_unaligned __attribute__((aligned(1)));
  *                                                                                      of a lane are merged into one fetch of its line, a DMA's are not)
  *    PF, coalesced requests (1 KiB per instruction, source swizzle)     0.78 / 0.875
  * So with full overlap of the loads and 3/8 of the walks in flight it ties the register kernel on fast pages and is 5 % ahead on slow ones:
- * not adopted (the default stays the register kernel), kept as a tested variant. */
+ * not adopted (the default stays the register kernel), kept as a tested variant.  (A thirteenth wave -- the words before the tile by an ordinary
+ * load into a register of their own, 8 KB of staging per wave -- was no faster: 0.865 - 0.945 beside the register kernel's 0.85 - 0.93 on one box.) */
 #define PAIR_STAGE_BYTES 8448u
 typedef __attribute__((address_space(3))) const fused_v4u pair_lds_cv4u;
 __device__ __forceinline__ void pair_glds16(const void *gsrc, uint32_t lds_dst)
