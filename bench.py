@@ -727,7 +727,7 @@ def main():
                     help="allocate ONE rank's text, workspace and record buffers, print what it needs of the GPU's memory "
                          "(per rank of --gpus N: every rank holds the same) and exit -- no scan, no launcher")
     ap.add_argument("--placement-candidates", type=int, default=8,
-                    help="hold the text in N device buffers (the plain allocation, blocks of 16, 32 and 64 GiB, then plain ones), scan each before the "
+                    help="hold the text in N device buffers (the plain allocation, then blocks of 16, 32, 64, 16, 32, 16, 32 GiB), scan each before the "
                          "warm-up and run the steps over the one whose scan kernel is fastest: k_pair's launch time follows the physical "
                          "pages a buffer gets from the driver, 0.77 or 0.92 ms per 3.75 GiB segment (DESIGN.md section 5); every "
                          "candidate's times are reported in `placement`; 1 = the plain allocation only")
@@ -837,13 +837,13 @@ def main():
     if args.placement_candidates > 1:
         cands = [text]
         keep, alloc_bytes = [], [nbytes]
-        # the extra candidates are cut from power-of-two blocks, 16 GiB and up for the headline text (the driver's VRAM allocator hands such
-        # a request one aligned block when it has one: in profiles/r04/placement_candidates.txt these were the fast ones); SEEQ_BENCH_CAND_BYTES
-        # sets other sizes (experiments); a candidate that does not fit is skipped
+        # the extra candidates are cut from power-of-two blocks, 16 GiB and up for the headline text: in profiles/r04/placement_candidates.txt
+        # 11 of 18 such blocks were fast against 1 of 36 plain allocations (the driver's VRAM allocator hands a power-of-two request one
+        # aligned block while it has one); SEEQ_BENCH_CAND_BYTES sets other sizes (experiments); a candidate that does not fit ends the list
         sizes = [int(x) for x in os.environ.get("SEEQ_BENCH_CAND_BYTES", "").split(",") if x]
         p2 = 1 << max(20, (nbytes - 1).bit_length())
         for ci in range(args.placement_candidates - 1):
-            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else (min(p2 << ci, 64 << 30) if ci < 3 else nbytes))      # (blocks of 16 / 32 / 64 GiB, then plain ones)
+            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else min(p2 << (0, 1, 2, 0, 1, 0, 1)[ci % 7], 64 << 30))      # (blocks of 16 / 32 / 64 / 16 / 32 / 16 / 32 GiB)
             free_now, _ = torch.cuda.mem_get_info(dev_index)
             if want_bytes + (24 << 30) > free_now:             # (room for the later sections' own buffers)
                 want_bytes = nbytes
@@ -864,7 +864,7 @@ def main():
                     sc.fetch()
                 row = {"forward_ms": round(sc.last_times_ms()["forward"], 4), "launch_ms": [round(x, 4) for x in sc.last_launch_times_ms()]}
                 if rnd == 0:
-                    rows.append({"allocated_bytes": alloc_bytes[i], "first_round": row})
+                    rows.append({"allocated_bytes": alloc_bytes[i], "device_address": "0x%x" % t2.data_ptr(), "first_round": row})
                 else:
                     rows[i].update(row)
         best = min(range(len(cands)), key=lambda i: rows[i]["forward_ms"])
