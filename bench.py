@@ -838,7 +838,7 @@ def main():
         cands = [text]
         keep, alloc_bytes = [], [nbytes]
         # the extra candidates are cut from power-of-two blocks, 16 GiB and up for the headline text: in profiles/r04/placement_candidates.txt
-        # 11 of 18 such blocks were fast against 1 of 36 plain allocations (the driver's VRAM allocator hands a power-of-two request one
+        # 28 of 60 such blocks were fast against 1 of 48 plain allocations (the driver's VRAM allocator hands a power-of-two request one
         # aligned block while it has one); SEEQ_BENCH_CAND_BYTES sets other sizes (experiments); a candidate that does not fit ends the list
         sizes = [int(x) for x in os.environ.get("SEEQ_BENCH_CAND_BYTES", "").split(",") if x]
         p2 = 1 << max(20, (nbytes - 1).bit_length())
