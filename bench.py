@@ -869,7 +869,7 @@ def main():
                     rows[i].update(row)
         best = min(range(len(cands)), key=lambda i: rows[i]["forward_ms"])
         text = cands[best]
-        spare = [t2 for i, t2 in enumerate(cands) if i != best] + keep     # (kept until the timed steps are over: freeing neighbours changed a buffer's speed in profiles/r04_placement.txt)
+        spare = [t2 for i, t2 in enumerate(cands) if i != best] + keep     # (held until the timed steps are over; freeing them first changes nothing: profiles/r04/placement_candidates.txt)
         placement = {"candidates": rows, "chosen": best,
                      "note": "the same text in N device buffers, each scanned twice before the warm-up; the steps run over the buffer whose scan kernel "
                              "was fastest (the launch time follows the physical pages a buffer gets from the driver, DESIGN.md section 5)"}

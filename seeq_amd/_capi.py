@@ -65,7 +65,7 @@ EXPORTS = [
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevScanLastLaunchTimes", "seeqdevScanLastClockMHz", "seeqdevSynthReads",
-    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanLastPackedQuad", "seeqdevScanCopyOffsets", "seeqdevHostAlloc",
+    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanLastPackedQuad", "seeqdevScanCopyOffsets", "seeqdevHostAlloc", "seeqdevTextAlloc", "seeqdevTextFree",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
     "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanLastMulti", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
 ]
@@ -199,6 +199,10 @@ def lib():
     L.seeqdevHostAlloc.restype = C.c_void_p
     L.seeqdevHostFree.argtypes = [C.c_void_p]
     L.seeqdevHostFree.restype = None
+    L.seeqdevTextAlloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.seeqdevTextAlloc.restype = C.c_void_p
+    L.seeqdevTextFree.argtypes = [C.c_void_p]
+    L.seeqdevTextFree.restype = None
     L.seeqdevSynthReads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                     C.c_uint64, C.c_void_p]
     L.seeqdevSynthReads.restype = C.c_int

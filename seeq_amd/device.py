@@ -36,6 +36,32 @@ def pack_reads(text, read_len, with_nmask=True):
     return bases[:n * stride], (nmask[:n * nstride] if with_nmask else None), int(n)
 
 
+class TextBuffer:
+    """Device memory for resident text chosen by measurement (seeqdevTextAlloc): the scan kernel's speed follows the physical pages a
+    buffer gets, so up to `candidates` allocations are probed and the fastest kept.  `ptr` is the device address, `probe_ms` the candidates'
+    scan-kernel times (empty when nothing was probed).  Contents undefined; free() or the garbage collector releases it."""
+
+    def __init__(self, nbytes, candidates=8):
+        ms = (C.c_float * 8)()
+        n = C.c_int(0)
+        p = _capi.lib().seeqdevTextAlloc(int(nbytes), int(candidates), ms, C.byref(n))
+        if not p:
+            raise SeeqDeviceError(_capi.error_text())
+        self.ptr, self.nbytes = int(p), int(nbytes)
+        self.probe_ms = [float(ms[i]) for i in range(n.value)]
+
+    def free(self):
+        if self.ptr:
+            _capi.lib().seeqdevTextFree(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def pack_reads_device(text_ptr, nreads, read_len, bases_ptr, nmask_ptr=None, stream=None):
     """ASCII reads in HBM (nreads lines of read_len bases + newline) -> the packed layout in HBM (device pointers)."""
     _check(_capi.lib().seeqdevPackReadsDevice(C.c_void_p(text_ptr), nreads, read_len, C.c_void_p(bases_ptr), C.c_void_p(nmask_ptr) if nmask_ptr else None,

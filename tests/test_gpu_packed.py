@@ -321,3 +321,34 @@ def test_packed_fuzz(gpu, capi, oracle):
     seed = int(env) if env else (int(time.time() * 1000) ^ os.getpid()) % 1_000_000_007
     print("SEEQ_FUZZ_SEED=%d" % seed)
     _packed_fuzz(dev, torch, oracle, seed, 40)
+
+
+def test_text_alloc_picks_a_buffer_by_measurement(gpu, capi):
+    """seeqdevTextAlloc (resident text placed by measurement): three candidates are probed, the returned buffer holds
+    text like any other -- the same reads scanned in it and in a torch allocation give the same counts and records; a small request or
+    candidates = 1 is a plain allocation."""
+    import torch
+    from seeq_amd import device as dev
+    n, L = 2_000_000, 150
+    pattern, tau = "GATGTAGCGCGATTAGCCTG", 3
+    nb = n * (L + 1)
+    buf = dev.TextBuffer(nb, candidates=3)
+    assert buf.ptr and len(buf.probe_ms) == 3 and all(t > 0 for t in buf.probe_ms)
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+    dev.synth_reads(ref.data_ptr(), 0, n, L, pattern, tau, stream=stream)
+    dev.synth_reads(buf.ptr, 0, n, L, pattern, tau, stream=stream)
+    torch.cuda.synchronize()
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner(stream)
+    sc.run(pat, ref.data_ptr(), nb, SQ_BEST, dev.WANT_RECORDS)
+    a = sc.fetch(); ra = sc.records(a["nrecords"])
+    sc.run(pat, buf.ptr, nb, SQ_BEST, dev.WANT_RECORDS)
+    b = sc.fetch(); rb = sc.records(b["nrecords"])
+    assert a == b and a["nmatchlines"] > n // 50 and np.array_equal(ra, rb)
+    sc.close(); pat.close()
+    buf.free()
+    small = dev.TextBuffer(1 << 20, candidates=8)
+    plain = dev.TextBuffer(nb, candidates=1)
+    assert small.ptr and plain.ptr and small.probe_ms == [] and plain.probe_ms == []
+    small.free(); plain.free()
