@@ -535,6 +535,7 @@ typedef struct {
    uint32_t  nstates_raw;
    uint32_t  table_bytes;    /* nstates * 512 */
    int       mp, nparts;     /* as seeq_pair_t */
+   int       warm;           /* text bytes a walk started at the root needs before it sees what the line-long walk sees (the chunked ASCII walk) */
    double    p_accept;
    uint16_t *table;          /* [nstates][256]: index = the packed byte (first base in bits 7-6; codes A 0, C 1, T 2, G 3) */
 } seeq_quad_t;
@@ -589,7 +590,7 @@ static inline seeq_quad_t *seeq_quad_plan(const char *keys, int m, int tau)
       if (!n) break;
       seeq_quad_t *d = seeq_quad_from_next(next, n, 4 * mp + 64);
       if (!d) break;                                        /* (sizes grow with the prefix) */
-      d->mp = mp; d->nparts = 1;
+      d->mp = mp; d->nparts = 1; d->warm = mp + tau - 1;
       seeq_quad_free(best);
       best = d;
    }
@@ -597,15 +598,18 @@ static inline seeq_quad_t *seeq_quad_plan(const char *keys, int m, int tau)
       int cut[SEEQ_DFA_MAX_PARTS + 1];
       for (int p = 0; p <= k; p++) cut[p] = (int)((long)p * m / k);
       const int t = tau / k;
-      int shortest = m;
-      for (int p = 0; p < k; p++) if (cut[p + 1] - cut[p] < shortest) shortest = cut[p + 1] - cut[p];
+      int shortest = m, longest = 0;
+      for (int p = 0; p < k; p++) {
+         if (cut[p + 1] - cut[p] < shortest) shortest = cut[p + 1] - cut[p];
+         if (cut[p + 1] - cut[p] > longest) longest = cut[p + 1] - cut[p];
+      }
       if (shortest < t + 2) continue;
       uint32_t *next = NULL;
       const uint32_t n = seeq_dfa_bfs_parts(keys, cut, k, t, &next);
       if (!n) continue;
       seeq_quad_t *d = seeq_quad_from_next(next, n, 4 * m + 64);
       if (!d) continue;
-      d->mp = m; d->nparts = k;
+      d->mp = m; d->nparts = k; d->warm = longest + t - 1;
       if (!best || d->p_accept < best->p_accept) { seeq_quad_free(best); best = d; }
       else seeq_quad_free(d);
    }

@@ -250,6 +250,43 @@ extern "C" long harness_quad_walk(const uint8_t *text, size_t n, const char *key
    return (long)ne;
 }
 
+// The same table under the chunked ASCII walk (seeq_pair.h, QD): every `chain`-byte chain of the text walked on its own from the root, four
+// bytes per step, after a warm-up over the `warm_bytes` bytes before it (0 = the automaton's own warm-up rounded up to whole words; '\n' where
+// the buffer starts or has ended).  An accept inside the owned chain reports its byte; an accept during the warm-up reports the chain's
+// first byte (the made-up candidate).  info as harness_quad_walk, info[5] = warm-up bytes of the automaton.
+extern "C" long harness_quad_chain_walk(const uint8_t *text, size_t n, const char *keys, int m, int tau, int chain, int warm_bytes,
+                                        uint64_t *out, size_t cap, uint32_t *info)
+{
+   seeq_quad_t *d = seeq_quad_plan(keys, m, tau);
+   if (!d) return -1;
+   if (info) { info[0] = d->nstates; info[1] = d->nstates_raw; info[2] = (uint32_t)d->mp; info[3] = (uint32_t)d->nparts; info[4] = (uint32_t)(d->p_accept * 1e9); info[5] = (uint32_t)d->warm; }
+   const long long W = warm_bytes > 0 ? warm_bytes : 4 * ((d->warm + 3) / 4);
+   size_t ne = 0;
+   for (size_t c0 = 0; c0 < n; c0 += (size_t)chain) {
+      uint32_t state = 0;
+      bool warm_flag = false, made_up = false;
+      for (long long p = (long long)c0 - W; p < (long long)c0 + chain && p < (long long)n; p += 4) {
+         uint32_t b = 0;
+         for (int i = 0; i < 4; i++) {
+            const long long q = p + i;
+            const uint8_t ch = (q < 0 || q >= (long long)n) ? (uint8_t)'\n' : text[q];
+            b |= ((uint32_t)(ch >> 1) & 3u) << (6 - 2 * i);
+         }
+         const uint16_t ent = d->table[(size_t)(state >> 9) * 256 + b];
+         state = ent & 0xFE00u;
+         if (p < (long long)c0) { warm_flag |= (ent & 0xFu) != 0; continue; }
+         if (p == (long long)c0 && warm_flag) made_up = true;
+         for (int i = 0; i < 4; i++) {
+            const bool hit = ((ent >> i) & 1u) != 0 || (i == 0 && made_up);
+            if (i == 0) made_up = false;
+            if (hit && p + i < (long long)n) { if (ne < cap) out[ne] = (uint64_t)(p + i); ne++; }
+         }
+      }
+   }
+   seeq_quad_free(d);
+   return (long)ne;
+}
+
 // ---- several patterns, one walk (seeq_dfa.h section 4) ----
 // keys: the patterns' key bytes concatenated (m[p] each).  harness_multi_walk: the union pair automaton walked as
 // harness_pair_walk walks a single one (chains of `chain` bytes, warm-up, restart, made-up candidates) -> candidate positions.

@@ -388,6 +388,78 @@ def test_quad_automaton_flags_every_hit_read_and_bounds_its_window(harness, orac
     assert nwalked >= 12, nwalked
 
 
+def test_quad_automaton_under_the_chunked_walk(harness, oracle):
+    """The quad table under the ASCII walk of seeq_pair.h (QD): 64-byte chains, each warmed up over the automaton's own warm-up (whole words)
+    and restarted when it accepts, newlines and N aliased onto bases.  (1) every line with a hit gets a candidate (the line of the
+    candidate's byte, a newline belonging to the line it ends); (2) the oracle over the line from m + tau columns before its FIRST candidate
+    reports the line's own hits -- what the exact pass scans."""
+    import ctypes as C
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(777001)
+    harness.harness_quad_chain_walk.restype = C.c_long
+    harness.harness_quad_chain_walk.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                C.POINTER(C.c_uint32)]
+    cases = [("GATGTAGCGCGATTAGCCTG", 3), ("GATTAGC", 1), ("CACAGAT", 3), ("ACNNGT[AC]TTG", 2), ("GATGTAGCGCGATTAGCCTGAAAATG", 2), ("TTTTTTTT", 2),
+             ("GATGTAGCGCGATTAG", 4), ("AAAAAAAAAAAAAAAAAAAA", 3), ("ACGTACGTACGTACGT", 2), ("GATGTAGCGCGATTAGCCTG", 1), ("GATGTAGCGCGATTAGCCTG", 5)]
+    for _ in range(6):
+        m = rng.choice([6, 12, 20, 31])
+        pat = "".join("N" if rng.random() < 0.05 else "[" + "".join(rng.sample("ACGT", 2)) + "]" if rng.random() < 0.08
+                      else rng.choice("ACGT") for _ in range(m))
+        cases.append((pat, rng.randint(0, min(4, m - 2))))
+    nwalked = 0
+    for pat, tau in cases:
+        keys, _ = oracle.parse(pat)
+        m = len(keys)
+        core = plain(pat)
+        lines = []
+        for i in range(500):
+            n = rng.choice([0, 1, 3, 20, 60, 150, 151, 400])
+            t = "".join(rng.choice("ACGT") for _ in range(n))
+            if i % 2 == 0 and n >= m:
+                cp = mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
+                q = rng.choice([0, 0, max(0, n - len(cp)), rng.randrange(max(1, n - len(cp) + 1))])
+                t = (t[:q] + cp + t[q + len(cp):])[:n]
+            if i % 17 == 0 and n:
+                q = rng.randrange(n)
+                t = t[:q] + "N" + t[q + 1:]
+            lines.append(t.lower() if i % 29 == 0 else t)
+        if len(set(core)) <= 2:
+            lines = []
+            for i in range(3000):
+                unit = core[:2] if len(set(core)) == 2 else core[:1]
+                run = (unit * m)[:rng.randint(max(1, m - tau - 1), m + 2)]
+                junk = lambda k: "".join(rng.choice("ACGT") for _ in range(k))
+                lines.append(rng.choice([run + junk(rng.randint(0, 50)), junk(rng.randint(0, 50)) + run, run, junk(rng.randint(0, 30)) + run + junk(rng.randint(0, 30))]))
+        buf = ("\n".join(lines) + ("\n" if rng.random() < 0.5 else "")).encode()
+        exp = oracle.buffer_scan(pat, tau, buf, SQ_ALL)
+        want = {}
+        for ln, st, en, di in exp["records"]:
+            want.setdefault(int(ln), []).append((int(st), int(en), int(di)))
+        starts = np.cumsum([0] + [len(x) + 1 for x in lines])
+        for chain, warm in ((64, 0), (64, 32), (16, 0)):
+            out = np.zeros(1 << 18, dtype=np.uint64)
+            info = (C.c_uint32 * 6)()
+            ne = harness.harness_quad_chain_walk(buf, len(buf), bytes(keys), m, tau, chain, warm, out.ctypes.data, out.size, info)
+            if ne < 0:
+                continue
+            assert ne <= out.size
+            nwalked += 1
+            first = {}
+            for p in out[:ne]:
+                p = int(p)
+                ln = int(np.searchsorted(starts, p, side="right"))
+                first.setdefault(ln, p - int(starts[ln - 1]))
+            missing = sorted(set(want) - set(first))
+            assert not missing, (pat, tau, chain, warm, missing[:5])
+            for ln, hits in want.items():
+                pos = max(0, first[ln] - (m + tau))
+                line = lines[ln - 1]
+                sub = oracle.string_match(pat, tau, line[pos:], SQ_ALL)[::-1]
+                assert [(s + pos, e + pos, d) for s, e, d in sub] == hits, (pat, tau, chain, ln, first[ln], pos)
+    assert nwalked >= 24, nwalked
+
+
 def test_multi_pattern_automata_cover_every_pattern_of_every_line(harness, oracle):
     """Host side of the one-pass multi-pattern scan (seeq_dfa.h section 4): the UNION pair automaton of a barcode set walked
     in 64-byte chains as k_pair walks it, then the resolve automaton over each candidate line's window
