@@ -726,8 +726,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="allocate ONE rank's text, workspace and record buffers, print what it needs of the GPU's memory "
                          "(per rank of --gpus N: every rank holds the same) and exit -- no scan, no launcher")
-    ap.add_argument("--placement-candidates", type=int, default=8,
-                    help="hold the text in N device buffers (the plain allocation, then blocks of 16, 32, 64, 16, 32, 16, 32 GiB), scan each before the "
+    ap.add_argument("--placement-candidates", type=int, default=12,
+                    help="hold the text in N device buffers (the plain allocation, then power-of-two blocks: 16 GiB each for the headline text), scan each before the "
                          "warm-up and run the steps over the one whose scan kernel is fastest: k_pair's launch time follows the physical "
                          "pages a buffer gets from the driver, 0.77 or 0.92 ms per 3.75 GiB segment (DESIGN.md section 5); every "
                          "candidate's times are reported in `placement`; 1 = the plain allocation only")
@@ -843,7 +843,7 @@ def main():
         sizes = [int(x) for x in os.environ.get("SEEQ_BENCH_CAND_BYTES", "").split(",") if x]
         p2 = 1 << max(20, (nbytes - 1).bit_length())
         for ci in range(args.placement_candidates - 1):
-            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else min(p2 << (0, 1, 2, 0, 1, 0, 1)[ci % 7], 64 << 30))      # (blocks of 16 / 32 / 64 / 16 / 32 / 16 / 32 GiB)
+            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else p2)      # (blocks of 16 GiB for the headline text: fast as often as the 32 and 64 GiB ones, more of them fit)
             free_now, _ = torch.cuda.mem_get_info(dev_index)
             if want_bytes + (24 << 30) > free_now:             # (room for the later sections' own buffers)
                 want_bytes = nbytes

@@ -139,9 +139,10 @@ void   seeqdevHostFree(void * p);
 
 /* Device memory for RESIDENT text, chosen by measurement: the scan kernel's time per 3.75 GiB follows the physical pages a buffer gets
  * from the driver (0.77 / 0.87 / 0.92 ms for the same text, stable for the life of the allocation), so a caller that
- * keeps text buffers resident picks each once.  Up to `candidates` (<= 8) allocations -- the plain one, then power-of-two blocks, which are
+ * keeps text buffers resident picks each once.  Up to `candidates` (<= 12) allocations -- the plain one, then power-of-two blocks, which are
  * fast far more often -- are filled with synthetic reads and scanned; the fastest is returned, the others freed.  candidates < 2 (or a
- * buffer under 64 MiB): a plain allocation.  probe_ms / nprobed (may be NULL): the candidates' scan-kernel times.  Contents undefined.
+ * buffer under 64 MiB): a plain allocation.  probe_ms (room for 12 floats) / nprobed (may be NULL): the candidates' scan-kernel times.
+ * Contents undefined.
  * NULL + errno on failure.  (The reference has no device memory: an addition of this boundary, like seeqdevHostAlloc.) */
 void * seeqdevTextAlloc(size_t bytes, int candidates, float * probe_ms, int * nprobed);
 void   seeqdevTextFree(void * d_text);

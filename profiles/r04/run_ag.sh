@@ -3,7 +3,7 @@
 O=gpurun_out/r04ag; mkdir -p $O
 B="--no-cpu-baseline --no-e2e --no-per-call --no-cli --no-packed --no-multi --no-fastq --check sample --check-lines 0 --steps 10 --warmup 1"
 for i in 1 2 3 4 5 6; do
-python bench.py $B --placement-candidates 8 > $O/p$i.json 2> $O/p$i.err
+python bench.py $B --placement-candidates 12 > $O/p$i.json 2> $O/p$i.err
 python3 - $O/p$i.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

@@ -2249,29 +2249,26 @@ extern "C" void seeqdevHostFree(void *p)
 
 /* Device memory for RESIDENT TEXT, chosen by measurement.  The scan kernel's time follows the physical pages a buffer gets from the driver
  * (0.77 / 0.87 / 0.92 ms per 3.75 GiB for the same text, stable for the life of the allocation; power-of-two blocks are fast far more often
- * than requests of an odd size: DESIGN.md section 5 (i)-(l)), so a caller that keeps text resident chooses its buffer once: up to eight
- * candidate allocations (the plain one, then blocks of p, 2p, 4p, p, 2p, p, 2p bytes, p = the power of two >= bytes, capped at 64 GiB),
- * each filled with synthetic reads and scanned twice with the benchmark pattern; the one whose scan kernel was fastest is returned, the
+ * than requests of an odd size: DESIGN.md section 5 (i)-(l)), so a caller that keeps text resident chooses its buffer once: up to twelve
+ * candidate allocations (the plain one, then blocks of p bytes, p = the power of two >= bytes), each filled with synthetic reads and
+ * scanned twice with the benchmark pattern; the one whose scan kernel was fastest is returned, the
  * others are freed.  probe_ms (may be NULL): the candidates' scan-kernel times, *nprobed of them.  The buffer's contents are undefined. */
 extern "C" void *seeqdevTextAlloc(size_t bytes, int candidates, float *probe_ms, int *nprobed)
 {
    seeqerr = 0;
    if (nprobed) *nprobed = 0;
    if (bytes == 0) bytes = 1;
-   void *blk[8] = {nullptr};
-   float ms[8];
+   void *blk[12] = {nullptr};
+   float ms[12];
    int n = 0;
-   if (candidates > 8) candidates = 8;
+   if (candidates > 12) candidates = 12;
    if (candidates < 2 || bytes < ((size_t)64 << 20)) candidates = 1;      /* (nothing to tell apart on a scan of microseconds) */
    size_t p2 = 1;
    while (p2 < bytes) p2 <<= 1;
-   static const int sh[7] = {0, 1, 2, 0, 1, 0, 1};
    for (int i = 0; i < candidates; i++) {
       size_t want = bytes;
       if (i > 0) {
-         want = p2 << sh[(i - 1) % 7];
-         const size_t cap = p2 > ((size_t)64 << 30) ? p2 : (size_t)64 << 30;
-         if (want > cap) want = cap;
+         want = p2;
          size_t freeb = 0, total = 0;
          if (hipMemGetInfo(&freeb, &total) != hipSuccess) break;
          if (want + bytes + ((size_t)2 << 30) > freeb) { want = bytes; if (want + bytes + ((size_t)2 << 30) > freeb) break; }   /* (room for the scan's workspace) */

@@ -41,8 +41,8 @@ class TextBuffer:
     buffer gets, so up to `candidates` allocations are probed and the fastest kept.  `ptr` is the device address, `probe_ms` the candidates'
     scan-kernel times (empty when nothing was probed).  Contents undefined; free() or the garbage collector releases it."""
 
-    def __init__(self, nbytes, candidates=8):
-        ms = (C.c_float * 8)()
+    def __init__(self, nbytes, candidates=12):
+        ms = (C.c_float * 12)()
         n = C.c_int(0)
         p = _capi.lib().seeqdevTextAlloc(int(nbytes), int(candidates), ms, C.byref(n))
         if not p:
