@@ -86,7 +86,7 @@ __device__ __forceinline__ void pair_warm4x2(uint32_t &sa, uint32_t wa, uint32_t
 
 /* four owned bytes of each chain: walk + pair masks (first pair of a chain ends up in bit 0), and the per-word checks of
  * both words between the gathers and their use */
-template <int EXP>
+template <int EXP, bool CHK>
 __device__ __forceinline__ void pair_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &nma, uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t &nmb,
                                             uint32_t &bad, bool first_of_two)
 {
@@ -96,14 +96,14 @@ __device__ __forceinline__ void pair_own4x2(uint32_t &sa, uint32_t wa, uint32_t 
       behind the walk, with every state and every intermediate kept -- spilled -- until then) */
    PAIR_X2(1)
    asm volatile("" : "+v"(wa));
-   if (EXP != 4) pair_chk(wa, bad, nma, first_of_two);
+   if (EXP != 4 && CHK) pair_chk(wa, bad, nma, first_of_two);
    asm volatile("" : "+v"(bad), "+v"(nma));
    __builtin_amdgcn_sched_barrier(0);
    hma = __builtin_amdgcn_alignbit(sa, hma, 1); hmb = __builtin_amdgcn_alignbit(sb, hmb, 1);
    asm volatile("" : "+v"(hma), "+v"(hmb));
    PAIR_X2(3)
    asm volatile("" : "+v"(wb));
-   if (EXP != 4) pair_chk(wb, bad, nmb, first_of_two);
+   if (EXP != 4 && CHK) pair_chk(wb, bad, nmb, first_of_two);
    asm volatile("" : "+v"(bad), "+v"(nmb));
    __builtin_amdgcn_sched_barrier(0);
    hma = __builtin_amdgcn_alignbit(sa, hma, 1); hmb = __builtin_amdgcn_alignbit(sb, hmb, 1);
@@ -164,6 +164,31 @@ __device__ __forceinline__ void pair_prefetch_tile(const FusedArgs &a, uint64_t 
    pair_glds4(a.text + (t0 >= 32 ? t0 - 32 : 0) + ((lid & 7u) << 2), sbase + 8192u);
 }
 
+/* The walk of one tile: warm-up of both chains, then their 64 owned bytes each; CHK: the fast alphabet check and the fast newline masks
+ * ride along (nmask[], bad); else the caller makes the masks. */
+template <int WU, int EXP, bool CHK>
+__device__ __forceinline__ void pair_walk(const fused_v4u (&v)[8], uint32_t halo, bool halo_nl, uint32_t (&hm)[2], uint32_t (&nmask)[4], uint32_t &tile_bad)
+{
+   constexpr int NQ = 8, NM = 4;
+   uint32_t sa = 0, sb = 0, hma = 0, hmb = 0, seena = 0, seenb = 0, bad = 0, nma = 0, nmb = 0;
+#pragma unroll
+   for (int k = 8 - WU; k < 8; k++)
+      pair_warm4x2<EXP>(sa, stream_from_prev_lane(pair_word8(v[NQ - 2], v[NQ - 1], k), halo_nl ? 0x0A0A0A0Au : (uint32_t)__builtin_amdgcn_readlane((int)halo, k)),
+                        sb, pair_word8(v[NQ / 2 - 2], v[NQ / 2 - 1], k), seena, seenb);
+#pragma unroll
+   for (int q = 0; q < NQ / 2; q++) {
+      pair_own4x2<EXP, CHK>(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, bad, true);
+      pair_own4x2<EXP, CHK>(sa, v[q].y, hma, nma, sb, v[q + NQ / 2].y, hmb, nmb, bad, false);
+      pair_own4x2<EXP, CHK>(sa, v[q].z, hma, nma, sb, v[q + NQ / 2].z, hmb, nmb, bad, true);
+      pair_own4x2<EXP, CHK>(sa, v[q].w, hma, nma, sb, v[q + NQ / 2].w, hmb, nmb, bad, false);
+      if (CHK && (q & 1)) { nmask[q >> 1] = nma; nmask[(q >> 1) + NM / 2] = nmb; nma = 0; nmb = 0; }
+   }
+   tile_bad = bad;
+   /* first pair of a chain in bit 31; a walk that accepted during its warm-up: my first pairs are candidates (see the header) */
+   hm[0] = __builtin_bitreverse32(hma) | ((seena & 1u) << 31);
+   hm[1] = __builtin_bitreverse32(hmb) | ((seenb & 1u) << 31);
+}
+
 /* WU: warm-up dwords (4 .. 8); FA: FASTA input (header lines: see k_stream) */
 /* EXP (profiles/r03, SEEQ_PAIR_EXP: timing only, the results are void): 0 the kernel; 2 no LDS gathers; 3 no bookkeeping;
  * 4 no per-word checks -- what each part of the kernel costs */
@@ -193,6 +218,7 @@ __global__ __launch_bounds__(64 * (PF ? 12 : STREAM_NW), PF ? 3 : 8) void k_pair
    uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0;    /* wave-uniform */
    bool wv_overflow = false;
    uint32_t wv_dirty = 0;
+   uint32_t dmode = 0;                                    /* wave-uniform: a tile of mine failed the fast alphabet check (DM, below) */
    uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
    const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
    const uint64_t last = a.nbytes - 1;
@@ -250,50 +276,35 @@ __global__ __launch_bounds__(64 * (PF ? 12 : STREAM_NW), PF ? 3 : 8) void k_pair
       }
       const bool halo_nl = t0 < 32;                       /* the buffer starts here: lane 0 warms up over newlines */
       /* ---- the walk: chain A = bytes 0..63 (warm-up: the previous lane's last bytes), chain B = bytes 64..127; the
-              alphabet check and the newline masks ride along ---- */
+              alphabet check and the newline masks ride along -- until a tile fails the check: from then on this wave walks
+              without them (DM, below) ---- */
       uint32_t hm[2], nmask[NM];
-      uint32_t tile_bad;
-      {
-         uint32_t sa = 0, sb = 0, hma = 0, hmb = 0, seena = 0, seenb = 0, bad = 0, nma = 0, nmb = 0;
-#pragma unroll
-         for (int k = 8 - WU; k < 8; k++)
-            pair_warm4x2<EXP>(sa, stream_from_prev_lane(pair_word8(v[NQ - 2], v[NQ - 1], k), halo_nl ? 0x0A0A0A0Au : (uint32_t)__builtin_amdgcn_readlane((int)halo, k)),
-                         sb, pair_word8(v[NQ / 2 - 2], v[NQ / 2 - 1], k), seena, seenb);
-#pragma unroll
-         for (int q = 0; q < NQ / 2; q++) {
-            pair_own4x2<EXP>(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, bad, true);
-            pair_own4x2<EXP>(sa, v[q].y, hma, nma, sb, v[q + NQ / 2].y, hmb, nmb, bad, false);
-            pair_own4x2<EXP>(sa, v[q].z, hma, nma, sb, v[q + NQ / 2].z, hmb, nmb, bad, true);
-            pair_own4x2<EXP>(sa, v[q].w, hma, nma, sb, v[q + NQ / 2].w, hmb, nmb, bad, false);
-            if (q & 1) { nmask[q >> 1] = nma; nmask[(q >> 1) + NM / 2] = nmb; nma = 0; nmb = 0; }
+      if (!dmode) {
+         uint32_t tile_bad;
+         pair_walk<WU, EXP, true>(v, halo, halo_nl, hm, nmask, tile_bad);
+         if (EXP == 3) {
+            wv_hitlines += (uint32_t)__popc(hm[0] ^ hm[1] ^ nmask[0] ^ nmask[1] ^ nmask[2] ^ nmask[3]) + tile_bad;
+            tile = next;
+            continue;
          }
-         tile_bad = bad;
-         /* first pair of a chain in bit 31; a walk that accepted during its warm-up: my first pairs are candidates (see the header) */
-         hm[0] = __builtin_bitreverse32(hma) | ((seena & 1u) << 31);
-         hm[1] = __builtin_bitreverse32(hmb) | ((seenb & 1u) << 31);
+         /* the fast check failed somewhere in the tile (wave-uniform): a byte that is not an upper-case base, N or a newline */
+         dmode = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(tile_bad != 0) != 0 ? 1 : 0);
+      } else {
+         uint32_t unused;
+         pair_walk<WU, EXP, false>(v, halo, halo_nl, hm, nmask, unused);
       }
-      if (EXP == 3) {
-         wv_hitlines += (uint32_t)__popc(hm[0] ^ hm[1] ^ nmask[0] ^ nmask[1] ^ nmask[2] ^ nmask[3]) + tile_bad;
-         tile = next;
-         continue;
-      }
-      /* the fast check failed somewhere in the tile (wave-uniform): the exact alphabet check and the exact newline masks, over
-         the tile's text fetched again piece by piece (its registers hold the next tile by now) */
-      if (__builtin_amdgcn_readfirstlane(__ballot(tile_bad != 0) != 0 ? 1 : 0)) {
-         uint32_t b2 = 0;
-#pragma unroll 1
-         for (int q = 0; q < NQ; q++) {
-            const fused_v4u x = pair_load16(a, my + 16 * q, lim, partial);
-            b2 |= fused_bad4(x.x) | fused_bad4(x.y) | fused_bad4(x.z) | fused_bad4(x.w);
-         }
-         uint32_t flag = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(b2 != 0) != 0 ? 1 : 0);
-         asm volatile("" : "+s"(flag));
-         wv_dirty |= flag;                                /* a byte that could end a line early: the exact pass then starts at the line's first byte */
+      /* DM (round 5): text with bytes outside { A C G T N \n } -- FASTQ quality lines, lower case.  Such a byte may alias onto the
+         newline column ('+', ':', 'J' ...), so the newline masks are made exactly, from the registers, which still hold the tile
+         (until round 5 the tile was fetched a second time, and text full of such bytes was kept off this kernel), and the scan is
+         flagged: a byte that could end a line early (SQ_FAIL; SQ_CONVERT: a NUL) may sit between a line's start and a candidate's
+         window, so the exact pass looks at that stretch before it trusts the window (verify_prefix_dirty, seeq_verify.h).  The flag
+         is conservative -- lower-case bases set it too -- and costs the exact pass one look per candidate.  Where one tile of a wave
+         is like that the next ones are too: the wave stays in this mode and its walks drop the fast check and the fast masks (6.5 of
+         the walk's 21 VALU per text word), which pays for the exact masks -- FASTQ records run at the speed of clean reads. */
+      if (dmode) {
+         wv_dirty |= 1u;
 #pragma unroll
-         for (int r = 0; r < NM; r++) {
-            const fused_v4u x = pair_load16(a, my + 32 * r, lim, partial), y = pair_load16(a, my + 32 * r + 16, lim, partial);
-            nmask[r] = stream_nl_mask32(x, y, flag == 0);
-         }
+         for (int r = 0; r < NM; r++) nmask[r] = stream_nl_mask32(v[2 * r], v[2 * r + 1], false);
       }
       /* ---- bookkeeping: what the tile owns ---- */
       uint32_t valid = CH;                                /* bytes of my chunk inside the segment */

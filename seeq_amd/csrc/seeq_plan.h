@@ -146,7 +146,10 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
    {
       const bool long_lines = (in.avg_line > 600.0 && kn.kernel != 3) || in.force_ll;      /* (a candidate inside a line of a whole tile sets force_ll) */
       if (p.fusable && in.force_path != 1 && (options & PLAN_MASK_INPUT) == 0 && (nd == 0 || nd == PLAN_SQ_CONVERT) && !long_lines && !in.no_stream &&
-          (kn.kernel == 3 || (kn.kernel == 0 && !(in.sample_dirty && in.line_hint <= 0))) && in.seg_bytes % (64u * 128u) == 0) {
+          /* (round 5: text full of foreign bytes -- FASTQ records -- stays here: a tile that fails the fast alphabet check makes its newline
+             masks again from its registers, and the exact pass looks at the bytes before a window, seeq_verify.h.  FASTA records with a
+             header per read stay with k_stream: the header test of the FA variant reads a byte per newline) */
+          (kn.kernel == 3 || (kn.kernel == 0 && !(in.sample_dirty && in.line_hint <= 0 && fasta))) && in.seg_bytes % (64u * 128u) == 0) {
          if (au.pair_state == 0) ensure(ctx, 1, 0, &au);
          p.use_pair = au.pair_state == 1 && (kn.kernel == 3 || in.multi_active || au.pair_pacc * in.avg_line <= 0.25);
       }

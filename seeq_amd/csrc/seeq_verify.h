@@ -208,6 +208,40 @@ struct verify_rules {
    }
 };
 
+/* Text with bytes outside the alphabet somewhere (Counters.dirty: FASTQ quality lines, lower case, binary junk): may the window of
+ * this lane's candidate be trusted?  The walk itself meets every byte of the window and ends the line at one that ends it; what
+ * it cannot see is such a byte BEFORE the window, in text[off, off + pos) -- the reference stopped there (libseeq.c:267-270) and
+ * the line has no occurrence behind it.  Under SQ_FAIL any byte outside { A C G T N a c g t n } counts (fused_bad4: U and u too,
+ * which is conservative), under SQ_CONVERT a NUL only (every other byte is an N there, libseeq.c:223-228).  Returns true when the
+ * stretch holds one: the lane then scans its line from the first byte, which is exact whatever the bytes are.  Wave-wide (every
+ * lane calls it; lanes with pos = 0 look at nothing): 64 bytes per round, the four loads in flight together. */
+__device__ __forceinline__ bool verify_prefix_dirty(const ScanArgs &a, uint64_t off, uint32_t pos)
+{
+   const bool nul_only = (a.options & SQ_CONVERT) != 0;
+   uint32_t bad = 0;
+   for (uint32_t o = 0; __any(o < pos && bad == 0u); o += 64u) {
+      if (o >= pos || bad) continue;
+      const uint64_t p0 = off + o;
+      fused_v4u v[4];
+      if (p0 + 64 <= a.nbytes) {
+#pragma unroll
+         for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const fused_v4u_unaligned *>(a.text + p0 + 16 * q);
+      } else {
+#pragma unroll
+         for (int q = 0; q < 4; q++) v[q] = direct_load16(a.text, p0 + 16 * q, a.nbytes);
+      }
+      const uint32_t n = pos - o;                           /* bytes of this block that lie before the window */
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+         const uint32_t w = verify_word_of(v, g);
+         const uint32_t b = nul_only ? (~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u) : fused_bad4(w);
+         const uint32_t keep = n >= 4u * g + 4u ? 0xFFFFFFFFu : n <= 4u * g ? 0u : (1u << (8u * (n - 4u * g))) - 1u;
+         bad |= b & keep;
+      }
+   }
+   return bad != 0u;
+}
+
 template <int W, int VAR>
 __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *eq2, const uint32_t *hit_col, uint4 *cache)
 {
@@ -245,7 +279,7 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
          /* the window: from skip_back columns before the line's first candidate (clean text: nothing ends the line before
             it, no occurrence ends before it) to m + tau + 1 behind its last one (seeq_pair.h; exact1_body has the argument) */
          const uint32_t col = hit_col[kk];
-         if (col > a.skip_back && !dirty) pos = col - a.skip_back;      /* (dirty: a byte outside the alphabet somewhere in the text scanned so far -- it may end this line early) */
+         if (col > a.skip_back) pos = col - a.skip_back;
          if (a.window_ok) {
             uint32_t lastcol = a.hit_last ? a.hit_last[kk] : col;
             bool unbounded = false;
@@ -254,6 +288,8 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
             if (!unbounded) stop_at = lastcol + m + tau1 + 1u;
          }
       }
+      /* dirty (kernel-uniform): a byte outside the alphabet somewhere in the text scanned so far -- it may end this line before the window */
+      if (dirty && verify_prefix_dirty(a, off, pos)) pos = 0;
       fused_state_t<W> st;
       st.init(m);
       verify_rules<VAR> r;

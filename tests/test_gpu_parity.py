@@ -1015,6 +1015,72 @@ def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle)
 
 
 @pytest.mark.parametrize("seg", [None, "65536"])
+def test_fastq_records_on_the_pair_walk(gpu, capi, oracle, seg, monkeypatch):
+    """Round 5: FASTQ-shaped text (four-line records, quality lines made of bytes that alias onto bases AND onto the newline
+    column: '+', ':', ';', '*', 'J') stays on k_pair under SQ_FAIL and SQ_CONVERT.  Every tile fails the fast alphabet check
+    there, remakes its newline masks from its registers, and k_verify looks at the bytes between a line's start and a
+    candidate's window (reference libseeq.c:267-270: under SQ_FAIL such a byte ends the line).  Adversarial lines: a perfect
+    copy of the pattern in a quality line BEHIND a foreign byte (no hit under SQ_FAIL, a hit under SQ_CONVERT), in front of the
+    first one (a hit in both), a NUL in front of a copy (no hit in either), copies in header and '+' lines, reads with lower
+    case, U, N; records of every match option, both counts, segments of 64 KiB (lines across seams)."""
+    from seeq_amd import device as dev
+    if seg:
+        monkeypatch.setenv("SEEQ_SEGMENT_BYTES", seg)
+    rng = random.Random(20255)
+    qual = "".join(chr(c) for c in range(33, 75))
+    for (pattern, tau, L) in ((PAT20, 3, 150), (PAT40, 5, 250), ("GATTAGC", 1, 36)):
+        core = dev.plain_pattern(pattern).replace("N", "A")
+        lines = []
+        for i in range(6000):
+            read = [rng.choice("ACGT") for _ in range(L)]
+            if rng.random() < 0.3:
+                c = _mutate(rng, core, rng.randint(0, tau + 2))
+                p = rng.randrange(0, max(1, L - len(c)))
+                read[p:p + len(c)] = list(c)
+            r = rng.random()
+            if r < 0.03: read[rng.randrange(L)] = rng.choice("Nn")
+            elif r < 0.06: read = [ch.lower() if rng.random() < 0.5 else ch for ch in read]
+            elif r < 0.08: read[rng.randrange(L)] = rng.choice("Uu")
+            elif r < 0.09: read[rng.randrange(L)] = "\0"
+            q = [rng.choice(qual) for _ in range(L)]
+            r = rng.random()
+            if r < 0.15:                                   # a copy somewhere in the quality line, foreign bytes before it
+                p = rng.randrange(1, max(2, L - len(core)))
+                q[p:p + len(core)] = list(core)
+            elif r < 0.25:                                 # a copy at the very start: nothing ends the line before it
+                q[0:len(core)] = list(core)
+            elif r < 0.32:                                 # clean DNA up to a copy deep in the line, one foreign byte / NUL far in front of it
+                q = [rng.choice("ACGT") for _ in range(L)]
+                p = rng.randrange(L // 2, L - len(core))
+                q[p:p + len(core)] = list(core)
+                q[rng.randrange(0, max(1, p - len(core) - tau - 2))] = rng.choice("!+:J*\0;@")
+            elif r < 0.36:                                 # the same without the foreign byte: a plain hit line among the quality lines
+                q = [rng.choice("ACGT") for _ in range(L)]
+                p = rng.randrange(0, L - len(core))
+                q[p:p + len(core)] = list(core)
+            hdr = "@r%07d" % i if rng.random() > 0.05 else "@" + core
+            plus = "+" if rng.random() > 0.05 else "+" + core
+            lines += [hdr, "".join(read), plus, "".join(q)]
+        buf = ("\n".join(lines) + ("\n" if rng.random() < 0.5 else "")).encode("latin-1")
+        pat = dev.Pattern(pattern, tau)
+        sc = dev.Scanner()
+        for nd in (SQ_FAIL, SQ_CONVERT):
+            for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
+                exp = oracle.buffer_scan(pattern, tau, buf, opt | nd)
+                got = sc.scan_host(pat, buf, opt | nd, dev.WANT_RECORDS)
+                if len(pattern) >= 20:
+                    assert sc.last_kernel() == "k_pair", (pattern, nd, sc.last_kernel())      # the library's own choice: no knob is set
+                assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (pattern, nd, opt)
+                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, nd, opt)
+            expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL | nd)
+            c1 = sc.scan_host(pat, buf, nd, dev.WANT_COUNTLINES)
+            c2 = sc.scan_host(pat, buf, nd, dev.WANT_COUNTMATCH)
+            assert c1["nmatchlines"] == expa["nmatchlines"] and c2["nhits"] == len(expa["records"]), (pattern, nd)
+        sc.close()
+        pat.close()
+
+
+@pytest.mark.parametrize("seg", [None, "65536"])
 def test_stream_fuzz_long_lines(gpu, capi, oracle, seg, monkeypatch):
     """Random patterns over long lines (up to 70 000 bytes, many planted hits per line, some with a non-DNA byte or as
     FASTA records): the long-line variant of k_stream and the window walk of the exact pass against the oracle.
