@@ -428,7 +428,7 @@ def fastq_shape(reads, nrec, L, pattern, tau, pat, steps=5):
     del idx
     torch.cuda.synchronize()
     res = {"records": nrec, "lines": 4 * nrec, "bytes": int(text.numel()), "match_option": "--best with positions", "modes": {}}
-    # the reference's counts over the whole buffer: shards of whole records in /dev/shm, one pinned process each
+    # the reference's counts over the whole buffer: shards of 500 k whole records in /dev/shm, waves of P pinned processes, the three modes per wave
     ref_counts = None
     files = []
     if os.path.exists(REF_BIN):
@@ -441,24 +441,28 @@ def fastq_shape(reads, nrec, L, pattern, tau, pat, steps=5):
         if quota and quota < procs:
             procs = max(1, int(quota))
         tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-        per = (nrec + procs - 1) // procs
+        per = 500_000
+        shards = [(lo, min(nrec, lo + per)) for lo in range(0, nrec, per)]
+        ref_counts = {"fail": 0, "convert": 0, "ignore": 0}
+        tref = time.perf_counter()
         try:
-            for k in range(procs):
-                lo, hi = k * per, min(nrec, (k + 1) * per)
-                if lo >= hi:
-                    break
-                path = os.path.join(tmpdir, "seeq_bench_fq_%d_%d.txt" % (os.getpid(), k))
-                buf[lo:hi].reshape(-1).cpu().numpy().tofile(path)
-                files.append(path)
-            ref_counts = {}
-            for name, x in (("fail", "0"), ("convert", "1"), ("ignore", "2")):
-                ps = [subprocess.Popen([REF_BIN, "-c", "-d", str(tau), "-x", x, pattern, f], stdout=subprocess.PIPE, text=True,
-                                       preexec_fn=(lambda c=allowed[k % len(allowed)]: os.sched_setaffinity(0, {c}))) for k, f in enumerate(files)]
-                ref_counts[name] = sum(int(p_.communicate()[0].split()[0]) for p_ in ps)
+            for w0 in range(0, len(shards), procs):
+                wave = shards[w0:w0 + procs]
+                files = [os.path.join(tmpdir, "seeq_bench_fq_%d_%d.txt" % (os.getpid(), k)) for k in range(len(wave))]
+                for f, (lo, hi) in zip(files, wave):
+                    buf[lo:hi].reshape(-1).cpu().numpy().tofile(f)
+                for name, x in (("fail", "0"), ("convert", "1"), ("ignore", "2")):
+                    ps = [subprocess.Popen([REF_BIN, "-c", "-d", str(tau), "-x", x, pattern, f], stdout=subprocess.PIPE, text=True,
+                                           preexec_fn=(lambda c=allowed[k % len(allowed)]: os.sched_setaffinity(0, {c}))) for k, f in enumerate(files)]
+                    ref_counts[name] += sum(int(p_.communicate()[0].split()[0]) for p_ in ps)
+                for f in files:
+                    os.unlink(f)
+                files = []
         finally:
             for f in files:
                 if os.path.exists(f):
                     os.unlink(f)
+        res["reference_count_seconds"] = round(time.perf_counter() - tref, 1)
     orc = Oracle()
     kpre = 50_000                                            # records of the oracle prefix (200 k lines)
     host = text[:kpre * REC].cpu().numpy()
@@ -481,8 +485,10 @@ def fastq_shape(reads, nrec, L, pattern, tau, pat, steps=5):
         ok = c2["nmatchlines"] == exp["nmatchlines"] and c2["nlines"] == exp["nlines"] and \
             np.array_equal(s2.records(c2["nrecords"]).astype(np.uint64), exp["records"])
         s2.close()
-        row = {"lines_per_s": cnt["nlines"] / dt, "gb_per_s": text.numel() / dt / 1e9, "ms_per_step": dt * 1e3, "kernel": kern,
-               "matching_lines": int(cnt["nmatchlines"]), "oracle_prefix_records_identical": bool(ok)}
+        tm = sc.last_times_ms()
+        row = {"lines_per_s": cnt["nlines"] / dt, "gb_per_s": text.numel() / dt / 1e9, "whole_step_frac": text.numel() / dt / 1e9 / HBM_PEAK_GBS,
+               "ms_per_step": dt * 1e3, "kernel": kern, "scan_launches": tm["forward_launches"], "forward_scan_ms": round(tm["forward"], 4),
+               "post_pass_ms": round(tm["exact"], 4), "matching_lines": int(cnt["nmatchlines"]), "oracle_prefix_records_identical": bool(ok)}
         if ref_counts is not None:
             row["reference_matching_lines"] = ref_counts[name]
             row["identical_to_reference_count"] = ref_counts[name] == int(cnt["nmatchlines"])
@@ -702,6 +708,212 @@ def launch_ranks(args):
     return 0
 
 
+class Ctx:
+    """What every section of a run needs: the modules, the process-group facts, the command line."""
+    pass
+
+
+def timed_steps(ctx, sc, pat, text_ptr, nbytes, opt, want, steps, barrier):
+    """`steps` passes of the hot path over resident text (seeqdevScanRun + seeqdevScanFetch + the count reduce), bracketed as the driver's
+    contract says; returns the host-clock seconds and the device-side sums."""
+    import gc
+    torch, dist, shard = ctx.torch, ctx.dist, ctx.shard
+    if barrier and ctx.world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    gc.disable()                                               # (no collector pause inside the timed region)
+    acc = {"fwd_ms": 0.0, "launches": 0, "idx_ms": 0.0, "ex_ms": 0.0, "step_wall": [], "step_fwd": [], "step_post": [], "launch_ms": [], "clk": []}
+    total = local = None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        sc.run(pat, text_ptr, nbytes, opt, want)
+        local = sc.fetch()
+        total = shard.reduce_counts(local, device=ctx.red_device, force=ctx.force_dist)
+        acc["step_wall"].append(1e3 * (time.perf_counter() - ts))
+        tm = sc.last_times_ms()
+        acc["fwd_ms"] += tm["forward"]; acc["launches"] += tm["forward_launches"]; acc["idx_ms"] += tm["index"]; acc["ex_ms"] += tm["exact"]
+        acc["step_fwd"].append(tm["forward"]); acc["step_post"].append(tm["exact"])
+        acc["launch_ms"].extend(sc.last_launch_times_ms())
+        clk = sc.last_clock_mhz()
+        if clk > 0:
+            acc["clk"].append(clk)
+    if barrier and ctx.world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    return elapsed, acc, total, local
+
+
+def run_workload(ctx, name, n, steps, warmup, candidates, first_steps, check_lines, check_mode, keep):
+    """One workload of WORKLOADS at `n` reads per rank: the text in a buffer from the PRODUCT's allocator (seeqdevTextAllocInfo through
+    dev.TextBuffer: `candidates` probed, the fastest kept), `steps` timed steps, the checks outside the timed region.  Before that, when
+    candidates > 1, the same text in a plain first allocation (what a caller that hipMallocs once gets) for `first_steps` timed steps:
+    `first_allocation`.  Returns the section of the bench line; with `keep` also the live objects (text, scanner, pattern, records)."""
+    torch, np, dev = ctx.torch, ctx.np, ctx.dev
+    args = ctx.args
+    wl = WORKLOADS[name]
+    PATTERN = (args.pattern if (args.pattern and name == args.workload) else wl[0])
+    TAU = wl[1] if (args.distance is None or name != args.workload) else args.distance
+    READ_LEN = (args.read_len if (args.read_len and name == args.workload) else wl[2])
+    mode, want_name = wl[3], wl[4]
+    L = READ_LEN + 1
+    first = ctx.rank * n                                       # this rank's read-index range (weak scaling)
+    nbytes = n * L
+    stream = torch.cuda.current_stream().cuda_stream
+    opt = {"best": dev.SQ_BEST, "first": 0, "all": dev.SQ_ALL}[mode]
+    want = dev.WANT_RECORDS if want_name == "records" else dev.WANT_COUNTLINES
+    mem_free0, mem_total = torch.cuda.mem_get_info(ctx.dev_index)
+    pat = dev.Pattern(PATTERN, TAU)
+    sc = dev.Scanner(stream)
+    seg = int(os.environ.get("SEEQ_SEGMENT_BYTES", str(SEG_BYTES_DEFAULT)))
+    seg_lines = min(n, seg // L + 2)
+    rec_cap = n // 8 + 1024 if mode != "all" else n // 4 + 1024
+    sc.reserve(nbytes, seg_lines + 64, max(seg_lines // 6 + 1024, 8192 * 64), rec_cap)
+    sc.set_profiling(True)
+
+    def synth(ptr):
+        dev.synth_reads(ptr, first, n, READ_LEN, dev.plain_pattern(PATTERN), TAU, stream=stream)
+        torch.cuda.synchronize()
+
+    first_alloc = None
+    if candidates > 1 and first_steps > 0 and not args.dry_run:
+        # the plain allocation a caller that hipMallocs once gets -- this process's first buffer of the size
+        tb0 = dev.TextBuffer(nbytes, 1)
+        synth(tb0.ptr)
+        for _ in range(2):
+            sc.run(pat, tb0.ptr, nbytes, opt, want); sc.fetch()
+        el0, a0, tot0, _ = timed_steps(ctx, sc, pat, tb0.ptr, nbytes, opt, want, first_steps, barrier=False)
+        full0 = [x for i, x in enumerate(a0["launch_ms"]) if (i + 1) % max(1, a0["launches"] // first_steps) != 0 or a0["launches"] == first_steps]
+        first_alloc = {"steps": first_steps, "ms_per_step": 1e3 * el0 / first_steps, "value": n / (el0 / first_steps),
+                       "scan_launch_ms": round(a0["fwd_ms"] / max(1, a0["launches"]), 4), "scan_launch_ms_full_segments": stats3(full0),
+                       "what": "the same text in a plain hipMalloc (seeqdevTextAlloc with one candidate), this rank only"}
+        tb0.free()
+    tb = dev.TextBuffer(nbytes, 1 if args.dry_run else candidates)
+    text = tb.tensor(ctx.device)
+    if not args.dry_run:
+        synth(tb.ptr)
+    torch.cuda.synchronize()
+    mem_free1, _ = torch.cuda.mem_get_info(ctx.dev_index)
+    hbm = {"total_bytes": int(mem_total), "free_before_bytes": int(mem_free0), "text_bytes": int(nbytes), "text_allocated_bytes": tb.allocated_bytes,
+           "text_workspace_records_bytes": int(mem_free0 - mem_free1), "free_after_bytes": int(mem_free1)}
+    if args.dry_run:
+        hbm["ranks"] = args.gpus
+        hbm["fits"] = bool(mem_free1 > (1 << 30))               # a GiB to spare for the later sections' own buffers
+        hbm["note"] = ("one rank's allocations (text + scan workspace reserved for its segments + record buffers), measured with hipMemGetInfo "
+                       "around them; every rank of a multi-GPU run holds the same")
+        return {"dry_run": True, "workload": wl[5] % n, "hbm_per_rank": hbm}, None
+    placement = {"api": "seeqdevTextAllocInfo", "candidates": candidates, "probed": len(tb.probe_ms), "chosen": tb.chosen,
+                 "probe_forward_ms": [round(x, 3) for x in tb.probe_ms], "allocated_bytes": tb.allocated_bytes, "selected": len(tb.probe_ms) > 1}
+
+    for _ in range(warmup):
+        sc.run(pat, text.data_ptr(), nbytes, opt, want); sc.fetch()
+    clocks = ClockSampler(ctx.dev_index) if (ctx.rank == 0 and args.log_clocks) else None
+    if clocks:
+        clocks.start()
+    elapsed, acc, total, local = timed_steps(ctx, sc, pat, text.data_ptr(), nbytes, opt, want, steps, barrier=True)
+    ctx.t_timed_end = time.perf_counter()
+    if clocks:
+        clocks.stop()
+    own_elapsed = elapsed
+    rank_rows = None
+    if ctx.world > 1:
+        dist = ctx.dist
+        mine = torch.tensor([elapsed, float(first), float(n), float(local["nlines"]), float(local["nmatchlines"]),
+                             acc["fwd_ms"] / max(1, steps), acc["ex_ms"] / max(1, steps), float(tb.chosen),
+                             acc["fwd_ms"] / max(1, acc["launches"])], dtype=torch.float64, device=ctx.red_device)
+        rows = [torch.zeros_like(mine) for _ in range(ctx.world)]
+        dist.all_gather(rows, mine)
+        rank_rows = [{"rank": r, "ms_per_step": 1e3 * float(x[0]) / steps, "first_read": int(x[1]), "reads": int(x[2]),
+                      "lines": int(x[3]), "matching_lines": int(x[4]), "forward_scan_ms": float(x[5]),
+                      "compaction_exact_records_ms": float(x[6]), "placement_chosen": int(x[7]), "scan_launch_ms": round(float(x[8]), 4)} for r, x in enumerate(rows)]
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.red_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity (rank 0, outside the timed region): prefix + every 97th block + segment seams vs the oracle; every line vs the reference ----
+    check = None
+    rec = None
+    if ctx.rank == 0 and check_lines > 0:
+        blocks, seams = parity_blocks(n, READ_LEN, seg, check_lines)
+        ranges = blocks + seams
+        rec = sc.records(local["nrecords"]) if want == dev.WANT_RECORDS else None
+        sc_chk = dev.Scanner(stream) if rec is None else None
+
+        def scan_block(f0, cnt_):
+            return sc_chk.scan_tensor(pat, text[f0 * L:(f0 + cnt_) * L], opt, want)
+        tchk = time.perf_counter()
+        lines_checked, nranges = oracle_check(text, ranges, READ_LEN, PATTERN, TAU, opt, rec is not None, rec, scan_block,
+                                              procs=min(32, max(1, (os.cpu_count() or 2) - 1)))
+        if rec is not None:       # size-independent properties of the whole record list
+            assert np.all(np.diff(rec[:, 0].astype(np.int64)) >= (0 if mode == "all" else 1)), "records not ordered by line"
+            assert np.all(rec[:, 1] <= rec[:, 2]) and np.all(rec[:, 2] <= READ_LEN) and np.all(rec[:, 3] <= TAU)
+            assert len(np.unique(rec[:, 0])) == local["nmatchlines"]
+        check = {"oracle_lines_checked": lines_checked, "ranges": nranges, "segment_seams_checked": len(seams),
+                 "seconds": round(time.perf_counter() - tchk, 2), "result": "bit-exact"}
+        if check_mode == "full":
+            # the whole buffer against the reference itself (SURVEY 8c: bit-exact match start / end / distance / count)
+            full = reference_full_check(text, n, READ_LEN, PATTERN, TAU, "first" if want != dev.WANT_RECORDS else mode, rec, local["nmatchlines"])
+            if full:
+                check.update(full)
+
+    sec = None
+    if ctx.rank == 0:
+        ms_per_step = 1e3 * elapsed / steps
+        lines_total = total["nlines"]
+        assert lines_total == n * ctx.world, (lines_total, n, ctx.world)
+        value = lines_total / (elapsed / steps)
+        # roofline of the dominant kernel (the scan kernel): algorithmic bytes per launch / mean launch time (HIP events on the scan's stream)
+        launches_per_step = acc["launches"] / steps
+        algo_bytes_launch = (n * L + 16 * local["nrecords"]) / launches_per_step + 8
+        fwd_avg_ms = acc["fwd_ms"] / max(1, acc["launches"])
+        achieved = algo_bytes_launch / (fwd_avg_ms * 1e-3) / 1e9
+        kern = sc.last_kernel()
+        filt = sc.last_filter()
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_scan_kernels.json")
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc)).get(kern)
+                # HBM bytes per text byte measured with rocprofv3 PMC passes (profiles/), scaled to this launch size -- only when the kernel
+                # sources are the ones it was measured on (else: null, the figure is not this build's)
+                if pj and pj.get("source_hash") == source_hash():
+                    traffic = pj["hbm_bytes_per_text_byte"] * (n * L / launches_per_step)
+                    traffic_src = "profiles/pmc_scan_kernels.json (rocprofv3 --pmc passes, source hash %s) x this launch's text bytes" % pj["source_hash"]
+                elif pj:
+                    traffic_src = "none: profiles/pmc_scan_kernels.json was measured on other kernel sources (%s, now %s)" % (pj.get("source_hash"), source_hash())
+            except Exception:
+                traffic = None
+        full_seg = [x for i, x in enumerate(acc["launch_ms"]) if (i + 1) % max(1, int(launches_per_step)) != 0 or launches_per_step == 1]
+        sec = {
+            "workload": wl[5] % n, "value": value, "gb_per_s": value * L / 1e9, "ms_per_step": ms_per_step, "steps": steps,
+            "config": {"pattern": PATTERN, "distance": TAU, "read_len": READ_LEN, "reads_per_gpu": n},
+            "device_ms_per_step": {"newline_index": round(acc["idx_ms"] / steps, 4), "forward_scan": round(acc["fwd_ms"] / steps, 4),
+                                   "compaction_exact_records": round(acc["ex_ms"] / steps, 4)},
+            "per_step": {"ms": stats3(acc["step_wall"]), "forward_scan_ms": stats3(acc["step_fwd"]), "post_pass_ms": stats3(acc["step_post"]),
+                         "scan_launch_ms_full_segments": stats3(full_seg), "scan_kernel_core_clock_mhz": stats3(acc["clk"]),
+                         "gpu_clock_power_during_steps": clocks.summary() if clocks else None},
+            "hbm_per_rank": hbm, "placement": placement, "first_allocation": first_alloc, "ranks": rank_rows,
+            "results": {"lines": lines_total, "matching_lines": total["nmatchlines"], "hits": total["nhits"],
+                        "oracle_check": check, "oracle_lines_checked": check["oracle_lines_checked"] if check else 0},
+            "roofline": {"bound": "hbm", "kernel": kern + (" (pair automaton: prefix / partition filter; candidates, verified by the exact pass)" if kern == "k_pair"
+                                                           else " (partition filter automaton)" if filt else ""),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "launches_per_step": launches_per_step, "avg_launch_ms": fwd_avg_ms, "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "whole_step_frac": (n * L + 16 * local["nrecords"] + 8 * launches_per_step) / (own_elapsed / steps) / 1e9 / HBM_PEAK_GBS},
+            "dtype": "int (u16 automaton state ids; exact-pass columns u32 bit-vectors)" if kern in ("k_stream", "k_pair") else "u32 bit-vectors",
+        }
+    live = {"text": text, "tb": tb, "sc": sc, "pat": pat, "rec": rec, "local": local, "opt": opt, "want": want, "mode": mode,
+            "PATTERN": PATTERN, "TAU": TAU, "READ_LEN": READ_LEN, "rec_cap": rec_cap, "stream": stream}
+    if not keep:
+        sc.close(); pat.close()
+        del text
+        tb.free()
+        live = None
+    return sec, live
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -712,6 +924,10 @@ def main():
     ap.add_argument("--pattern", default=None, help="non-default patterns are for experiments (config names them)")
     ap.add_argument("--distance", type=int, default=None)
     ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--sections", choices=["auto", "all", "none"], default="auto",
+                    help="the single-GPU sections behind the timed steps (full check against the reference, pinned-host end to end, packed batch, FASTQ shape, "
+                         "multi-pattern, per call, CPU baseline + regions + CLI, configs[4]): auto = all of them on one GPU, none of them under --gpus N > 1 "
+                         "(ranks 1 .. N-1 would only wait for rank 0); all / none force it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-memory end-to-end measurement")
     ap.add_argument("--no-per-call", action="store_true", help="skip the seeqStringMatch per-call measurement")
@@ -719,6 +935,9 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI wall-clock measurement (timed region iii)")
     ap.add_argument("--no-multi", action="store_true", help="skip the sixteen-barcode multi-pattern measurement")
     ap.add_argument("--no-fastq", action="store_true", help="skip the FASTQ-shaped text section (shape Q of SURVEY 8d)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] section of the default run")
+    ap.add_argument("--fastq-records", type=int, default=25_000_000, help="four-line records of the FASTQ section (25 M = 100 M lines, 7.9 GB)")
+    ap.add_argument("--cfg5-reads", type=int, default=100_000_000, help="reads of the configs[4] section (its stated size: 100 M x 250 bp)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl = RCCL) even at world size 1 and run the step's collectives over it "
@@ -727,13 +946,14 @@ def main():
                     help="allocate ONE rank's text, workspace and record buffers, print what it needs of the GPU's memory "
                          "(per rank of --gpus N: every rank holds the same) and exit -- no scan, no launcher")
     ap.add_argument("--placement-candidates", type=int, default=12,
-                    help="hold the text in N device buffers (the plain allocation, then power-of-two blocks: 16 GiB each for the headline text), scan each before the "
-                         "warm-up and run the steps over the one whose scan kernel is fastest: k_pair's launch time follows the physical "
-                         "pages a buffer gets from the driver, 0.77 or 0.92 ms per 3.75 GiB segment (DESIGN.md section 5); every "
-                         "candidate's times are reported in `placement`; 1 = the plain allocation only")
+                    help="candidates the PRODUCT's allocator (seeqdevTextAllocInfo) probes for the resident text: the plain allocation, then power-of-two "
+                         "blocks; the fastest is kept (k_pair's launch time follows the physical pages a buffer gets: DESIGN.md section 5).  The plain "
+                         "first allocation's figure is reported beside `value` as `first_allocation`; 1 = the plain allocation only; capped at 4 per rank "
+                         "under --gpus N > 1")
+    ap.add_argument("--first-steps", type=int, default=20, help="timed steps over the plain first allocation (`first_allocation`)")
     ap.add_argument("--log-clocks", action="store_true", help="sample the GPU's clock / power from sysfs during the timed steps (a thread)")
     ap.add_argument("--check", choices=["full", "sample"], default="full",
-                    help="full (default when oracle/_ref/seeq_ref exists): besides the oracle sample, EVERY line of the run is compared with the "
+                    help="full (default on one GPU when oracle/_ref/seeq_ref exists): besides the oracle sample, EVERY line of the run is compared with the "
                          "reference binary's output, outside the timed region; sample: the oracle sample only")
     ap.add_argument("--check-lines", type=int, default=1_000_000,
                     help="prefix verified against the oracle (plus every 97th 64 Ki-line block and the segment seams); 0 = no check")
@@ -745,12 +965,6 @@ def main():
         return bench_chrom(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.dry_run:
         sys.exit(launch_ranks(args))
-
-    wl = WORKLOADS[args.workload]
-    PATTERN = args.pattern or wl[0]
-    TAU = wl[1] if args.distance is None else args.distance
-    READ_LEN = args.read_len or wl[2]
-    mode, want_name = wl[3], wl[4]
 
     import numpy as np
     import torch
@@ -798,244 +1012,47 @@ def main():
         if int(ones.item()) != args.gpus:
             sys.stderr.write("bench.py: %d ranks joined the all-reduce, expected %d\n" % (int(ones.item()), args.gpus))
             sys.exit(3)
-    red_device = "cpu" if (share and world > 1) else device
-    force_dist = dist_info is not None
+        dist_info = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_joined": int(ones.item())}
+
+    ctx = Ctx()
+    ctx.args, ctx.torch, ctx.np, ctx.dist, ctx.dev, ctx.shard = args, torch, np, dist, dev, shard
+    ctx.world, ctx.rank, ctx.device, ctx.dev_index = world, rank, device, dev_index
+    ctx.red_device = "cpu" if (share and world > 1) else device
+    ctx.force_dist = world == 1 and args.force_dist and not args.dry_run
+    sections = args.sections if args.sections != "auto" else ("all" if world == 1 else "none")
+    extra = sections == "all" and rank == 0 and world == 1      # (the sections run on one GPU: under N ranks the others would only wait)
+    candidates = args.placement_candidates if world == 1 else min(4, args.placement_candidates)
+    check_mode = args.check if (world == 1 or sections == "all") else "sample"
+    t_start = time.perf_counter()
 
     n = args.reads
-    first = rank * n                                           # this rank's read-index range (weak scaling)
-    nbytes = n * (READ_LEN + 1)
-    stream = torch.cuda.current_stream().cuda_stream
-    mem_free0, mem_total = torch.cuda.mem_get_info(dev_index)
-    text = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    if not args.dry_run:
-        dev.synth_reads(text.data_ptr(), first, n, READ_LEN, dev.plain_pattern(PATTERN), TAU, stream=stream)
-    torch.cuda.synchronize()
-
-    opt = {"best": dev.SQ_BEST, "first": 0, "all": dev.SQ_ALL}[mode]
-    want = dev.WANT_RECORDS if want_name == "records" else dev.WANT_COUNTLINES
-    pat = dev.Pattern(PATTERN, TAU)
-    sc = dev.Scanner(stream)
-    seg = int(os.environ.get("SEEQ_SEGMENT_BYTES", str(SEG_BYTES_DEFAULT)))
-    seg_lines = min(n, seg // (READ_LEN + 1) + 2)
-    rec_cap = n // 8 + 1024 if mode != "all" else n // 4 + 1024
-    sc.reserve(nbytes, seg_lines + 64, max(seg_lines // 6 + 1024, 8192 * 64), rec_cap)
-    sc.set_profiling(True)
-    torch.cuda.synchronize()
-    mem_free1, _ = torch.cuda.mem_get_info(dev_index)
-    hbm = {"total_bytes": int(mem_total), "free_before_bytes": int(mem_free0), "text_bytes": int(nbytes),
-           "text_workspace_records_bytes": int(mem_free0 - mem_free1), "free_after_bytes": int(mem_free1),
-           "note": "one rank's allocations (text + scan workspace reserved for its segments + record buffers), measured with "
-                   "hipMemGetInfo around them; every rank of a multi-GPU run holds the same"}
+    sec, live = run_workload(ctx, args.workload, n, args.steps, args.warmup, candidates, args.first_steps if world == 1 else 0,
+                             args.check_lines, check_mode, keep=True)
     if args.dry_run:
-        hbm["ranks"] = args.gpus
-        hbm["fits"] = bool(mem_free1 > (1 << 30))               # a GiB to spare for the packed / multi-pattern sections' own buffers
-        print(json.dumps({"dry_run": True, "workload": wl[5] % n, "hbm_per_rank": hbm}))
+        print(json.dumps(sec))
         return
-
-    placement = None
-    spare = []
-    if args.placement_candidates > 1:
-        cands = [text]
-        keep, alloc_bytes = [], [nbytes]
-        # the extra candidates are cut from power-of-two blocks, 16 GiB and up for the headline text: in profiles/r04/placement_candidates.txt
-        # 28 of 60 such blocks were fast against 1 of 48 plain allocations (the driver's VRAM allocator hands a power-of-two request one
-        # aligned block while it has one); SEEQ_BENCH_CAND_BYTES sets other sizes (experiments); a candidate that does not fit ends the list
-        sizes = [int(x) for x in os.environ.get("SEEQ_BENCH_CAND_BYTES", "").split(",") if x]
-        p2 = 1 << max(20, (nbytes - 1).bit_length())
-        for ci in range(args.placement_candidates - 1):
-            want_bytes = max(nbytes, sizes[ci] if ci < len(sizes) else p2)      # (blocks of 16 GiB for the headline text: fast as often as the 32 and 64 GiB ones, more of them fit)
-            free_now, _ = torch.cuda.mem_get_info(dev_index)
-            if want_bytes + (24 << 30) > free_now:             # (room for the later sections' own buffers)
-                want_bytes = nbytes
-                if want_bytes + (24 << 30) > free_now:
-                    break
-            big = torch.empty(want_bytes, dtype=torch.uint8, device=device)
-            t2 = big[:nbytes]
-            t2.copy_(text)
-            cands.append(t2)
-            keep.append(big)
-            alloc_bytes.append(want_bytes)
-        torch.cuda.synchronize()
-        rows = []
-        for rnd in range(2):                                   # two rounds over the candidates: the second one counts (the first also warms the device up)
-            for i, t2 in enumerate(cands):
-                for _ in range(2):
-                    sc.run(pat, t2.data_ptr(), nbytes, opt, want)
-                    sc.fetch()
-                row = {"forward_ms": round(sc.last_times_ms()["forward"], 4), "launch_ms": [round(x, 4) for x in sc.last_launch_times_ms()]}
-                if rnd == 0:
-                    rows.append({"allocated_bytes": alloc_bytes[i], "device_address": "0x%x" % t2.data_ptr(), "first_round": row})
-                else:
-                    rows[i].update(row)
-        best = min(range(len(cands)), key=lambda i: rows[i]["forward_ms"])
-        text = cands[best]
-        spare = [t2 for i, t2 in enumerate(cands) if i != best] + keep     # (held until the timed steps are over; freeing them first changes nothing: profiles/r04/placement_candidates.txt)
-        placement = {"candidates": rows, "chosen": best,
-                     "note": "the same text in N device buffers, each scanned twice before the warm-up; the steps run over the buffer whose scan kernel "
-                             "was fastest (the launch time follows the physical pages a buffer gets from the driver, DESIGN.md section 5)"}
-
-    def step():
-        sc.run(pat, text.data_ptr(), nbytes, opt, want)
-        cnt = sc.fetch()
-        return shard.reduce_counts(cnt, device=red_device, force=force_dist), cnt
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    clocks = ClockSampler(dev_index) if (rank == 0 and args.log_clocks) else None
-    if clocks:
-        clocks.start()
-    import gc
-    gc.disable()                                               # (no collector pause inside the timed region; enabled again behind it)
-    t0 = time.perf_counter()
-    fwd_ms = 0.0
-    fwd_launches = 0
-    idx_ms = ex_ms = 0.0
-    step_wall, step_fwd, step_post, launch_ms, step_clk = [], [], [], [], []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        total, local = step()
-        step_wall.append(1e3 * (time.perf_counter() - ts))     # (inside the timed region: two clock reads per step)
-        tm = sc.last_times_ms()
-        fwd_ms += tm["forward"]
-        fwd_launches += tm["forward_launches"]
-        idx_ms += tm["index"]
-        ex_ms += tm["exact"]
-        step_fwd.append(tm["forward"]); step_post.append(tm["exact"])
-        launch_ms.extend(sc.last_launch_times_ms())
-        clk = sc.last_clock_mhz()
-        if clk > 0:
-            step_clk.append(clk)
-    if clocks:
-        clocks.stop()
-    if force_dist:      # the all-gather of the global line numbering (seeq.c:377) through the shard layer, over RCCL
-        dist_info["line_base_of_rank0"] = shard.line_base(local["nlines"], device=device, force=True)
+    if ctx.force_dist:      # the all-gather of the global line numbering (seeq.c:377) through the shard layer, over RCCL
+        dist_info["line_base_of_rank0"] = shard.line_base(live["local"]["nlines"], device=device, force=True)
         dist_info["count_reduce_per_step"] = "all_reduce of (lines, matching lines, hits) over RCCL inside every timed step"
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    del spare[:]                                               # (the other placement candidates: the later sections need the room)
-    rank_rows = None
-    if world > 1:
-        # per rank, for the line: its own clock, its read range, what it counted there (the step's value uses the MAX clock)
-        mine = torch.tensor([elapsed, float(first), float(n), float(local["nlines"]), float(local["nmatchlines"]),
-                             fwd_ms / max(1, args.steps), ex_ms / max(1, args.steps)], dtype=torch.float64, device=red_device)
-        rows = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(rows, mine)
-        rank_rows = [{"rank": r, "ms_per_step": 1e3 * float(x[0]) / args.steps, "first_read": int(x[1]), "reads": int(x[2]),
-                      "lines": int(x[3]), "matching_lines": int(x[4]), "forward_scan_ms": float(x[5]),
-                      "compaction_exact_records_ms": float(x[6])} for r, x in enumerate(rows)]
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- parity (rank 0, outside the timed region): prefix + every 97th block + segment seams vs the oracle ----
-    check = None
-    if rank == 0 and args.check_lines > 0:
-        blocks, seams = parity_blocks(n, READ_LEN, seg, args.check_lines)
-        ranges = blocks + seams
-        rec = sc.records(local["nrecords"]) if want == dev.WANT_RECORDS else None
-        sc_chk = dev.Scanner(stream) if rec is None else None
-
-        def scan_block(f0, cnt_):
-            return sc_chk.scan_tensor(pat, text[f0 * (READ_LEN + 1):(f0 + cnt_) * (READ_LEN + 1)], opt, want)
-        tchk = time.perf_counter()
-        lines_checked, nranges = oracle_check(text, ranges, READ_LEN, PATTERN, TAU, opt, rec is not None, rec, scan_block,
-                                              procs=min(32, max(1, (os.cpu_count() or 2) - 1)))
-        if rec is not None:       # size-independent properties of the whole record list
-            assert np.all(np.diff(rec[:, 0].astype(np.int64)) >= (0 if mode == "all" else 1)), "records not ordered by line"
-            assert np.all(rec[:, 1] <= rec[:, 2]) and np.all(rec[:, 2] <= READ_LEN) and np.all(rec[:, 3] <= TAU)
-            assert len(np.unique(rec[:, 0])) == local["nmatchlines"]
-        check = {"oracle_lines_checked": lines_checked, "ranges": nranges, "segment_seams_checked": len(seams),
-                 "seconds": time.perf_counter() - tchk, "result": "bit-exact"}
-        if args.check == "full" and args.workload in ("best", "all", "count", "cfg5"):
-            # the whole buffer against the reference itself (bit-exact match start / end / distance / count)
-            full = reference_full_check(text, n, READ_LEN, PATTERN, TAU, "first" if want != dev.WANT_RECORDS else mode, rec, local["nmatchlines"])
-            if full:
-                check.update(full)
+    t_steps_done = ctx.t_timed_end
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        lines_total = total["nlines"]
-        assert lines_total == n * world, (lines_total, n, world)
-        value = lines_total / (elapsed / args.steps)
-        gbs = value * (READ_LEN + 1) / 1e9
-        # roofline of the dominant kernel (the scan kernel): algorithmic bytes per launch / mean launch time
-        launches_per_step = fwd_launches / args.steps
-        algo_bytes_launch = (n * (READ_LEN + 1) + 16 * local["nrecords"]) / launches_per_step + 8
-        fwd_avg_ms = fwd_ms / max(1, fwd_launches)
-        achieved = algo_bytes_launch / (fwd_avg_ms * 1e-3) / 1e9
-        traffic = None
-        kern = sc.last_kernel()
-        filt = sc.last_filter()
-        pmc = os.path.join(ROOT, "profiles", "pmc_scan_kernels.json")
-        traffic_src = None
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc)).get(kern)
-                # HBM bytes per text byte measured with rocprofv3 PMC passes (profiles/), scaled to this launch size -- only
-                # when the kernel sources are the ones it was measured on (else: null, the figure is not this build's)
-                if pj and pj.get("source_hash") == source_hash():
-                    traffic = pj["hbm_bytes_per_text_byte"] * (n * (READ_LEN + 1) / launches_per_step)
-                    traffic_src = "profiles/pmc_scan_kernels.json (rocprofv3 --pmc passes of this kernel on this build, source hash %s; ratio x this launch's text bytes)" % pj["source_hash"]
-                elif pj:
-                    traffic_src = "none: profiles/pmc_scan_kernels.json was measured on other kernel sources (%s, now %s)" % (pj.get("source_hash"), source_hash())
-            except Exception:
-                traffic = None
-        notes = {
-            "k_stream": "line-agnostic table-driven scan: text read once (coalesced 128 B per lane), one LDS gather and five VALU "
-                        "instructions per walk step, 1.375 steps per text byte; bound by the LDS gather unit (32 banks, 5.65 cycles per "
-                        "64-lane gather, ~85 % busy; VALU issue right behind it, but removing 18 % of it changes nothing), above the "
-                        "HBM stream time: see DESIGN.md",
-            "k_pair": "line-agnostic table walk, TWO text bytes per LDS gather (pair automaton of the pattern's longest prefix that fits / "
-                      "a partition filter; every hit line a candidate, verified by the exact pass): 0.66 gathers per text byte; no longer held "
-                      "by the LDS unit (60 % busy, VALU issue 40-60 %) -- without its bookkeeping it runs at 0.645 ms per launch, 7 % above what a plain read sweep of this layout takes (0.60 ms at 6.2 TB/s); the packed walk shows the LDS unit's own floor (0.57 ms); "
-                      "PMC tables and the phase experiments: profiles/r03*, DESIGN.md section 5",
-            "k_direct": "one-pass per-line scan kernel; issue-bound on the integer VALU pipe (~13 ops per text byte) and "
-                        "on re-reading lines from L2: see DESIGN.md",
-        }
+        text, sc, pat, local, opt, want, mode = live["text"], live["sc"], live["pat"], live["local"], live["opt"], live["want"], live["mode"]
+        PATTERN, TAU, READ_LEN, rec_cap, stream = live["PATTERN"], live["TAU"], live["READ_LEN"], live["rec_cap"], live["stream"]
+        value = sec["value"]
         out = {
             "metric": "lines/s scanned (20 bp pattern, d=3, 150 bp reads; GB/s in gb_per_s)" if args.workload != "cfg5" else
                       "lines/s scanned (40-position class/N pattern, d=5, 250 bp reads, --all; GB/s in gb_per_s)",
-            "value": value, "unit": "lines/s", "gb_per_s": gbs,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int (u16 automaton state ids; exact-pass columns u32 bit-vectors)" if kern in ("k_stream", "k_pair") else "u32 bit-vectors",
-            "data": "synthetic",
-            "dist": dist_info, "hbm_per_rank": hbm,
-            "config": {"workload": wl[5] % n,
-                       "pattern": PATTERN, "distance": TAU, "read_len": READ_LEN, "reads_per_gpu": n,
-                       "parallelism": "line-sharded x%d, RCCL count all-reduce" % world},
-            "results": {"lines": lines_total, "matching_lines": total["nmatchlines"], "hits": total["nhits"],
-                        "oracle_check": check, "oracle_lines_checked": check["oracle_lines_checked"] if check else 0},
-            "device_ms_per_step": {"newline_index": idx_ms / args.steps, "forward_scan": fwd_ms / args.steps,
-                                   "compaction_exact_records": ex_ms / args.steps},
-            # the spread behind the means: per step (host clock around run + fetch; device events of its two parts) and per launch of
-            # the scan kernel (full-size launches only: the last segment of a buffer is shorter)
-            "per_step": {"ms": stats3(step_wall), "ms_all": [round(x, 3) for x in step_wall[:64]], "forward_scan_ms": stats3(step_fwd), "post_pass_ms": stats3(step_post),
-                         "scan_launch_ms_full_segments": stats3([x for i, x in enumerate(launch_ms) if (i + 1) % max(1, int(launches_per_step)) != 0 or launches_per_step == 1]),
-                         "scan_launch_ms_all": [round(x, 4) for x in launch_ms[:64]],
-                         # the scan kernel's own reading of the clock it ran at: shader clock / constant 100 MHz counter around its first wave's work
-                         "scan_kernel_core_clock_mhz": stats3(step_clk),
-                         "gpu_clock_power_during_steps": clocks.summary() if clocks else None},
-            "placement": placement,
-            "roofline": {"bound": "hbm", "kernel": kern + (" (pair automaton: a prefix of the pattern or a partition filter; candidates, verified by the exact pass)" if kern == "k_pair"
-                                          else " (partition filter automaton)" if filt else ""),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launches_per_step": launches_per_step, "avg_launch_ms": fwd_avg_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "whole_step_frac": (n * (READ_LEN + 1) + 16 * local["nrecords"] + 8 * launches_per_step)
-                         / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
-                         "note": notes.get(kern, "see DESIGN.md")},
+            "value": value, "unit": "lines/s", "gb_per_s": sec["gb_per_s"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": sec["dtype"], "data": "synthetic",
+            "config": dict(sec["config"], workload=sec["workload"], parallelism="line-sharded x%d, RCCL count all-reduce" % world),
+            "dist": dist_info, "hbm_per_rank": sec["hbm_per_rank"], "device_ms_per_step": sec["device_ms_per_step"], "per_step": sec["per_step"],
         }
-        if rank_rows is not None:
-            out["ranks"] = rank_rows
-        if world == 1 and not args.no_e2e:
+        if sec["ranks"] is not None:
+            out["ranks"] = sec["ranks"]
+            out["slowest_rank"] = max(sec["ranks"], key=lambda r: r["ms_per_step"])
+        if extra and not args.no_e2e:
             # Timed region (ii) of SURVEY 8d: same path fed from page-locked HOST memory (H2D + scan + D2H of the
             # records), on a 10 M-line sample.  PCIe-bound; reported beside, never as, `value`.
             ne = min(n, 10_000_000)
@@ -1049,17 +1066,18 @@ def main():
                     sc2.records(cnt2["nrecords"])
                 dt = time.perf_counter() - t1
                 best = dt if best is None else min(best, dt)
-            out["end_to_end_pinned_host"] = {"lines": ne, "seconds": best, "lines_per_s": ne / best,
-                                             "gb_per_s": ne * (READ_LEN + 1) / best / 1e9,
+            out["end_to_end_pinned_host"] = {"lines": ne, "seconds": best, "lines_per_s": ne / best, "gb_per_s": ne * (READ_LEN + 1) / best / 1e9,
                                              "note": "H2D over PCIe + scan + D2H records; best of 3"}
-        if world == 1 and not args.no_packed and READ_LEN <= 256:
+            sc2.close()
+            del hostbuf
+        if extra and not args.no_packed and READ_LEN <= 256:
             # The same reads as a PACKED batch (2 bits per base + an N mask: seeq_amd.h seeqdev_packed_t; SURVEY 8d allows a scan-only
             # figure on pre-packed data beside the headline): packed on the device here, scanned from HBM, every count and every record
             # compared with the ASCII run's; then timed region (ii) again with the packed bytes coming from page-locked host memory.
             try:
                 stride, nstride = (READ_LEN + 3) // 4, (READ_LEN + 7) // 8
-                pb = torch.empty(n * stride, dtype=torch.uint8, device=device)      # (the packed walk does not care where its batch lies: 2.08-2.10 ms per step in a
-                pn = torch.empty(n * nstride, dtype=torch.uint8, device=device)     #  plain allocation and inside a power-of-two block alike, three processes each)
+                pb = torch.empty(n * stride, dtype=torch.uint8, device=device)
+                pn = torch.empty(n * nstride, dtype=torch.uint8, device=device)
                 dev.pack_reads_device(text.data_ptr(), n, READ_LEN, pb.data_ptr(), pn.data_ptr(), stream=stream)
                 torch.cuda.synchronize()
                 scp = dev.Scanner(stream)
@@ -1070,7 +1088,7 @@ def main():
                     pc = scp.fetch()
                 torch.cuda.synchronize()
                 tp0 = time.perf_counter()
-                psteps = max(3, args.steps // 2)
+                psteps = max(3, min(50, args.steps // 2))
                 pfwd = 0.0
                 plaunch = 0
                 for _ in range(psteps):
@@ -1090,9 +1108,7 @@ def main():
                                       "scan_kernel_ms_per_launch": pfwd / max(1, plaunch), "scan_kernel_launches_per_step": plaunch / psteps,
                                       "scan_kernel_hbm_frac": (pbytes / (plaunch / psteps)) / (pfwd / max(1, plaunch) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "identical_to_ascii_run": same,
-                                      "walk_table": "quad: four bases (one packed byte) per gather, two-part filter" if scp.last_packed_quad() else "pair: two bases per gather",
-                                      "note": "2 bits per base + 1 bit per base N mask, one read per lane, no warm-up (seeq_packed.h); scan-only figure on "
-                                              "pre-packed data, beside the headline (SURVEY 8d)"}
+                                      "walk_table": "quad (four bases per gather, two-part filter)" if scp.last_packed_quad() else "pair (two bases per gather)"}
                 if not args.no_e2e:
                     ne = min(n, 10_000_000)
                     hb = pb[:ne * stride].cpu().pin_memory()
@@ -1116,20 +1132,12 @@ def main():
                                                             "packed_gb_per_s": ne * (stride + nstride) / best / 1e9,
                                                             "note": "packed bases + N mask from page-locked host memory: H2D + scan + D2H records; best of 3"}
                     sc3.close()
+                    del hb, hn, db, dn
                 scp.close()
                 del pb, pn
             except Exception as e:                      # (reported, not fatal: the ASCII line above is the graded one)
                 out["packed_scan"] = {"error": str(e)}
-        if world == 1 and not args.no_fastq and args.workload in ("best", "count", "all"):
-            # Shape Q (secondary): the first 5 M reads as four-line FASTQ records ("@r<id>", read, "+", 150 Phred+33
-            # bytes that alias onto the alphabet: libseeq.c:265-270), 20 M lines scanned as plain lines under the reference's three
-            # non-DNA modes (-x 0 / 1 / 2), --best with positions; the matching-line count of the WHOLE buffer against the reference
-            # binary's (seeq -c -x <mode>), and the records of a 200 k-line prefix against the oracle.
-            try:
-                out["fastq_shape"] = fastq_shape(text, min(n, 5_000_000), READ_LEN, PATTERN, TAU, pat)
-            except Exception as e:                      # (reported, not fatal)
-                out["fastq_shape"] = {"error": repr(e)}
-        if world == 1 and not args.no_multi and args.workload in ("best", "count", "all"):
+        if extra and not args.no_multi and args.workload in ("best", "count", "all"):
             # Sixteen barcodes over the first 10 M reads of the buffer (row f4b, seeq_multi.h): ONE walk for the set against a scan per
             # pattern (SEEQ_MULTI=sequential) -- the set holds three windows of the planted pattern and thirteen random 10-mers, d = 1;
             # counts and (for the records run) every record of every pattern compared between the two paths.
@@ -1160,55 +1168,95 @@ def main():
                             if m_it:
                                 m_best = m_dt if m_best is None else min(m_best, m_dt)
                         m_res[(m_mode, m_wname)] = (m_best, scm.last_multi_one_pass(), [g["nmatchlines"] for g in m_got],
-                                              [g["records"].copy() for g in m_got] if w_ == dev.WANT_RECORDS else None)
+                                                    [g["records"].copy() for g in m_got] if w_ == dev.WANT_RECORDS else None)
                 os.environ.pop("SEEQ_MULTI", None)
                 m_sec = {"patterns": 16, "pattern_len": 10, "distance": 1, "lines": m_nm}
                 for m_wname in ("count_lines", "best_records"):
                     a_, b_ = m_res[("one_walk", m_wname)], m_res[("per_pattern", m_wname)]
                     m_same = a_[2] == b_[2] and (a_[3] is None or all(np.array_equal(x, y) for x, y in zip(a_[3], b_[3])))
                     m_sec[m_wname] = {"one_walk_ms": a_[0] * 1e3, "per_pattern_ms": b_[0] * 1e3, "speedup": b_[0] / a_[0], "one_walk_ran": bool(a_[1]),
-                                  "matching_line_pattern_pairs": int(sum(a_[2])), "identical_results": bool(m_same)}
-                m_sec["note"] = ("seeqdevScanRunMulti on resident text: one k_pair walk over the union automaton of the set + pattern sets per candidate line + "
-                               "the exact pass over (line, pattern) pairs, against sixteen scans of the same text; records land in page-locked host memory "
-                               "in both cases (DESIGN.md section 8, profiles/multi_bench.py for planted barcode sets)")
+                                      "matching_line_pattern_pairs": int(sum(a_[2])), "identical_results": bool(m_same)}
                 out["multi_pattern"] = m_sec
                 scm.close()
                 for p_ in mp:
                     p_.close()
             except Exception as e:
                 out["multi_pattern"] = {"error": str(e)}
-        if world == 1 and not args.no_per_call:
+        if extra and not args.no_per_call:
             out["per_call"] = per_call_rates(PATTERN, TAU, READ_LEN)
-        if not args.no_cpu_baseline and world == 1:
+        fq = None
+        if extra and not args.no_fastq and args.workload in ("best", "count", "all"):
+            # Shape Q (the north star's "FASTQ-shaped reads"): the first 25 M reads as four-line FASTQ records ("@r<id>", read, "+", 150
+            # Phred+33 bytes that alias onto the alphabet and onto the newline column: libseeq.c:265-270) = 100 M lines, 7.9 GB, several
+            # scan-kernel launches, scanned as plain lines under the reference's three non-DNA modes (-x 0 / 1 / 2), --best with positions; the
+            # matching-line count of the WHOLE buffer against the reference binary's (seeq -c -x <mode>), the records of a 200 k-line prefix
+            # against the oracle.
+            try:
+                fq = fastq_shape(text, min(n, args.fastq_records), READ_LEN, PATTERN, TAU, pat)
+            except Exception as e:                      # (reported, not fatal)
+                fq = {"error": repr(e)}
+        regions = None
+        if extra and not args.no_cpu_baseline:
             sample = args.cpu_sample if args.workload != "cfg5" else max(200_000, args.cpu_sample // 4)
             out["cpu_baseline"] = cpu_baseline(sample, PATTERN, TAU, READ_LEN, mode)
             cpu = out["cpu_baseline"]["value"]
             out["gpu_over_cpu"] = value / cpu
-            # the three timed regions, each against the P-core CPU aggregate (region iii: one reference process,
-            # what a user of the CLI runs), and whether the north star's 10x holds for it
+            # the three timed regions, each against the P-core CPU aggregate (region iii: one reference process, what a user of
+            # the CLI runs) and against the whole-socket estimate, and whether the north star's 10x holds for it (README: where 10x holds)
             est = out["cpu_baseline"].get("whole_socket_estimate_lines_per_s") or cpu
-            regions = {"device_resident": {"lines_per_s": value, "gpu_over_cpu": value / cpu, "meets_10x": value / cpu >= 10.0,
-                                           "over_whole_socket_estimate": value / est}}
+
+            def region(lps, **kw):
+                return dict({"lines_per_s": lps, "gpu_over_cpu": lps / cpu, "over_whole_socket_estimate": lps / est, "meets_10x": lps / cpu >= 10.0,
+                             "meets_10x_whole_socket_estimate": lps / est >= 10.0}, **kw)
+            regions = {"cpu": {"measured_processes": out["cpu_baseline"]["cores"], "measured_lines_per_s": cpu, "whole_socket_estimate_lines_per_s": est},
+                       "device_resident": region(value)}
             if "end_to_end_pinned_host_packed" in out:
-                e = out["end_to_end_pinned_host_packed"]["lines_per_s"]
-                regions["end_to_end_pinned_host_packed"] = {"lines_per_s": e, "gpu_over_cpu": e / cpu, "meets_10x": e / cpu >= 10.0, "over_whole_socket_estimate": e / est,
-                                                            "note": "region (ii) with the reads handed over packed (57 instead of 151 bytes per read over the link)"}
+                regions["end_to_end_pinned_host_packed"] = region(out["end_to_end_pinned_host_packed"]["lines_per_s"], bytes_per_read_over_the_link=57)
             if "end_to_end_pinned_host" in out:
-                e = out["end_to_end_pinned_host"]["lines_per_s"]
-                regions["end_to_end_pinned_host"] = {"lines_per_s": e, "gpu_over_cpu": e / cpu, "meets_10x": e / cpu >= 10.0, "over_whole_socket_estimate": e / est,
-                                                     "note": "one PCIe link: ASCII text at ~55 GB/s caps this region near 0.37 G lines/s"}
+                e2e = out["end_to_end_pinned_host"]
+                regions["end_to_end_pinned_host"] = region(e2e["lines_per_s"], bytes_per_read_over_the_link=READ_LEN + 1,
+                                                           link_gb_per_s=e2e["gb_per_s"], note="one PCIe link per GPU: ASCII text at ~55 GB/s caps this region near 0.37 G lines/s; SEEQ_DEVICES spreads a file's chunks over several GPUs (links)")
             if not args.no_cli and args.workload in ("best", "count", "all"):
                 cw = cli_wall_clock(PATTERN, TAU, READ_LEN)
                 out["cli_wall_clock"] = cw
                 if cw.get("gpu_lines_per_s"):
                     r1 = cw["gpu_lines_per_s"] / cw["reference_lines_per_s_one_core"] if cw.get("reference_lines_per_s_one_core") else None
-                    regions["cli_wall_clock"] = {"lines_per_s": cw["gpu_lines_per_s"], "gpu_over_cpu": cw["gpu_lines_per_s"] / cpu,
-                                                 "meets_10x": cw["gpu_lines_per_s"] / cpu >= 10.0, "over_whole_socket_estimate": cw["gpu_lines_per_s"] / est,
-                                                 "over_one_reference_process": r1,
-                                                 "note": "includes process start and HIP start-up (0.25-0.35 s of it)"}
+                    regions["cli_wall_clock"] = region(cw["gpu_lines_per_s"], over_one_reference_process=r1,
+                                                       note="10 M-line file, page-cache warm; includes process start and HIP start-up (0.25-0.35 s of it)")
+        # ---- BASELINE configs[4] at its stated size, as a section of the default line (the headline's buffers are released first) ----
+        cfg5 = None
+        if extra and not args.no_cfg5 and args.workload == "best":
+            sc.close(); pat.close()
+            del text
+            live["tb"].free()
+            live = None
+            torch.cuda.empty_cache()
+            try:
+                c5, _ = run_workload(ctx, "cfg5", args.cfg5_reads, 3, 2, min(4, candidates), 0, args.check_lines, check_mode, keep=False)
+                cfg5 = {k: c5[k] for k in ("workload", "value", "gb_per_s", "ms_per_step", "steps", "device_ms_per_step", "placement", "results", "roofline")}
+                cfg5["whole_step_frac"] = c5["roofline"]["whole_step_frac"]
+            except Exception as e:                      # (reported, not fatal: the headline above is the graded line)
+                cfg5 = {"error": repr(e)}
+        # ---- the tail of the line: what the driver's record keeps (its last 8 KB) ----
+        if fq is not None:
+            out["fastq_shape"] = fq
+        if regions is not None:
             out["regions"] = regions
+        if cfg5 is not None:
+            out["cfg5"] = cfg5
+        out["seconds"] = {"to_end_of_timed_steps": round(t_steps_done - t_start, 1), "sections_after": round(time.perf_counter() - t_steps_done, 1)}
+        out["placement"] = sec["placement"]
+        out["first_allocation"] = sec["first_allocation"]
+        out["results"] = sec["results"]
+        out["roofline"] = sec["roofline"]
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
+        # every rank waits here for rank 0's line, says so, and leaves together
+        dist.barrier()
+        sys.stderr.write("bench.py: rank %d of %d done %.1f s after its timed steps; leaving the process group\n" % (rank, world, time.perf_counter() - t_steps_done))
+        dist.destroy_process_group()
+    elif dist_info is not None and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -145,6 +145,17 @@ void   seeqdevHostFree(void * p);
  * Contents undefined.
  * NULL + errno on failure.  (The reference has no device memory: an addition of this boundary, like seeqdevHostAlloc.) */
 void * seeqdevTextAlloc(size_t bytes, int candidates, float * probe_ms, int * nprobed);
+/* The same, telling the caller what it got: the block returned may be LARGER than `bytes` (a power-of-two block: up to 2 x bytes stay
+ * allocated until seeqdevTextFree), and while the candidates are probed up to candidates x 2 x bytes + the probing scan's workspace
+ * (about half a segment's bytes + 256 MiB) are held on the device -- probe_peak_bytes; other allocations of the caller may fail meanwhile. */
+typedef struct seeqdev_textinfo {
+   float  probe_ms[12];        /* the candidates' scan-kernel times (nprobed of them; candidate 0 = the plain allocation) */
+   int    nprobed;             /* 0: nothing was probed (one candidate, a small buffer, or the probe failed: the plain allocation) */
+   int    chosen;              /* index of the candidate returned */
+   size_t allocated_bytes;     /* size of the allocation behind the returned pointer (>= bytes) */
+   size_t probe_peak_bytes;    /* device memory held at the peak of the call */
+} seeqdev_textinfo_t;
+void * seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_textinfo_t * info);
 void   seeqdevTextFree(void * d_text);
 
 /* Convenience: host buffer in, counts (+ records) out.  Stages through the

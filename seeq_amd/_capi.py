@@ -53,6 +53,11 @@ class seeqdev_counts_t(C.Structure):
                 ("nrecords", C.c_uint64), ("nheaders", C.c_uint64)]
 
 
+class seeqdev_textinfo_t(C.Structure):
+    _fields_ = [("probe_ms", C.c_float * 12), ("nprobed", C.c_int), ("chosen", C.c_int), ("allocated_bytes", C.c_size_t),
+                ("probe_peak_bytes", C.c_size_t)]
+
+
 # Every symbol the three public headers declare (tests check the .so exports all of them).
 EXPORTS = [
     # libseeq.h
@@ -65,7 +70,7 @@ EXPORTS = [
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevScanLastLaunchTimes", "seeqdevScanLastClockMHz", "seeqdevSynthReads",
-    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanLastPackedQuad", "seeqdevScanCopyOffsets", "seeqdevHostAlloc", "seeqdevTextAlloc", "seeqdevTextFree",
+    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanLastPackedQuad", "seeqdevScanCopyOffsets", "seeqdevHostAlloc", "seeqdevTextAlloc", "seeqdevTextAllocInfo", "seeqdevTextFree",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
     "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanLastMulti", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
 ]
@@ -201,6 +206,8 @@ def lib():
     L.seeqdevHostFree.restype = None
     L.seeqdevTextAlloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.seeqdevTextAlloc.restype = C.c_void_p
+    L.seeqdevTextAllocInfo.argtypes = [C.c_size_t, C.c_int, C.POINTER(seeqdev_textinfo_t)]
+    L.seeqdevTextAllocInfo.restype = C.c_void_p
     L.seeqdevTextFree.argtypes = [C.c_void_p]
     L.seeqdevTextFree.restype = None
     L.seeqdevSynthReads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int,

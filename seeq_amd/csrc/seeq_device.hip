@@ -2253,27 +2253,36 @@ extern "C" void seeqdevHostFree(void *p)
  * candidate allocations (the plain one, then blocks of p bytes, p = the power of two >= bytes), each filled with synthetic reads and
  * scanned twice with the benchmark pattern; the one whose scan kernel was fastest is returned, the
  * others are freed.  probe_ms (may be NULL): the candidates' scan-kernel times, *nprobed of them.  The buffer's contents are undefined. */
-extern "C" void *seeqdevTextAlloc(size_t bytes, int candidates, float *probe_ms, int *nprobed)
+extern "C" void *seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_textinfo_t *info)
 {
    seeqerr = 0;
-   if (nprobed) *nprobed = 0;
+   if (info) memset(info, 0, sizeof *info);
    if (bytes == 0) bytes = 1;
    void *blk[12] = {nullptr};
-   float ms[12];
+   size_t blk_bytes[12] = {0};
+   float ms[12] = {0};
    int n = 0;
    if (candidates > 12) candidates = 12;
    if (candidates < 2 || bytes < ((size_t)64 << 20)) candidates = 1;      /* (nothing to tell apart on a scan of microseconds) */
    size_t p2 = 1;
    while (p2 < bytes) p2 <<= 1;
+   /* what the probing scan context allocates beside the candidates (reserve_impl for one segment of `bytes`: per-line, per-hit-line, per-tile arrays
+      and the records: about 0.46 bytes per text byte of a segment), kept free while the candidates are taken */
+   seeqdev_scan_t *sc = nullptr;
+   const size_t seg = bytes < (size_t)0xF0000000u ? bytes : (size_t)0xF0000000u;
+   const size_t headroom = seg / 2 + ((size_t)256 << 20);
+   size_t peak = 0;
    for (int i = 0; i < candidates; i++) {
       size_t want = bytes;
       if (i > 0) {
          want = p2;
          size_t freeb = 0, total = 0;
          if (hipMemGetInfo(&freeb, &total) != hipSuccess) break;
-         if (want + bytes + ((size_t)2 << 30) > freeb) { want = bytes; if (want + bytes + ((size_t)2 << 30) > freeb) break; }   /* (room for the scan's workspace) */
+         if (want + headroom > freeb) { want = bytes; if (want + headroom > freeb) break; }
       }
       if (hipMalloc(&blk[n], want) != hipSuccess) { (void)hipGetLastError(); blk[n] = nullptr; break; }
+      blk_bytes[n] = want;
+      peak += want;
       n++;
    }
    if (n == 0) { hip_fail(hipErrorOutOfMemory, "seeqdevTextAlloc", ENOMEM); return NULL; }
@@ -2283,7 +2292,7 @@ extern "C" void *seeqdevTextAlloc(size_t bytes, int candidates, float *probe_ms,
       char keys[20];
       for (int i = 0; i < 20; i++) keys[i] = plain[i] == 'A' ? 1 : plain[i] == 'C' ? 2 : plain[i] == 'G' ? 4 : 8;
       seeqdev_pattern_t *pat = seeqdevPatternNew(keys, 20, 3);
-      seeqdev_scan_t *sc = pat ? seeqdevScanNew(NULL) : NULL;
+      sc = pat ? seeqdevScanNew(NULL) : NULL;
       const uint64_t nreads = bytes / 151;
       bool ok = pat && sc && nreads > 0 && seeqdevScanSetProfiling(sc, 1) == 0;
       for (int i = 0; ok && i < n; i++) {
@@ -2300,13 +2309,22 @@ extern "C" void *seeqdevTextAlloc(size_t bytes, int candidates, float *probe_ms,
       if (pat) seeqdevPatternFree(pat);
       if (ok) {
          for (int i = 1; i < n; i++) if (ms[i] < ms[best]) best = i;
-         if (probe_ms) for (int i = 0; i < n; i++) probe_ms[i] = ms[i];
-         if (nprobed) *nprobed = n;
-      }                                                     /* (a failed probe: the plain allocation) */
+         if (info) { for (int i = 0; i < n; i++) info->probe_ms[i] = ms[i]; info->nprobed = n; }
+      }                                                     /* (a failed probe: the plain allocation, nprobed = 0) */
       for (int i = 0; i < n; i++) if (i != best) (void)hipFree(blk[i]);
       seeqerr = 0;
    }
+   if (info) { info->chosen = best; info->allocated_bytes = blk_bytes[best]; info->probe_peak_bytes = n > 1 ? peak + headroom : peak; }
    return blk[best];
+}
+
+extern "C" void *seeqdevTextAlloc(size_t bytes, int candidates, float *probe_ms, int *nprobed)
+{
+   seeqdev_textinfo_t info;
+   void *p = seeqdevTextAllocInfo(bytes, candidates, &info);
+   if (nprobed) *nprobed = p ? info.nprobed : 0;
+   if (p && probe_ms) for (int i = 0; i < info.nprobed; i++) probe_ms[i] = info.probe_ms[i];
+   return p;
 }
 
 extern "C" void seeqdevTextFree(void *d_text)

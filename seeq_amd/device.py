@@ -37,18 +37,31 @@ def pack_reads(text, read_len, with_nmask=True):
 
 
 class TextBuffer:
-    """Device memory for resident text chosen by measurement (seeqdevTextAlloc): the scan kernel's speed follows the physical pages a
+    """Device memory for resident text chosen by measurement (seeqdevTextAllocInfo): the scan kernel's speed follows the physical pages a
     buffer gets, so up to `candidates` allocations are probed and the fastest kept.  `ptr` is the device address, `probe_ms` the candidates'
-    scan-kernel times (empty when nothing was probed).  Contents undefined; free() or the garbage collector releases it."""
+    scan-kernel times (empty when nothing was probed; candidate 0 is the plain allocation), `chosen` the index of the one kept,
+    `allocated_bytes` the size of the allocation behind it (a power-of-two block may be up to twice `nbytes`), `probe_peak_bytes` what the
+    call held on the device at its peak.  Contents undefined; free() or the garbage collector releases it.  `tensor()`: a torch uint8
+    view of the first `nbytes` bytes (plumbing for callers that slice / copy with torch; the buffer must outlive the view)."""
 
     def __init__(self, nbytes, candidates=12):
-        ms = (C.c_float * 12)()
-        n = C.c_int(0)
-        p = _capi.lib().seeqdevTextAlloc(int(nbytes), int(candidates), ms, C.byref(n))
+        info = _capi.seeqdev_textinfo_t()
+        p = _capi.lib().seeqdevTextAllocInfo(int(nbytes), int(candidates), C.byref(info))
         if not p:
             raise SeeqDeviceError(_capi.error_text())
         self.ptr, self.nbytes = int(p), int(nbytes)
-        self.probe_ms = [float(ms[i]) for i in range(n.value)]
+        self.probe_ms = [float(info.probe_ms[i]) for i in range(info.nprobed)]
+        self.chosen = int(info.chosen)
+        self.allocated_bytes = int(info.allocated_bytes)
+        self.probe_peak_bytes = int(info.probe_peak_bytes)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def tensor(self, device=None):
+        import torch
+        return torch.as_tensor(self, device=device if device is not None else "cuda")
 
     def free(self):
         if self.ptr:

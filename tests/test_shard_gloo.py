@@ -191,6 +191,41 @@ def test_bench_launches_its_own_ranks(gpu):
     assert sum(r["matching_lines"] for r in rows) == line["results"]["matching_lines"]
     assert rows[0]["matching_lines"] != rows[1]["matching_lines"] or rows[0]["matching_lines"] > 0     # (different reads: the generator is indexed by the read number)
     assert line["ms_per_step"] >= max(r["ms_per_step"] for r in rows) * 0.999                          # the step is the slowest rank's
+    # under N ranks rank 0 runs none of the single-GPU sections: the run ends soon after the timed steps, every rank says when it leaves
+    assert line["seconds"]["sections_after"] < 60 and "cfg5" not in line and "fastq_shape" not in line and "packed_scan" not in line
+    assert line["slowest_rank"]["rank"] in (0, 1) and "placement_chosen" in line["slowest_rank"]
+    assert r.stderr.count("leaving the process group") == 2
+    assert list(line)[-2:] == ["results", "roofline"]
+
+
+@pytest.mark.gpu
+def test_bench_default_line_sections_at_small_sizes(gpu):
+    """The sections of the default `bench.py` line, shrunk: the headline (text from seeqdevTextAllocInfo, `first_allocation` beside it), the
+    FASTQ shape (k_pair under SQ_FAIL / SQ_CONVERT since round 5, counts = the reference binary's, prefix records = the oracle's) and
+    BASELINE configs[4] as a section with its own roofline and full check; `results` and `roofline` close the line."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "1500000", "--steps", "3", "--warmup", "1", "--first-steps", "2",
+                        "--placement-candidates", "3", "--fastq-records", "400000", "--cfg5-reads", "700000", "--cpu-sample", "200000",
+                        "--no-e2e", "--no-per-call", "--no-packed", "--no-multi", "--no-cli", "--check-lines", "200000"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert list(line)[-4:] == ["placement", "first_allocation", "results", "roofline"]
+    assert line["results"]["lines"] == 1500000 and line["results"]["oracle_check"]["result"] == "bit-exact"
+    assert line["placement"]["probed"] == 3 and line["first_allocation"]["steps"] == 2
+    fq = line["fastq_shape"]
+    assert fq["lines"] == 1600000 and all(fq["modes"][m]["oracle_prefix_records_identical"] for m in ("fail", "convert", "ignore")), fq
+    assert fq["modes"]["fail"]["kernel"] == "k_pair" and fq["modes"]["convert"]["kernel"] == "k_pair", fq
+    c5 = line["cfg5"]
+    assert c5["results"]["lines"] == 700000 and c5["results"]["oracle_check"]["result"] == "bit-exact" and 0 < c5["whole_step_frac"] < 1, c5
+    assert "device_resident" in line["regions"] and line["cpu_baseline"]["value"] > 0
+    from oracle.pyoracle import REF_BIN
+    if os.path.exists(REF_BIN):
+        assert c5["results"]["oracle_check"]["reference_lines_checked"] == 700000
+        assert all(fq["modes"][m]["identical_to_reference_count"] for m in ("fail", "convert", "ignore")), fq
 
 
 @pytest.mark.gpu
@@ -211,7 +246,7 @@ def test_bench_rccl_process_group_over_one_rank(gpu):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--reads", "2000000",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-per-call", "--no-packed", "--no-cli",
-                        "--no-multi", "--check-lines", "100000"], capture_output=True, text=True, env=env, timeout=900)
+                        "--no-multi", "--no-cfg5", "--no-fastq", "--check-lines", "100000"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     d = line["dist"]
@@ -248,7 +283,7 @@ def test_two_real_segments_full_size_parity(gpu, workload, reads):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--reads", str(reads), "--steps", "1",
-                        "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-per-call"],
+                        "--warmup", "0", "--first-steps", "2", "--no-cpu-baseline", "--no-e2e", "--no-per-call", "--no-cfg5", "--no-fastq", "--no-multi", "--no-packed"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -256,10 +291,14 @@ def test_two_real_segments_full_size_parity(gpu, workload, reads):
     assert line["results"]["lines"] == reads and chk["result"] == "bit-exact"
     assert chk["oracle_lines_checked"] >= 1_000_000 and chk["segment_seams_checked"] >= 1
     assert line["roofline"]["launches_per_step"] >= 2
-    # the text was held in several candidate buffers and the steps ran over the one whose scan kernel was fastest
+    # the text lies in a buffer from the PRODUCT's allocator (seeqdevTextAllocInfo: several candidates probed, the fastest kept, DESIGN.md
+    # section 5), and the same text in a plain first allocation was timed beside it
     pl = line["placement"]
-    assert len(pl["candidates"]) >= 2 and all(len(c["launch_ms"]) == line["roofline"]["launches_per_step"] for c in pl["candidates"])
-    assert pl["candidates"][pl["chosen"]]["forward_ms"] == min(c["forward_ms"] for c in pl["candidates"])
+    assert pl["api"] == "seeqdevTextAllocInfo" and pl["probed"] >= 2 and pl["selected"] and pl["allocated_bytes"] >= reads * (151 if workload == "best" else 251)
+    assert pl["probe_forward_ms"][pl["chosen"]] == min(pl["probe_forward_ms"])
+    fa = line["first_allocation"]
+    assert fa["steps"] == 2 and fa["value"] > 0 and fa["scan_launch_ms"] > 0
+    assert list(line)[-2:] == ["results", "roofline"]                            # the driver's record keeps the END of the line
     # ... and EVERY line against the reference binary itself (bench.py --check full, the default when oracle/_ref travelled)
     from oracle.pyoracle import REF_BIN
     if os.path.exists(REF_BIN):
