@@ -1587,6 +1587,9 @@ static int run_segments(seeqdev_scan *s)
             a.nz_sum = superset && nh_is_count ? s->nh_sum + (s->cap_hitlines / 256 + 2) : nullptr;
             /* k_nh_top ends the segment unless k_exact1's EMIT pass follows (SQ_ALL records): k_emit1 works from what k_nh_top saved */
             a.fin = (want == SEEQDEV_WANT_RECORDS && var == VERIFY_ALL) ? 0u : 1u + (uint32_t)seg_flags;
+            /* behind a partition filter every part of an occurrence reports: more than half of the entries are repeats of their line, and
+               k_verify packs them away, 512 entries per workgroup (seeq_verify.h); behind a prefix automaton it does not pay */
+            a.vrange = (use_pair ? pat->pair_parts > 1 : pat->sdfa_parts > 1) ? 512u : 0u;
             seeq_launch_verify(fw, var, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
             if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
             else if (want == SEEQDEV_WANT_RECORDS && ecache && !s->knobs.old_emit_all)      /* SQ_ALL: the first records from the cache, the others from the overflow lists */

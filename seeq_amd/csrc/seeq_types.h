@@ -82,6 +82,7 @@ struct ScanArgs {
                                    (line - 1) * rec_pitch, the offset the same read has in the ASCII form of the batch (0: the line's real offset) */
    uint32_t       *nz_sum;      /* k_verify: per chunk the entries with >= 1 hit (NULL: not wanted) */
    uint32_t        fin;         /* != 0: k_nh_top ends the segment (seg_end_body with flags fin - 1); 0: k_seg_end does, behind the EMIT pass */
+   uint32_t        vrange;      /* k_verify: entries per workgroup range, 256 .. 1024 (0: 256): the repeats of a range are packed away before the walk */
    Counters      *cnt;
 };
 

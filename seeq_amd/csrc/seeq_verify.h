@@ -263,15 +263,54 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
    /* overflow lists (VERIFY_ALL with records): k_exact1's layout -- the free entries above the per-line ones, one list per wave of the grid */
    const uint32_t ovf_r = (a.cap_hitlines > nhl ? a.cap_hitlines - nhl : 0u) / (gridDim.x * 4u);
    const uint32_t wave_id = threadIdx.x >> 6;
-   uint4 *ovf = cache ? cache + nhl + (size_t)(blockIdx.x * 4u + wave_id) * ovf_r : nullptr;
-   const uint32_t stride = gridDim.x * 256u;
-   const uint32_t kmax = (nhl + stride - 1u) / stride * stride;
-   for (uint32_t k0 = blockIdx.x * 256u; k0 < kmax; k0 += stride) {
-      const uint32_t k = k0 + threadIdx.x;
-      bool done = k >= nhl;
+   uint4 *const ovf_all = cache ? cache + nhl : nullptr;
+   /* Round 5: the hit list holds REPEATS (an entry per candidate; a line's second and later candidates only stretch its window:
+      hit_start = 0xFFFFFFFF) -- a quarter of the entries behind the headline pattern's prefix automaton, more than half behind a
+      three-part filter (configs[4]: every part of an occurrence reports) -- and a lane that draws one idles while its wave walks.  So a
+      workgroup takes a RANGE of 512 consecutive entries (ScanArgs.vrange), packs the indices of those that are not repeats into LDS (one
+      block scan per 256) and walks them 256 at a time: full waves but for the range's last round.  The counts go back to the entries' own
+      places (s_cnt), the per-chunk scan of nh[] / nh_sum[] is what it was.  Measured (profiles/r05/ab_verify_range.txt): configs[4]'s post-pass
+      2.95 -> 2.17 ms per step with ranges of 512 or 1 024 (2.52 with 256); behind the headline's prefix automaton, where a quarter of the
+      entries are repeats, the packing costs more than the idle lanes (0.715 -> 0.75 / 0.77 / 0.81 ms with 256 / 512 / 1 024: an extra block
+      scan per chunk, fewer and longer workgroups) -- so the host asks for it behind partition filters only (vrange = 0: as before). */
+   __shared__ uint16_t s_idx[1024];
+   __shared__ uint32_t s_cnt[1024];
+   const bool compact = a.vrange != 0u;                    /* (kernel-uniform; 0: the list holds few repeats -- the packing costs more than the idle lanes) */
+   const uint32_t range = (a.vrange == 512u || a.vrange == 1024u) && nhl >= 65536u ? a.vrange : 256u;
+   const uint32_t nranges = (nhl + range - 1u) / range;
+   /* the overflow lists are one per wave of the GRID (k_emit_all walks them all); with fewer ranges than workgroups the workgroups beyond the
+      ranges have nothing to do, and workgroup b fills -- one after the other -- the lists of workgroups b, b + nr, b + 2 nr ... as well */
+   /* (recomputed where they are used -- an emission beyond a line's first is rare --: kept live across the walk they cost registers it does not have) */
+#define VERIFY_NR        ((nranges == 0u || nranges > gridDim.x) ? gridDim.x : nranges)
+#define VERIFY_MY_LISTS  (blockIdx.x < VERIFY_NR ? (gridDim.x - blockIdx.x + VERIFY_NR - 1u) / VERIFY_NR : 0u)
+#define VERIFY_LIST_ROOM (ovf_r > 1u ? ovf_r - 1u : 0u)                         /* entries of a list (entry 0 is its count) */
+   for (uint32_t rg = blockIdx.x; rg < nranges; rg += gridDim.x) {
+    const uint32_t r0 = rg * range;
+    uint32_t nact = 0;                                      /* block-uniform */
+    if (!compact) {                                         /* every entry of the (256-entry) range in its own lane, repeats included */
+       s_cnt[threadIdx.x] = 0u;
+       nact = nhl - r0 < 256u ? nhl - r0 : 256u;
+    }
+    else for (uint32_t u = 0; u < range; u += 256u) {
+       const uint32_t k = r0 + u + threadIdx.x;
+       const bool live = k < nhl;
+       const uint32_t kk = (a.hit_idx && live) ? a.hit_idx[k] : k;
+       const bool act = live && a.hit_start[kk] != 0xFFFFFFFFu;      /* (a repeat of the previous entry's line: no work) */
+       s_cnt[u + threadIdx.x] = 0u;
+       uint32_t tot;
+       const uint32_t ex = block_excl_scan(act ? 1u : 0u, &tot, s_wave);
+       if (act) s_idx[nact + ex] = (uint16_t)(u + threadIdx.x);
+       if (live && !act && caching) cache[k] = make_uint4(0u, 0u, 0u, 0u);
+       nact += tot;
+    }
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < nact; j0 += 256u) {
+      bool done = j0 + threadIdx.x >= nact;
+      const uint32_t k = r0 + (done ? 0u : compact ? (uint32_t)s_idx[j0 + threadIdx.x] : threadIdx.x);
+#define VERIFY_MINE (j0 + threadIdx.x < nact)                /* (recomputed where it is needed: one register less across the walk) */
       const uint32_t kk = (a.hit_idx && !done) ? a.hit_idx[k] : k;
       const uint32_t hs = done ? 0u : a.hit_start[kk];
-      if (hs == 0xFFFFFFFFu) done = true;                  /* repeat of the previous entry's line */
+      if (hs == 0xFFFFFFFFu) done = true;                  /* repeat of the previous entry's line (not packed away) */
       const uint64_t off = done ? a.seg_base : a.seg_base + hs;
       if (a.use_nh == 3 && (a.options & SEEQDEV_FASTA) && !done && a.text[off] == '>') done = true;
       uint32_t pos = 0, stop_at = 0xFFFFFFFFu;
@@ -296,8 +335,12 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
       r.prevL = 0; r.latch = 0; r.nhits = 0; r.best_d = tau1; r.best_end = 0; r.ce0 = 0; r.ce1 = 0; r.done = false;
       auto second = [&](uint32_t p, uint32_t streak) {      /* second and later emissions of a line: to my wave's overflow list */
          if (VAR == VERIFY_ALL && caching) {
-            const uint32_t idx = atomicAdd(&s_novf[wave_id], 1u) + 1u;
-            if (idx < ovf_r) ovf[idx] = make_uint4(k, r.nhits, p, streak);
+            const uint32_t idx = atomicAdd(&s_novf[wave_id], 1u);
+            const uint32_t list_room = VERIFY_LIST_ROOM;
+            if (idx < VERIFY_MY_LISTS * list_room) {
+               const uint32_t t = idx / list_room;
+               ovf_all[(size_t)((blockIdx.x + t * VERIFY_NR) * 4u + wave_id) * ovf_r + 1u + (idx - t * list_room)] = make_uint4(k, r.nhits, p, streak);
+            }
          }
       };
       while (__any(!done)) {
@@ -350,31 +393,51 @@ __device__ __forceinline__ void verify_body(const ScanArgs &a, const uint32_t *e
          second and later records of a line from the overflow lists) */
       uint32_t ce2 = 0, ce3 = 0;
       if (caching) {
-         const bool need = k < nhl && nhits != 0u;
+         const bool need = VERIFY_MINE && nhits != 0u;
          if (__any(need)) {
             const uint32_t s0 = verify_reverse<W>(a, need, off, ce0, ce1, eqr_base, sh, m, tau1);
             if (need) { ce2 = s0; ce3 = 1u; }
          }
       }
-      if (caching && k < nhl) cache[k] = make_uint4(ce0, ce1, ce2, ce3);
-      /* offsets inside this chunk of 256 entries, the chunk's sum */
+      if (caching && VERIFY_MINE) cache[k] = make_uint4(ce0, ce1, ce2, ce3);
+      if (VERIFY_MINE) s_cnt[k - r0] = nhits;
+#undef VERIFY_MINE
+    }
+    __syncthreads();
+    /* offsets inside every chunk of 256 entries, the chunks' sums */
+    for (uint32_t u = 0; u < range && r0 + u < nhl; u += 256u) {
+      const uint32_t k0 = r0 + u, k = k0 + threadIdx.x;
+      const uint32_t nhits = s_cnt[u + threadIdx.x];
       uint32_t tot;
       const uint32_t ex = block_excl_scan(nhits, &tot, s_wave);
       if (k < nhl) a.nh[k] = ex;
-      if (threadIdx.x == 0 && k0 < nhl) a.nh_sum[k0 >> 8] = tot;
+      if (threadIdx.x == 0) a.nh_sum[k0 >> 8] = tot;
       if (a.nz_sum) {                                       /* entries with >= 1 hit (kernel-uniform branch) */
          const uint32_t nzw = (uint32_t)__popcll(__ballot(nhits != 0u));
          if ((threadIdx.x & 63u) == 0) s_wave[wave_id] = nzw;
          __syncthreads();
-         if (threadIdx.x == 0 && k0 < nhl) a.nz_sum[k0 >> 8] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+         if (threadIdx.x == 0) a.nz_sum[k0 >> 8] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
          __syncthreads();
       }
+    }
+    __syncthreads();
    }
    /* publish the length of my wave's overflow list (EMIT reads it whatever the match option: an empty list otherwise) */
    if (caching && (threadIdx.x & 63u) == 0) {
       const uint32_t n = s_novf[wave_id];
-      if (ovf_r) { ovf[0] = make_uint4(n, 0u, 0u, 0u); if (n + 1u > ovf_r) c->seg_novf = 1u; }
+      if (ovf_r) {
+         const uint32_t my_lists = VERIFY_MY_LISTS, list_room = VERIFY_LIST_ROOM, nr = VERIFY_NR;
+         for (uint32_t t = 0; t < my_lists; t++) {
+            const uint32_t before = t * list_room;
+            const uint32_t cnt = n > before ? (n - before < list_room ? n - before : list_room) : 0u;
+            ovf_all[(size_t)((blockIdx.x + t * nr) * 4u + wave_id) * ovf_r] = make_uint4(cnt, 0u, 0u, 0u);
+         }
+         if (n > my_lists * list_room) c->seg_novf = 1u;
+      }
       else if (n) c->seg_novf = 1u;
+#undef VERIFY_NR
+#undef VERIFY_MY_LISTS
+#undef VERIFY_LIST_ROOM
    }
 }
 
