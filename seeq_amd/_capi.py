@@ -115,7 +115,7 @@ def lib():
         raise OSError("%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C seeq_amd/csrc`; seeq_amd has no fallback matcher" % LIB_PATH)
     _share_torch_hip_runtime()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(LIB_PATH, use_errno=True)      # (C.get_errno(): the errno a failed call left -- device failures are errno's, seeqerr = 0)
     P = C.POINTER
     L.seeqNew.argtypes = [C.c_char_p, C.c_int, C.c_size_t]
     L.seeqNew.restype = P(seeq_t)

@@ -817,6 +817,7 @@ struct seeqdev_scan {
    unsigned long long *clk_probe;  /* page-locked, 4 words per segment: the scan kernel's own clock readings (profiling; k_pair) */
    size_t      cap_clk_probe;
    float       clk_mhz;           /* core clock the last run's scan launches ran at (mean over the launches; 0: not measured) */
+   bool        clk_valid;         /* the last run's scan kernel filled clk_probe (k_pair under profiling): else the readings are an earlier run's */
    int         ncu;               /* compute units of the device (cached) */
    size_t      lds_per_wg;        /* LDS a workgroup may allocate on it */
    size_t      lds_per_cu;        /* LDS of a compute unit (what a workgroup gets when it asks for it: hipFuncAttributeMaxDynamicSharedMemorySize) */
@@ -903,11 +904,15 @@ struct seeqdev_scan {
    unsigned sample_age;        /* runs since the line-length sample was taken (a reused buffer may hold other text by now) */
 };
 
+/* A workspace array of a new size: the new block first, then the old one goes -- a refused allocation (ENOMEM) leaves the array, and with it the
+   capacity its group was sized for, as it was: the context stays usable (tests/test_gpu_parity.py::test_a_refused_reserve_leaves_the_context_usable). */
 static int ws_alloc(void **p, size_t bytes)
 {
-   if (*p) { (void)hipFree(*p); *p = NULL; }
-   hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-   if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)", ENOMEM);
+   void *g = NULL;
+   hipError_t e = hipMalloc(&g, bytes ? bytes : 16);
+   if (e != hipSuccess) { (void)hipGetLastError(); return hip_fail(e, "hipMalloc(workspace)", ENOMEM); }
+   if (*p) (void)hipFree(*p);
+   *p = g;
    return 0;
 }
 
@@ -1418,6 +1423,7 @@ static int run_segments(seeqdev_scan *s)
       if (hipHostMalloc((void **)&s->clk_probe, nseg * 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) s->cap_clk_probe = nseg;
    }
    if (s->prof && s->clk_probe) memset(s->clk_probe, 0, nseg * 4 * sizeof(unsigned long long));
+   s->clk_valid = s->prof && s->clk_probe && use_pair && use_fused;
    /* (Tried: the post-pass of segment k on a second stream under k_pair of segment k + 1, k_pair on one workgroup per CU --
       it is as fast there.  The post-pass kernels do run beside it, and take 3 to 14 times as long as alone: they are
       made of scattered loads and the memory system is what k_pair saturates.  Net: +2 % .. -3 % per step.  Not kept;
@@ -1663,9 +1669,20 @@ static int run_packed(seeqdev_scan *s)
    Counters *c = s->d_cnt;
    hipStream_t st = s->stream;
    const uint32_t L = b.read_len;
+   /* the exact pass reads the candidates' windows from the batch itself (seeq_verify_packed.h) -- no staging text -- unless SQ_ALL records are
+      wanted (k_emit_all recovers their starts from text) or the round-3 exact pass is asked for */
+   const bool direct = !s->knobs.old_verify && !s->knobs.packed_stage && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   const uint32_t pitch = (L + 1u + 15u) & ~15u;            /* bytes per line of the staging text (L <= 256: the newline's word exists for every lane count up to 17; 16 lanes serve L <= 255, L = 256 below) */
    /* workspace: per read of a segment, per candidate */
-   const size_t PACKED_SEG_READS = s->pk_seg_reads;
+   size_t PACKED_SEG_READS = s->pk_seg_reads;
+   /* the staging text is addressed with 32-bit offsets: where it is used a segment holds no more reads than it has lines for (every wave fills its own
+      share of it and a share never sees more candidates than its wave has reads) -- smaller segments, not E2BIG (round 4 refused above 26.8 M hit-list
+      entries at read_len 150, whether or not the staging text was used at all) */
+   const size_t stage_lines_max = (size_t)(0xFFFF0000ull / pitch);
+   if (!direct && PACKED_SEG_READS + 64u * MAX_FUSED_GRID > stage_lines_max)
+      PACKED_SEG_READS = (stage_lines_max - 64u * MAX_FUSED_GRID) & ~(size_t)63;
    const size_t seg_reads = b.nreads < PACKED_SEG_READS ? (size_t)b.nreads : PACKED_SEG_READS;
+   const size_t cap_use = (!direct && s->cap_hitlines > stage_lines_max) ? stage_lines_max : s->cap_hitlines;      /* hit-list entries a segment may make */
    if (seg_reads > s->cap_pk_reads) {
       if (ws_alloc((void **)&s->pk_cand, seg_reads * sizeof(uint32_t))) return -1;
       if (ws_alloc((void **)&s->pk_slot, seg_reads * sizeof(uint32_t))) return -1;
@@ -1673,10 +1690,9 @@ static int run_packed(seeqdev_scan *s)
       if (ws_alloc((void **)&s->pk_bmask, (seg_reads / 64 + 1) * sizeof(uint64_t))) return -1;
       s->cap_pk_reads = seg_reads;
    }
-   const uint32_t pitch = (L + 1u + 15u) & ~15u;            /* bytes per line of the staging text (L <= 256: the newline's word exists for every lane count up to 17; 16 lanes serve L <= 255, L = 256 below) */
-   if (s->cap_hitlines * (size_t)pitch > s->cap_pk_stage) {
-      if (ws_alloc((void **)&s->pk_stage, s->cap_hitlines * (size_t)pitch + 64)) return -1;
-      s->cap_pk_stage = s->cap_hitlines * (size_t)pitch;
+   if (!direct && cap_use * (size_t)pitch > s->cap_pk_stage) {
+      if (ws_alloc((void **)&s->pk_stage, cap_use * (size_t)pitch + 64)) return -1;
+      s->cap_pk_stage = cap_use * (size_t)pitch;
    }
    if (s->cap_hitlines > s->cap_pk_last) {
       if (ws_alloc((void **)&s->pk_last, s->cap_hitlines * sizeof(uint32_t))) return -1;
@@ -1686,7 +1702,6 @@ static int run_packed(seeqdev_scan *s)
       const size_t nb = seg_reads / SCAN_BLOCK + 2;
       if (nb > s->cap_scan_ws) { if (ws_alloc((void **)&s->scan_ws, nb * sizeof(uint32_t))) return -1; s->cap_scan_ws = nb; }
    }
-   if (s->cap_hitlines * (uint64_t)pitch > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
    /* EQ tables of the exact pass (as run_segments makes them) */
    if (s->eq_pat_id != pat->id || s->eq_options != options) {
       const int Wp = pat->words;
@@ -1713,6 +1728,7 @@ static int run_packed(seeqdev_scan *s)
       s->eq_options = options;
    }
    HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), st), EIO);
+   s->clk_valid = false;                                    /* (the packed walk reads no clock) */
    /* four bases per gather over the quad table (seeq_dfa.h section 3b) when the pattern has one and the false candidates it adds
       -- each an exact-pass window, ~13 walks' worth -- stay below the gathers it saves: 4 % of the reads */
    const bool quad = pat->quad_state == 1 && !s->knobs.no_packed_quad && (pat->quad_pacc - pat->pair_pacc) * (double)L <= 0.04;
@@ -1730,9 +1746,6 @@ static int run_packed(seeqdev_scan *s)
    const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
    unsigned grid_hits = (unsigned)(hit_blocks < (size_t)s->ncu * 16 ? hit_blocks : (size_t)s->ncu * 16);
    if (grid_hits == 0) grid_hits = 1;
-   /* the exact pass reads the candidates' windows from the batch itself (seeq_verify_packed.h) -- no staging text -- unless SQ_ALL records are
-      wanted (k_exact1<EMIT> recovers their starts from text) or the round-3 exact pass is asked for */
-   const bool direct = !s->knobs.old_verify && !s->knobs.packed_stage && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const size_t nseg = (size_t)((b.nreads + PACKED_SEG_READS - 1) / PACKED_SEG_READS);
    s->prof_segs = 0;
    if (s->prof && nseg > s->nev_seg) {
@@ -1754,10 +1767,10 @@ static int run_packed(seeqdev_scan *s)
       p.total_bytes = b.nreads * (uint64_t)b.stride;
       p.dfa = quad ? pat->d_quad : pat->d_pair; p.dfa_units = quad ? pat->quad_units : pat->pair_units;
       p.cand = s->pk_cand; p.cslot = s->pk_slot; p.boff = s->pk_coff; p.bmask = s->pk_bmask; p.stage = direct ? nullptr : s->pk_stage;
-      p.wave_cap = (uint32_t)(s->cap_hitlines / ((size_t)wgrid * STREAM_NW_HOST));
+      p.wave_cap = (uint32_t)(cap_use / ((size_t)wgrid * STREAM_NW_HOST));
       p.pitch = pitch;
       p.hit_start = s->hit_start; p.hit_line = s->hit_line; p.hit_col = s->hit_col; p.hit_last = s->pk_last; p.nh = s->nh;
-      p.cap = (uint32_t)s->cap_hitlines;
+      p.cap = (uint32_t)cap_use;
       p.line_base = p.first;
       p.cnt = c;
       if (ev) { HIP_TRY(hipEventRecord(ev[0], st), EIO); HIP_TRY(hipEventRecord(ev[1], st), EIO); }
@@ -1773,8 +1786,8 @@ static int run_packed(seeqdev_scan *s)
       /* from here: the exact pass over the staging text, as behind k_pair */
       ScanArgs a;
       memset(&a, 0, sizeof a);
-      a.text = s->pk_stage;
-      a.nbytes = s->cap_hitlines * (uint64_t)pitch;
+      a.text = direct ? nullptr : s->pk_stage;              /* (direct: nothing reads text -- the windows come from the batch) */
+      a.nbytes = direct ? 0 : cap_use * (uint64_t)pitch;
       a.seg_base = 0; a.seg_len = (uint32_t)a.nbytes; a.first_seg = sg == 0;
       a.peq = pat->d_peq;
       a.m = pat->wlen; a.tau = pat->tau; a.options = options & ~(MASK_NONDNA | MASK_INPUT); a.want = want;
@@ -1908,10 +1921,15 @@ static int multi_post(seeqdev_scan *s, const ScanArgs &ua, hipStream_t st)
       /* the automaton in LDS when it fits what a workgroup may ask for beside the kernel's static arrays (the device's limit, not a literal) */
       const size_t lds2 = (size_t)mp->res_states * 20, lds1 = (size_t)mp->res_states * 16;
       const size_t lds_room = s->lds_per_wg > 1024 ? s->lds_per_wg - 1024 : 0;
+      HIP_TRY(hipGetLastError(), EIO);                       /* (an error of an EARLIER launch of this segment is a failure, not a reason for the per-pattern fall-back) */
       if (lds2 <= lds_room && lds2 <= 65536) hipLaunchKernelGGL(k_multi_resolve<2>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds2, st, m);
       else if (lds1 <= lds_room && lds1 <= 65536) hipLaunchKernelGGL(k_multi_resolve<1>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), lds1, st, m);
       else hipLaunchKernelGGL(k_multi_resolve<0>, dim3(grid ? grid : 1), dim3(MULTI_RESOLVE_WG), 0, st, m);
-      if (hipGetLastError() != hipSuccess) return 1;       /* the launch was refused: a scan per pattern (seeqdevScanRunMulti) */
+      {
+         const hipError_t le = hipGetLastError();            /* this launch refused for its resources: a scan per pattern (seeqdevScanRunMulti); anything else fails */
+         if (le == hipErrorInvalidValue || le == hipErrorLaunchOutOfResources || le == hipErrorInvalidConfiguration) return 1;
+         if (le != hipSuccess) return hip_fail(le, "k_multi_resolve", EIO);
+      }
       hipLaunchKernelGGL(k_multi_reduce, dim3(m.nb), dim3(256), 0, st, m);
       hipLaunchKernelGGL(k_multi_top, dim3((unsigned)npat), dim3(256), 0, st, m);
       if (trust) { HIP_TRY(hipGetLastError(), EIO); return 0; }
@@ -2084,7 +2102,7 @@ extern "C" int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
             if (sg < s->cap_launch_ms) s->launch_ms[sg] = t12;
          }
          s->clk_mhz = 0.f;
-         if (s->prof_segs && s->clk_probe && s->cap_clk_probe >= s->prof_segs) {
+         if (s->clk_valid && s->prof_segs && s->clk_probe && s->cap_clk_probe >= s->prof_segs) {
             double sum = 0; size_t nn = 0;
             for (size_t sg = 0; sg < s->prof_segs; sg++) {
                const unsigned long long *q = s->clk_probe + 4 * sg;

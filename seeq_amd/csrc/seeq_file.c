@@ -88,6 +88,8 @@ typedef struct fstate_t {
    pthread_mutex_t  mu;
    pthread_cond_t   cv;
    int              sync_init, reader_on, reader_stop, reader_done, reader_err, waiting;
+   int              dead;          /* errno of the device / reader failure that ended this file's scanning: every later seeqFileMatch fails with it (no call into a
+                                      device context whose state is unknown, no line out of order after a lost chunk) */
    lane_t           lane[MAX_LANES];
    int              nlanes, next_lane;
    unsigned long    lanes_eng;
@@ -683,7 +685,11 @@ long seeqFileMatch(seeqfile_t *sqfile, seeq_t *sq, int match_opt, int file_opt)
 
    for (;;) {
       slot_t *c;
-      if (pump(s, eng, sq, dev_opt, want, &c)) return -1;
+      /* A failure of the device boundary (HIP: -1, seeqerr = 0, errno = ENOMEM / EIO / ENODEV) or of the reader ends the scanning of this file: the
+         chunk it happened on is lost and a device context may be in any state, so every later call reports the same failure (the reference, with
+         nothing but malloc to fail, loses the line and goes on: seeq.c:361-371; its callers stop at the first -1: seeq.c:131,176) */
+      if (s->dead) { seeqerr = 0; errno = s->dead; return -1; }
+      if (pump(s, eng, sq, dev_opt, want, &c)) { if (seeqerr == 0) s->dead = errno ? errno : EIO; return -1; }
       if (!c) break;                           /* end of the input, everything replayed */
       if (s->pos >= c->avail) {                /* this chunk is done: the reader may have it back */
          advance(s);

@@ -11,6 +11,13 @@
  * A scan "enqueued" with seeqdevScanHostBegin runs on a worker thread and is joined by seeqdevScanFetch, so the
  * caller's buffers are really read while the caller goes on -- an early reuse or free shows up under the sanitizers.
  * FAKE_SEEQ_DEVICES=n pretends to have n devices (seeqFileMatch's SEEQ_DEVICES spreading).
+ *
+ * FAULT INJECTION (round 5; the reference tests every allocation failure of its own, test/faultymalloc.c:20-56 -- here the failures
+ * that matter are the device boundary's): FAKE_SEEQDEV_FAIL="begin@3,fetch@7,copy@2" makes the N-th call (1-based, counted over the
+ * process) of the named entry point fail the way the HIP library does -- -1 / NULL, seeqerr = 0, errno set (EIO; ENOMEM for the
+ * allocating ones):  new = seeqdevScanNew, pattern = seeqdevPatternNew, hostalloc = seeqdevHostAlloc, setdevice = seeqdevSetDevice,
+ * begin = seeqdevScanHostBegin, fetch = seeqdevScanFetch (the job has run: the failure is the device's), copy = seeqdevScanCopyRecords,
+ * offsets = seeqdevScanCopyOffsets, string = seeqdevStringMatch.  N may be a range "fetch@3-5" or open "fetch@3-" (every call from the third).
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -44,6 +51,30 @@ struct seeqdev_scan {
 
 static __thread int t_device = 0;
 
+enum { FP_NEW, FP_PATTERN, FP_HOSTALLOC, FP_SETDEVICE, FP_BEGIN, FP_FETCH, FP_COPY, FP_OFFSETS, FP_STRING, FP_COUNT };
+static const char *const fp_name[FP_COUNT] = {"new", "pattern", "hostalloc", "setdevice", "begin", "fetch", "copy", "offsets", "string"};
+static unsigned long fp_calls[FP_COUNT];
+
+/* 1 when this call of entry point `fp` is to fail (errno set, seeqerr cleared) */
+static int fake_fail(int fp, int err_no)
+{
+   const unsigned long n = __atomic_add_fetch(&fp_calls[fp], 1ul, __ATOMIC_RELAXED);
+   const char *e = getenv("FAKE_SEEQDEV_FAIL");
+   if (!e) return 0;
+   const size_t ln = strlen(fp_name[fp]);
+   while (*e) {
+      if (!strncmp(e, fp_name[fp], ln) && e[ln] == '@') {
+         char *end;
+         unsigned long lo = strtoul(e + ln + 1, &end, 10), hi = lo;
+         if (*end == '-') { hi = end[1] >= '0' && end[1] <= '9' ? strtoul(end + 1, &end, 10) : ~0ul; }
+         if (n >= lo && n <= hi) { seeqerr = 0; errno = err_no; return 1; }
+      }
+      while (*e && *e != ',') e++;
+      if (*e == ',') e++;
+   }
+   return 0;
+}
+
 const char *seeqdevLastError(void) { return "fake device layer (tests)"; }
 
 int seeqdevDeviceCount(void)
@@ -56,6 +87,7 @@ int seeqdevDeviceCount(void)
 int seeqdevSetDevice(int device)
 {
    if (device < 0 || device >= seeqdevDeviceCount()) { seeqerr = 0; errno = ENODEV; return -1; }
+   if (fake_fail(FP_SETDEVICE, ENODEV)) return -1;
    t_device = device;
    return 0;
 }
@@ -66,6 +98,7 @@ seeqdev_pattern_t *seeqdevPatternNew(const char *keys, int wlen, int tau)
    if (!keys || wlen < 1 || tau < 0 || tau >= wlen) { errno = EINVAL; return NULL; }
    if (wlen > SEEQDEV_MAX_WLEN) { errno = E2BIG; return NULL; }
    if (seeqdevDeviceCount() < 1) { errno = ENODEV; return NULL; }
+   if (fake_fail(FP_PATTERN, ENOMEM)) return NULL;
    struct seeqdev_pattern *p = calloc(1, sizeof *p);
    if (!p) return NULL;
    p->device = t_device; p->wlen = wlen; p->tau = tau;
@@ -83,6 +116,7 @@ seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
    (void)hip_stream;
    seeqerr = 0;
    if (seeqdevDeviceCount() < 1) { errno = ENODEV; return NULL; }
+   if (fake_fail(FP_NEW, ENOMEM)) return NULL;
    struct seeqdev_scan *s = calloc(1, sizeof *s);
    if (s) s->device = t_device;
    return s;
@@ -176,6 +210,7 @@ int seeqdevScanHostBegin(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const 
 {
    seeqerr = 0;
    if (!s || !pat || (!host_text && nbytes) || pat->device != s->device) { errno = EINVAL; return -1; }
+   if (fake_fail(FP_BEGIN, EIO)) return -1;
    join_job(s);
    s->pat = pat; s->text = host_text; s->nbytes = nbytes; s->options = options; s->want = want;
    s->failed = 0; s->ran = 0;
@@ -190,6 +225,7 @@ int seeqdevScanFetch(seeqdev_scan_t *s, seeqdev_counts_t *counts)
    if (!s || (!s->running && !s->ran)) { errno = EINVAL; return -1; }
    join_job(s);
    s->ran = 1;
+   if (fake_fail(FP_FETCH, EIO)) return -1;
    if (s->failed) { errno = ENOMEM; return -1; }
    if (counts) *counts = s->cnt;
    return 0;
@@ -205,6 +241,7 @@ int seeqdevScanHost(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const char 
 int seeqdevScanCopyRecords(seeqdev_scan_t *s, seeqdev_hit_t *out, size_t first, size_t n)
 {
    if (!s || first + n > s->cnt.nrecords) { errno = EINVAL; return -1; }
+   if (fake_fail(FP_COPY, EIO)) return -1;
    if (n) memcpy(out, s->rec + first, n * sizeof *out);
    return 0;
 }
@@ -212,11 +249,12 @@ int seeqdevScanCopyRecords(seeqdev_scan_t *s, seeqdev_hit_t *out, size_t first, 
 int seeqdevScanCopyOffsets(seeqdev_scan_t *s, uint64_t *out, size_t first, size_t n)
 {
    if (!s || first + n > s->cnt.nrecords) { errno = EINVAL; return -1; }
+   if (fake_fail(FP_OFFSETS, EIO)) return -1;
    if (n) memcpy(out, s->off + first, n * sizeof *out);
    return 0;
 }
 
-void *seeqdevHostAlloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void *seeqdevHostAlloc(size_t bytes) { if (fake_fail(FP_HOSTALLOC, ENOMEM)) return NULL; return malloc(bytes ? bytes : 1); }
 void seeqdevHostFree(void *p) { free(p); }
 
 int seeqdevStringMatch(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const char *data, size_t n, int options,
@@ -224,6 +262,7 @@ int seeqdevStringMatch(seeqdev_scan_t *s, const seeqdev_pattern_t *pat, const ch
 {
    seeqerr = 0;
    if (!s || !pat || !rec || !nrec) { errno = EINVAL; return -1; }
+   if (fake_fail(FP_STRING, EIO)) return -1;
    char *z = malloc(n + 1);                               /* the oracle wants a NUL-terminated string */
    if (!z) return -1;
    memcpy(z, data, n); z[n] = 0;

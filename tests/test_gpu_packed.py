@@ -334,6 +334,11 @@ def test_text_alloc_picks_a_buffer_by_measurement(gpu, capi):
     nb = n * (L + 1)
     buf = dev.TextBuffer(nb, candidates=3)
     assert buf.ptr and len(buf.probe_ms) == 3 and all(t > 0 for t in buf.probe_ms)
+    # what the caller got (seeqdevTextAllocInfo): the candidate kept is the fastest, its block may be larger than asked (a power of two), the call's peak is reported
+    assert buf.probe_ms[buf.chosen] == min(buf.probe_ms) and buf.allocated_bytes >= nb and buf.allocated_bytes in (nb, 1 << (nb - 1).bit_length())
+    assert buf.probe_peak_bytes >= 3 * nb
+    view = buf.tensor()
+    assert view.data_ptr() == buf.ptr and view.numel() == nb and view.dtype == torch.uint8
     stream = torch.cuda.current_stream().cuda_stream
     ref = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
     dev.synth_reads(ref.data_ptr(), 0, n, L, pattern, tau, stream=stream)
@@ -351,4 +356,36 @@ def test_text_alloc_picks_a_buffer_by_measurement(gpu, capi):
     small = dev.TextBuffer(1 << 20, candidates=8)
     plain = dev.TextBuffer(nb, candidates=1)
     assert small.ptr and plain.ptr and small.probe_ms == [] and plain.probe_ms == []
+    assert small.chosen == 0 and plain.allocated_bytes == nb
     small.free(); plain.free()
+
+
+def test_packed_segment_where_every_read_is_a_candidate(gpu, capi, monkeypatch):
+    """64 Mi reads per packed segment met a 32-bit limit of the ASCII staging text -- cap_hitlines x pitch above
+    4 GiB was refused with E2BIG, at read_len 150 from 26.8 M hit-list entries, whether the staging text was used or not.  30 M reads that
+    ALL carry the pattern in one segment: --best (the exact pass reads its windows from the batch: no staging text, no limit) and --all
+    records (staging text in use: the segment is cut to what the text can address) both return one record per read, no E2BIG."""
+    import torch
+    from seeq_amd import device as dev
+    monkeypatch.setenv("SEEQ_PACKED_SEG_READS", str(1 << 25))           # 33.5 M reads per segment: more than the 26.8 M lines a staging text can hold
+    n, L = 30_000_000, 150
+    pattern, tau = "GATGTAGCGCGATTAGCCTG", 3
+    line = (pattern + "T" * (L - len(pattern))).encode() + b"\n"
+    one = torch.frombuffer(bytearray(line), dtype=torch.uint8).to("cuda:0")
+    text = one.repeat(n)
+    stream = torch.cuda.current_stream().cuda_stream
+    pb = torch.empty(n * ((L + 3) // 4), dtype=torch.uint8, device="cuda:0")
+    pn = torch.empty(n * ((L + 7) // 8), dtype=torch.uint8, device="cuda:0")
+    dev.pack_reads_device(text.data_ptr(), n, L, pb.data_ptr(), pn.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    del text
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner(stream)
+    for opt in (SQ_BEST, SQ_ALL):
+        sc.run_packed(pat, pb.data_ptr(), pn.data_ptr(), n, L, options=opt, want=dev.WANT_RECORDS)
+        c = sc.fetch()
+        assert c["nlines"] == n and c["nmatchlines"] == n and c["nrecords"] == n, (opt, c)
+        rec = sc.records(n)
+        assert np.array_equal(rec[:, 0], np.arange(1, n + 1, dtype=rec.dtype))
+        assert (rec[:, 1] == 0).all() and (rec[:, 2] == len(pattern)).all() and (rec[:, 3] == 0).all()
+    sc.close(); pat.close()

@@ -941,6 +941,38 @@ def test_long_lines_window_walk(gpu, capi, oracle):
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], fasta
 
 
+def test_a_refused_reserve_leaves_the_context_usable(gpu, capi, oracle):
+    """Round 5, the device boundary's failure contract on the real device (the CPU suite injects the same failures into the host code:
+    tests/test_host_sanitizers.py): seeqdevScanReserve for more records than the card has memory is REFUSED -- -1, seeqerr = 0,
+    errno = ENOMEM, seeqdevLastError names the call -- and the scan context goes on with the workspace it had: the next scans return
+    the oracle's records (reference contract for its own allocation failures: libseeq.c:75-135, test/testset.c:150-155)."""
+    import errno
+    from seeq_amd import device as dev
+    buf = open(os.path.join(GOLDEN, "reads_small.txt"), "rb").read()
+    exp = oracle.buffer_scan(PAT20, 3, buf, SQ_BEST)
+    pat = dev.Pattern(PAT20, 3)
+    sc = dev.Scanner()
+    L = capi.lib()
+    got = sc.scan_host(pat, buf, SQ_BEST, dev.WANT_RECORDS)
+    assert np.array_equal(got["records"].astype(np.uint64), exp["records"])
+    for (nbytes, nlines, nhl, nrec) in ((0, 0, 0, 1 << 40), (0, 0, 1 << 38, 0), (0, 1 << 40, 0, 0)):      # 24 TB of records / 12 TB of hit-list arrays / 4 TB of line starts
+        C.set_errno(0)
+        rc = L.seeqdevScanReserve(sc._h, nbytes, nlines, nhl, nrec)
+        assert rc == -1 and C.get_errno() == errno.ENOMEM and capi.seeqerr() == 0, (rc, C.get_errno(), capi.seeqerr())
+        assert b"hipMalloc" in L.seeqdevLastError()
+        for opt in (SQ_BEST, SQ_ALL):
+            e2 = oracle.buffer_scan(PAT20, 3, buf, opt)
+            g2 = sc.scan_host(pat, buf, opt, dev.WANT_RECORDS)
+            assert g2["nlines"] == e2["nlines"] and np.array_equal(g2["records"].astype(np.uint64), e2["records"]), (nrec, opt)
+    # a scan that needs MORE than the refused context has grows it by the ordinary re-run
+    big = buf * 40
+    e3 = oracle.buffer_scan(PAT20, 3, big, SQ_ALL)
+    g3 = sc.scan_host(pat, big, SQ_ALL, dev.WANT_RECORDS)
+    assert np.array_equal(g3["records"].astype(np.uint64), e3["records"])
+    sc.close()
+    pat.close()
+
+
 def test_every_byte_value_alone(gpu, capi, oracle):
     """One foreign byte value at a time in otherwise clean text, right in front of a perfect copy of the pattern:
     k_stream's alphabet check must flag exactly the bytes that are not A C G T N (either case) or newline -- each of

@@ -130,6 +130,79 @@ def test_file_api_sequences_under_sanitizers(kind):
         assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
 
 
+FAULTS = ["begin@1", "begin@2", "begin@5", "fetch@1", "fetch@3", "fetch@6", "copy@1", "copy@4", "offsets@2", "new@1", "new@2", "new@3",
+          "pattern@1", "pattern@2", "hostalloc@1", "hostalloc@2", "hostalloc@4", "setdevice@1", "setdevice@3", "fetch@2,begin@9", "fetch@4-"]
+FAULT_ENVS = [{"SEEQ_CHUNK_BYTES": "2000", "SEEQ_LANES": "1"},
+              {"SEEQ_CHUNK_BYTES": "3000", "SEEQ_LANES": "3"},
+              {"SEEQ_CHUNK_BYTES": "5000", "SEEQ_LANES": "3", "FAKE_SEEQ_DEVICES": "3", "SEEQ_DEVICES": "2,0,1"},
+              {"SEEQ_CHUNK_BYTES": "100000", "SEEQ_LANES": "2"}]          # (one chunk holds the whole file: the failure is the first and the last chunk's)
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_device_failures_under_the_file_api(kind):
+    """Round 5: the device boundary FAILING under seeqFileMatch / seeqStringMatch / seeqNew (FAKE_SEEQDEV_FAIL: the N-th call of
+    seeqdevScanNew / PatternNew / HostAlloc / SetDevice / ScanHostBegin / ScanFetch / CopyRecords / CopyOffsets / StringMatch returns
+    -1 or NULL with errno set, as the HIP library does).  tests/host_fault_driver.c checks the reference's contract (libseeq.c:75-135,
+    505; test/faultymalloc.c:20-56 is how the reference tests its own failures): -1 / NULL, seeqerr = 0, errno kept, every line
+    delivered before the failure is the oracle's, nothing after it, no hang, seeqClose / seeqFree in either order -- on the first
+    chunk, in the middle of the file and on its last chunks, one and several lanes and devices; under ASan with its leak check on
+    (a failed call must not leak the chunk, the lane or the scan it was working on), under TSan for the reader thread."""
+    exe = _build(kind, os.path.join(ROOT, "tests", "host_fault_driver.c"), "host_fault_driver")
+    path = os.path.join(GOLDEN, "reads_small.txt")
+    probe = _run(exe, [path, "file", "close-first"], {"SEEQ_CHUNK_BYTES": "3000"}, text=True, timeout=300)
+    if kind == "tsan" and "unexpected memory mapping" in probe.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert probe.returncode == 0 and probe.stdout.startswith("OK file") and "rv=0" in probe.stdout, (probe.stdout, probe.stderr[-2000:])
+    leak = {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0"} if kind == "asan" else {}
+    # (LeakSanitizer needs ptrace rights some containers do not give: probe once, fall back to the leak check off)
+    if leak:
+        pr = _run(exe, [path, "string", "close-first"], leak, text=True, timeout=300)
+        if "LeakSanitizer has encountered a fatal error" in pr.stderr or "LeakSanitizer does not work" in pr.stderr:
+            leak = {}
+    failures_seen = 0
+    faults = FAULTS if kind == "asan" else FAULTS[::2]
+    for fault in faults:
+        for ei, env in enumerate(FAULT_ENVS if kind == "asan" else FAULT_ENVS[1:3]):
+            for order in (("close-first", "free-first") if ei == 1 else ("close-first",)):
+                e = dict(env, FAKE_SEEQDEV_FAIL=fault, **leak)
+                r = _run(exe, [path, "file", order], e, text=True, timeout=300)       # (a hang is the timeout's failure)
+                assert r.returncode == 0 and r.stdout.startswith("OK"), (fault, env, order, r.stdout[-500:], r.stderr[-3000:])
+                assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (fault, env, order, r.stderr[-3000:])
+                failures_seen += "rv=-1" in r.stdout or "seeqNew=NULL" in r.stdout
+    assert failures_seen >= len(faults)                      # (the injected failures really reached the API: most runs end in -1)
+    for fault, mode in (("string@1", "string"), ("string@2-4", "string"), ("new@1", "string"), ("new@1", "new"), ("pattern@1", "new"), ("pattern@2", "new"), ("string@1", "new")):
+        if True:
+            r = _run(exe, [path, mode, "close-first"], dict(FAKE_SEEQDEV_FAIL=fault, **leak), text=True, timeout=300)
+            assert r.returncode == 0 and r.stdout.startswith("OK"), (fault, mode, r.stdout[-500:], r.stderr[-3000:])
+            assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (fault, mode, r.stderr[-3000:])
+
+
+def test_cli_with_a_failing_device_boundary(host_cli, cli_cases):
+    """The CLI over the same failures: the reference's seeq() reports a failed seeqFileMatch on stderr -- "error in 'seeqFileMatch()':
+    <strerror(errno)>" (seeq.c:105-107,176-178) -- and returns; a failed seeqNew is EXIT_FAILURE (seeq.c:77-81).  What reached stdout
+    before the failure is a prefix of the reference's output made of whole lines, nothing is printed after the report, no hang."""
+    exe, kind = host_cli
+    picked = [c for c in cli_cases if "stdout" in c and c["file"] in ("reads_small.txt", "fastq_small.txt") and len(c["stdout"]) > 2000][:6 if kind == "asan" else 2]
+    assert picked
+    for c in picked:
+        for fault in ("begin@1", "fetch@2", "fetch@5", "copy@3", "offsets@1", "begin@4", "hostalloc@2"):
+            for env in ({"SEEQ_CHUNK_BYTES": "3000", "SEEQ_LANES": "1"}, {"SEEQ_CHUNK_BYTES": "2000", "SEEQ_LANES": "3", "FAKE_SEEQ_DEVICES": "2", "SEEQ_DEVICES": "all"}):
+                r = _run(exe, c["args"] + [os.path.join(GOLDEN, c["file"])], dict(env, FAKE_SEEQDEV_FAIL=fault), timeout=300)
+                out, err = r.stdout.decode("latin-1"), r.stderr.decode("latin-1")
+                assert "Sanitizer" not in err and "runtime error" not in err, (c["args"], fault, env, err[-3000:])
+                assert c["stdout"].startswith(out) and (out == "" or out.endswith("\n")), (c["args"], fault, env, out[-300:])
+                if out != c["stdout"]:                       # the failure reached the run (a count-only case fetches no records: copy@N never fires)
+                    assert "error in 'seeqFileMatch()': " in err and r.returncode == 0, (c["args"], fault, env, r.returncode, err[-500:])
+                else:
+                    assert r.returncode == 0
+    for fault in ("pattern@1",):                             # (the scan contexts are made by the file layer: new@N fails seeqFileMatch, above)
+        c = picked[0]
+        r = _run(exe, c["args"] + [os.path.join(GOLDEN, c["file"])], {"FAKE_SEEQDEV_FAIL": fault}, timeout=300)
+        err = r.stderr.decode("latin-1")
+        assert "Sanitizer" not in err and "runtime error" not in err, (fault, err[-3000:])
+        assert r.returncode == 1 and "error in 'seeqNew()'" in err and r.stdout == b"", (fault, r.returncode, err[-500:])
+
+
 REF_SRC = "/root/reference/src"
 
 
