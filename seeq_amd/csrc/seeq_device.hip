@@ -950,24 +950,14 @@ extern "C" seeqdev_scan_t *seeqdevScanNew(void *hip_stream)
       ScanKnobs &kn = s->knobs;
       const char *v;
       v = getenv("SEEQ_FUSED_KERNEL"); kn.kernel = v ? (!strcmp(v, "stream") ? 1 : !strcmp(v, "direct") ? 2 : !strcmp(v, "pair") ? 3 : 0) : 0;
-      v = getenv("SEEQ_DFA_WGS");      kn.wgs_per_cu = v ? atoi(v) : 0;
       v = getenv("SEEQ_NO_LEADERS");   kn.no_leaders = v && atoi(v) == 1;
       v = getenv("SEEQ_TILE_BYTES");   kn.tile_bytes = v ? atoi(v) : 0;
-      v = getenv("SEEQ_EXACT");        kn.exact_generic = v && !strcmp(v, "generic");
       v = getenv("SEEQ_NO_FILTER");    kn.no_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_STREAM_SUB");   kn.no_sub = v && atoi(v) == 0;
       v = getenv("SEEQ_STREAM_WU");    kn.min_wu = v ? atoi(v) : 0;
       v = getenv("SEEQ_NO_MYERS");     kn.no_myers = v && atoi(v) == 1;
       v = getenv("SEEQ_NO_WINDOW");    kn.no_window = v && atoi(v) == 1;
-      v = getenv("SEEQ_PAIR_EXP");     kn.pair_exp = v ? atoi(v) : 0;
-      v = getenv("SEEQ_PAIR_PF");      kn.pair_pf = v && atoi(v) == 1;
-      v = getenv("SEEQ_VERIFY");       kn.old_verify = v && !strcmp(v, "old");
-      v = getenv("SEEQ_EMIT_ALL");     kn.old_emit_all = v && !strcmp(v, "old");
-      v = getenv("SEEQ_ORDER");        kn.old_order = v && !strcmp(v, "old");
-      v = getenv("SEEQ_NO_SKIPCOUNT"); kn.no_skipcount = v && atoi(v) == 1;
-      v = getenv("SEEQ_NO_LL_FILTER"); kn.no_ll_filter = v && atoi(v) == 1;
       v = getenv("SEEQ_EXPLAIN");      kn.explain = v && atoi(v) == 1;
-      v = getenv("SEEQ_PACKED_STAGE"); kn.packed_stage = v && atoi(v) == 1;
       v = getenv("SEEQ_PACKED_QUAD");  kn.no_packed_quad = v && atoi(v) == 0;
       v = getenv("SEEQ_PACKED_SEG_READS");
       s->pk_seg_reads = v && atol(v) >= 64 && (size_t)atol(v) <= ((size_t)1 << 26) ? (size_t)atol(v) & ~(size_t)63 : PACKED_SEG_READS_DEFAULT;
@@ -1266,18 +1256,61 @@ static void plan_ensure(void *ctx, int which, int complete_only, PlanAutomata *a
    pattern_automata(mp, au);
 }
 
-template <int W>
-static int run_segments(seeqdev_scan *s)
+/* ---- a run of seeqdevScanRun, in pieces (round 5: run_segments was one function of 385 lines; the decisions had moved to seeq_plan.h in round 4,
+        what is left executes the plan):  run_setup -- the plan, the kernel instance and its grid, the EQ tables, the profiling events;
+        seg_onepass -- a segment's one-pass scan kernel (k_pair / k_stream / k_direct) and the ordering of its hit slices;
+        seg_index_forward<W> -- the generic path's newline index and k_forward<W>;  seg_post<W> -- the exact pass and the records ---- */
+struct SegRun {
+   const seeqdev_pattern *pat;
+   int       options, want;
+   ScanPlan  plan;
+   int       fw, nw;                  /* column words of the one-pass kernels; waves per workgroup of the scan kernel */
+   uint32_t  tile_bytes;
+   unsigned  fused_grid, nslices, grid_lines;
+   const void *stream_fn;             /* the k_stream / k_pair instance of this run */
+   size_t    dfa_lds, seg_bytes, nseg;
+};
+
+/* EQ[dir][byte][fw]: the top-aligned Peq column of the byte's class, or a flag (reference seeqcore.h:89-111 folded with the non-DNA option,
+   libseeq.c:223-228,265-270) -- uploaded when the pattern or the options changed since the context's last scan */
+static int eq_tables_upload(seeqdev_scan *s, const seeqdev_pattern *pat, int options, int fw)
+{
+   if (s->eq_pat_id == pat->id && s->eq_options == options) return 0;
+   const int Wp = pat->words;
+   for (int dir = 0; dir < 2; dir++)
+      for (int b = 0; b < 256; b++) {
+         const uint8_t cls = sq_class_of((uint32_t)b, options);
+         uint64_t v;
+         if (cls < 5) {
+            const uint32_t *q = pat->h_peq + (dir * 5 + cls) * Wp;
+            const uint64_t col = (uint64_t)q[0] | (Wp > 1 ? (uint64_t)q[1] << 32 : 0);
+            v = col << (32 * fw - pat->wlen);                /* row m lands on the top bit */
+         } else {
+            v = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
+         }
+         uint32_t *dst = s->h_eqtab + (size_t)(dir * 256 + b) * fw;
+         dst[0] = (uint32_t)v;
+         if (fw == 2) dst[1] = (uint32_t)(v >> 32);
+      }
+   /* third table, k_stream's Myers mode: the forward table with the newline marked (flag bits 0-1 = 3) */
+   memcpy(s->h_eqtab + (size_t)512 * fw, s->h_eqtab, (size_t)256 * fw * sizeof(uint32_t));
+   s->h_eqtab[(size_t)512 * fw + (size_t)'\n' * fw] |= 3u;
+   /* the pinned staging table may still be read by an earlier copy on this stream: wait before the next rewrite */
+   HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)768 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
+   HIP_TRY(hipStreamSynchronize(s->stream), EIO);
+   s->eq_pat_id = pat->id;
+   s->eq_options = options;
+   return 0;
+}
+
+static int run_setup(seeqdev_scan *s, SegRun &r)
 {
    const seeqdev_pattern *pat = s->pat;
    const int options = s->options, want = s->want;
    const bool fasta = (options & SEEQDEV_FASTA) != 0;
    const bool single = (options & SEEQDEV_SINGLELINE) != 0;
-   const int match_opt = options & 3;
    const size_t nbytes = s->nbytes;
-   Counters *c = s->d_cnt;
 
-   HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), s->stream), EIO);
 
    const int ncu = s->ncu;
    const ScanKnobs &kn = s->knobs;
@@ -1297,7 +1330,8 @@ static int run_segments(seeqdev_scan *s)
    pin.seg_bytes = s->seg_bytes; pin.kn = &kn;
    PlanAutomata au;
    pattern_automata(pat, &au);
-   const ScanPlan plan = seeq_plan_scan(pin, au, plan_ensure, const_cast<seeqdev_pattern *>(pat));
+   r.plan = seeq_plan_scan(pin, au, plan_ensure, const_cast<seeqdev_pattern *>(pat));
+   const ScanPlan &plan = r.plan;
    if (kn.explain) seeq_plan_print(stderr, pin, au, plan);
    if (plan.rc) return plan.rc;
    const int fw = plan.fw;
@@ -1336,22 +1370,10 @@ static int run_segments(seeqdev_scan *s)
                           : stream_wu == 7 ? (const void *)k_pair<7, __VA_ARGS__> : (const void *)k_pair<8, __VA_ARGS__>)
             stream_fn = fasta ? SEEQ_PAIR_FN(true) : SEEQ_PAIR_FN(false);
             dfa_lds = (size_t)pat->pair_units * 16;
-            /* SEEQ_PAIR_PF=1: the variant that requests the next tile into LDS before it walks this one (seeq_pair.h, PF): twelve waves per
-               workgroup, their staging rows above the table */
-            if (kn.pair_pf && !fasta && dfa_lds + 12 * (size_t)PAIR_STAGE_BYTES <= s->lds_per_cu) {      /* (160 KB of LDS per CU on gfx950) */
-               stream_fn = SEEQ_PAIR_FN(false, 0, true);
-               nw = 12;
-               dfa_lds += 12 * (size_t)PAIR_STAGE_BYTES;
-            }
-#ifdef SEEQ_EXPERIMENTS                                   /* (builds of profiles/ only: the shipped library holds no kernel whose results are void) */
-            if (!fasta && stream_wu == 5 && kn.pair_exp >= 2 && kn.pair_exp <= 4)       /* experiments (profiles/r03): timing only */
-               stream_fn = kn.pair_exp == 2 ? (const void *)k_pair<5, false, 2> : kn.pair_exp == 3 ? (const void *)k_pair<5, false, 3> : (const void *)k_pair<5, false, 4>;
-#endif
 #undef SEEQ_PAIR_FN
          }
          int per_cu = occupancy_of(s, stream_fn, 64 * nw, dfa_lds);
          if (per_cu < 0) return -1;
-         if (kn.wgs_per_cu >= 1 && kn.wgs_per_cu < per_cu) per_cu = kn.wgs_per_cu;       /* experiments: workgroups per CU */
          fused_grid = (unsigned)(ncu * per_cu);
          if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
          nslices = fused_grid * nw;                         /* one hit slice per wave */
@@ -1367,43 +1389,13 @@ static int run_segments(seeqdev_scan *s)
          if ((size_t)fused_grid * nw > MAX_FUSED_GRID) fused_grid = (unsigned)(MAX_FUSED_GRID / nw);
          nslices = fused_grid * nw;                         /* one hit slice per wave */
       }
-      if (s->eq_pat_id != pat->id || s->eq_options != options) {
-         /* EQ[dir][byte][fw]: the top-aligned Peq column of the byte's class, or a flag (reference
-            seeqcore.h:89-111 folded with the non-DNA option, libseeq.c:223-228,265-270) */
-         uint32_t hpeq[20];                               /* [2 dirs][5 classes][Wp <= 2 words] */
-         const int Wp = pat->words;
-         memcpy(hpeq, pat->h_peq, (size_t)10 * Wp * sizeof(uint32_t));
-         for (int dir = 0; dir < 2; dir++)
-            for (int b = 0; b < 256; b++) {
-               const uint8_t cls = sq_class_of((uint32_t)b, options);
-               uint64_t v;
-               if (cls < 5) {
-                  const uint32_t *q = hpeq + (dir * 5 + cls) * Wp;
-                  const uint64_t col = (uint64_t)q[0] | (Wp > 1 ? (uint64_t)q[1] << 32 : 0);
-                  v = col << (32 * fw - pat->wlen);                /* row m lands on the top bit */
-               } else {
-                  v = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
-               }
-               uint32_t *dst = s->h_eqtab + (size_t)(dir * 256 + b) * fw;
-               dst[0] = (uint32_t)v;
-               if (fw == 2) dst[1] = (uint32_t)(v >> 32);
-            }
-         /* third table, k_stream's Myers mode: the forward table with the newline marked (flag bits 0-1 = 3) */
-         memcpy(s->h_eqtab + (size_t)512 * fw, s->h_eqtab, (size_t)256 * fw * sizeof(uint32_t));
-         s->h_eqtab[(size_t)512 * fw + (size_t)'\n' * fw] |= 3u;
-         /* the pinned staging table may still be read by an earlier copy on this stream: wait before the next rewrite */
-         HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)768 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream), EIO);
-         HIP_TRY(hipStreamSynchronize(s->stream), EIO);
-         s->eq_pat_id = pat->id;
-         s->eq_options = options;
-      }
+      if (eq_tables_upload(s, pat, options, fw)) return -1;
    }
    const bool use_direct = plan.use_direct;
    s->last_path = plan.path;
    s->last_filter = filter;
    const bool superset = plan.superset;                  /* the scan kernel's hit lines are candidates: nh[] decides */
    const bool need_nh = plan.need_nh, nh_is_count = plan.nh_is_count;
-   const bool generic_exact = plan.generic_exact;        /* A/B knob */
 
    const size_t seg_bytes = single ? (nbytes ? nbytes : 1) : s->seg_bytes;
    if (single && nbytes > 0xFFFF0000ull) { seeqerr = 0; errno = E2BIG; return -1; }
@@ -1428,11 +1420,292 @@ static int run_segments(seeqdev_scan *s)
       it is as fast there.  The post-pass kernels do run beside it, and take 3 to 14 times as long as alone: they are
       made of scattered loads and the memory system is what k_pair saturates.  Net: +2 % .. -3 % per step.  Not kept;
       tag r03-experiment-overlap-postpass, profiles/r03/overlap_trace.txt.) */
+   r.pat = pat; r.options = options; r.want = want;
+   r.fw = fw; r.nw = nw; r.tile_bytes = tile_bytes; r.fused_grid = fused_grid; r.nslices = nslices; r.grid_lines = grid_lines;
+   r.stream_fn = stream_fn; r.dfa_lds = dfa_lds; r.seg_bytes = seg_bytes; r.nseg = nseg;
+   (void)use_direct; (void)superset; (void)need_nh; (void)nh_is_count; (void)use_myers;
+   return 0;
+}
+
+/* a segment's one-pass scan kernel + the ordering of its hit slices: newline handling, forward scan and per-tile compaction in ONE kernel */
+static int seg_onepass(seeqdev_scan *s, const SegRun &r, ScanArgs &a, size_t sg, hipEvent_t *ev, bool &order2, uint32_t &stream_ntiles)
+{
+   const seeqdev_pattern *pat = r.pat;
+   const int options = r.options, want = r.want, match_opt = r.options & 3, fw = r.fw, ncu = s->ncu;
+   const ScanPlan &plan = r.plan;
+   const bool fasta = (options & SEEQDEV_FASTA) != 0, single = (options & SEEQDEV_SINGLELINE) != 0;
+   const bool use_stream = plan.use_stream, use_pair = plan.use_pair, use_myers = plan.use_myers, filter = plan.filter, use_fused = plan.use_fused, use_direct = plan.use_direct;
+   const bool stream_ll = plan.stream_ll, superset = plan.superset, need_nh = plan.need_nh, nh_is_count = plan.nh_is_count;
+   const int stream_sub = plan.stream_sub, stream_ch = 128, nw = r.nw;
+   const uint32_t tile_bytes = r.tile_bytes;
+   const unsigned fused_grid = r.fused_grid, nslices = r.nslices, grid_lines = r.grid_lines;
+   const void *stream_fn = r.stream_fn;
+   const size_t dfa_lds = r.dfa_lds, nbytes = s->nbytes;
+   Counters *c = s->d_cnt;
+   seeqdev_scan::OnePassWs &ow = s->ow;
+   hipStream_t st = s->stream;
+   (void)pat; (void)want; (void)match_opt; (void)fw; (void)ncu; (void)fasta; (void)single; (void)use_stream; (void)use_pair; (void)use_myers; (void)filter; (void)use_fused;
+   (void)use_direct; (void)stream_ll; (void)superset; (void)need_nh; (void)nh_is_count; (void)stream_sub; (void)stream_ch; (void)nw; (void)tile_bytes; (void)fused_grid;
+   (void)nslices; (void)grid_lines; (void)stream_fn; (void)dfa_lds; (void)nbytes; (void)c; (void)ow; (void)st;
+
+   /* ---- fused path: newline index + forward scan + per-tile compaction in ONE kernel ---- */
+   FusedArgs f;
+   memset(&f, 0, sizeof f);
+   f.text = a.text; f.nbytes = nbytes; f.seg_base = a.seg_base; f.seg_len = a.seg_len; f.first_seg = a.first_seg;
+   f.tile_bytes = tile_bytes;
+   f.ntiles = (uint32_t)(((uint64_t)a.seg_len + tile_bytes - 1) / tile_bytes);
+   stream_ntiles = f.ntiles;
+   f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
+   f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
+   f.tile_cl = ow.tile_cl; f.tile_hits = ow.tile_hits; f.tmp = ow.tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
+   f.wg_hits = ow.wg_hits; f.wg_part = ow.wg_part; f.wg_lastnl = stream_ll ? ow.wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
+   f.tile_dirty = f.wg_lastnl ? ow.tile_dirty : nullptr;
+   f.tile_dmask = f.wg_lastnl ? ow.tile_dmask : nullptr;
+   f.cnt = c;
+   f.clk_probe = (s->prof && s->clk_probe && use_pair) ? s->clk_probe + 4 * sg : nullptr;
+   uint32_t pos_bias = 0;
+   if (use_stream) {
+      f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
+      f.ll_filter = plan.ll_filter ? 1u : 0u;
+      f.skip_thr = plan.skip_thr;
+      if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
+      if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
+      /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
+      uint64_t room = 0xFFFFFFF0ull - a.seg_len;
+      if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;
+      pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room) & ~127u;     /* chunk boundaries stay multiples of the chunk */
+      f.pos_bias = pos_bias;
+   }
+   if (ev) { HIP_TRY(hipEventRecord(ev[0], st), EIO); HIP_TRY(hipEventRecord(ev[1], st), EIO); }
+   unsigned fgrid = fused_grid;                     /* persistent: workgroups without a tile just publish zeros */
+   const unsigned nsl = nslices;
+   f.slice_cap = f.cap_tmp / nsl;
+   if (use_stream) {
+      void *kargs[] = {&f};
+      HIP_TRY(hipLaunchKernel(stream_fn, dim3(fgrid), dim3(64 * (unsigned)nw), kargs, dfa_lds, st), EIO);
+   }
+   else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st, f);
+   else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st, f);
+   if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
+   /* read-length lines behind k_pair / k_stream: the three launches of seeq_order.h; else (long lines, k_direct) the seven of before */
+   const uint32_t order_nb = (f.ntiles + SEEQ_ORDER_BLOCK - 1) / SEEQ_ORDER_BLOCK;
+   order2 = plan.order2 && order_nb <= SEEQ_ORDER_MAX_BLOCKS && 2 * (size_t)order_nb <= s->cap_scan_ws;
+   if (order2) {
+      const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
+      seeq_launch_tiles_post(st, f, (uint32_t)nsl, s->scan_ws, order_nb);
+      seeq_launch_order(rgrid, st, f, (uint32_t)nsl, (const uint32_t *)s->scan_ws, order_nb, s->ent);
+   }
+   else hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, st, f, (uint32_t)nsl);
+   if (!order2 && (want != SEEQDEV_WANT_COUNTLINES || superset)) {
+      launch_scanset(s, st, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
+      const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
+      if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
+      else hipLaunchKernelGGL(k_fused_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line);
+   }
+   a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
+   a.pos_bias = pos_bias;
+   a.tile_dirty = f.tile_dirty; a.tile_dmask = f.tile_dmask; a.stream_ntiles = f.ntiles; a.stream_tile_bytes = tile_bytes;
+   /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
+      read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
+   a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;
+   a.walk_ext = plan.walk_ext;
+   return 0;
+}
+
+/* the generic path's segment: newline index (K0), k_forward<W> (K1), ranks of the hit lines and of the FASTA headers (K2) */
+template <int W>
+static int seg_index_forward(seeqdev_scan *s, const SegRun &r, ScanArgs &a, hipEvent_t *ev)
+{
+   const seeqdev_pattern *pat = r.pat;
+   const int options = r.options, want = r.want, match_opt = r.options & 3, fw = r.fw, ncu = s->ncu;
+   const ScanPlan &plan = r.plan;
+   const bool fasta = (options & SEEQDEV_FASTA) != 0, single = (options & SEEQDEV_SINGLELINE) != 0;
+   const bool use_stream = plan.use_stream, use_pair = plan.use_pair, use_myers = plan.use_myers, filter = plan.filter, use_fused = plan.use_fused, use_direct = plan.use_direct;
+   const bool stream_ll = plan.stream_ll, superset = plan.superset, need_nh = plan.need_nh, nh_is_count = plan.nh_is_count;
+   const int stream_sub = plan.stream_sub, stream_ch = 128, nw = r.nw;
+   const uint32_t tile_bytes = r.tile_bytes;
+   const unsigned fused_grid = r.fused_grid, nslices = r.nslices, grid_lines = r.grid_lines;
+   const void *stream_fn = r.stream_fn;
+   const size_t dfa_lds = r.dfa_lds, nbytes = s->nbytes;
+   Counters *c = s->d_cnt;
+   seeqdev_scan::OnePassWs &ow = s->ow;
+   hipStream_t st = s->stream;
+   (void)pat; (void)want; (void)match_opt; (void)fw; (void)ncu; (void)fasta; (void)single; (void)use_stream; (void)use_pair; (void)use_myers; (void)filter; (void)use_fused;
+   (void)use_direct; (void)stream_ll; (void)superset; (void)need_nh; (void)nh_is_count; (void)stream_sub; (void)stream_ch; (void)nw; (void)tile_bytes; (void)fused_grid;
+   (void)nslices; (void)grid_lines; (void)stream_fn; (void)dfa_lds; (void)nbytes; (void)c; (void)ow; (void)st;
+
+   /* ---- K0: newline index ---- */
+   if (ev) HIP_TRY(hipEventRecord(ev[0], st), EIO);
+   if (single) {
+      hipLaunchKernelGGL(k_single_line, dim3(1), dim3(1), 0, st, a);
+   } else {
+      hipLaunchKernelGGL(k_nl_count, dim3(a.ntiles), dim3(WG), 0, st, a);
+      hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, st, a.tile_cnt, a.ntiles, &c->seg_nlines);
+      hipLaunchKernelGGL(k_index_finalize, dim3(1), dim3(1), 0, st, a);
+      hipLaunchKernelGGL(k_nl_write, dim3(a.ntiles), dim3(WG), 0, st, a);
+   }
+   /* ---- K1: forward scan ---- */
+   if (ev) HIP_TRY(hipEventRecord(ev[1], st), EIO);
+   hipLaunchKernelGGL(k_forward<W>, dim3(grid_lines), dim3(WG), 0, st, a);
+   if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
+   /* ---- K2: ranks of hit lines (and FASTA headers) ---- */
+   launch_scan<1>(s, st, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
+   if (fasta) launch_scan<1>(s, st, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
+   return 0;
+}
+
+/* behind a segment's scan: hit list -> (multi-pattern hand-over | leaders) -> the exact pass (K4) -> the records (K5).  Returns 1 when the segment
+   is finished here (several patterns: multi_post ended it), 0 to go on, < 0 on failure */
+template <int W>
+static int seg_post(seeqdev_scan *s, const SegRun &r, ScanArgs &a, hipEvent_t *ev, bool order2, uint32_t stream_ntiles)
+{
+   const seeqdev_pattern *pat = r.pat;
+   const int options = r.options, want = r.want, match_opt = r.options & 3, fw = r.fw, ncu = s->ncu;
+   const ScanPlan &plan = r.plan;
+   const bool fasta = (options & SEEQDEV_FASTA) != 0, single = (options & SEEQDEV_SINGLELINE) != 0;
+   const bool use_stream = plan.use_stream, use_pair = plan.use_pair, use_myers = plan.use_myers, filter = plan.filter, use_fused = plan.use_fused, use_direct = plan.use_direct;
+   const bool stream_ll = plan.stream_ll, superset = plan.superset, need_nh = plan.need_nh, nh_is_count = plan.nh_is_count;
+   const int stream_sub = plan.stream_sub, stream_ch = 128, nw = r.nw;
+   const uint32_t tile_bytes = r.tile_bytes;
+   const unsigned fused_grid = r.fused_grid, nslices = r.nslices, grid_lines = r.grid_lines;
+   const void *stream_fn = r.stream_fn;
+   const size_t dfa_lds = r.dfa_lds, nbytes = s->nbytes;
+   Counters *c = s->d_cnt;
+   seeqdev_scan::OnePassWs &ow = s->ow;
+   hipStream_t st = s->stream;
+   (void)pat; (void)want; (void)match_opt; (void)fw; (void)ncu; (void)fasta; (void)single; (void)use_stream; (void)use_pair; (void)use_myers; (void)filter; (void)use_fused;
+   (void)use_direct; (void)stream_ll; (void)superset; (void)need_nh; (void)nh_is_count; (void)stream_sub; (void)stream_ch; (void)nw; (void)tile_bytes; (void)fused_grid;
+   (void)nslices; (void)grid_lines; (void)stream_fn; (void)dfa_lds; (void)nbytes; (void)c; (void)ow; (void)st;
+
+   /* ---- K3: compaction ---- */
+   if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, st, a);
+   if (!use_fused) hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, st, a);   /* the fused paths: done by k_fused_post */
+   const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
+   unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
+   if (grid_hits == 0) grid_hits = 1;
+   if (order2) seeq_launch_bounds2(grid_hits, st, a, (const uint4 *)s->ent, s->hit_col);
+   else if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col,
+                                      (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
+   if (s->multi_active) {
+      /* several patterns: the candidate list is the union's -- pattern sets per line, a list per pattern, the exact pass per pattern */
+      { const int mr = multi_post(s, a, st); if (mr > 0) return -2; if (mr) return -1; }      /* (1: a launch was refused -- a scan per pattern) */
+      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 3);
+      if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
+      HIP_TRY(hipGetLastError(), EIO);
+      return 1;
+   }
+   /* long lines, every hit counted: candidates far behind the one before them get a lane of their own (seeq_stream.h, leaders) */
+   const bool lead_best = plan.lead_best, leaders = plan.leaders;
+   const uint32_t lead_wback = a.skip_back > 32u ? a.skip_back : 32u;
+   if (leaders) {
+      if (s->cap_hitlines > s->cap_lead) {
+         if (ws_alloc((void **)&s->lead_fidx, s->cap_hitlines * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->lead_flag, s->cap_hitlines * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->lead_wend, s->cap_hitlines * sizeof(uint32_t))) return -1;
+         if (ws_alloc((void **)&s->lead_key, s->cap_hitlines * sizeof(unsigned long long))) return -1;
+         s->cap_lead = s->cap_hitlines;
+      }
+      const unsigned nbl = (unsigned)(s->cap_hitlines / LEAD_BLOCK + 1);
+      hipLaunchKernelGGL(k_lead_reduce, dim3(nbl), dim3(256), 0, st, a, s->scan_ws);
+      hipLaunchKernelGGL(k_lead_top, dim3(1), dim3(256), 0, st, a, s->scan_ws);
+      hipLaunchKernelGGL(k_lead_apply, dim3(nbl), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->scan_ws, s->lead_fidx, s->lead_flag, ow.tmp, lead_wback, lead_best ? s->lead_key : (unsigned long long *)nullptr);
+      a.walk_end = s->lead_wend;
+      /* SQ_BEST: COUNT has to walk every group itself (and leave each group's best hit in the cache) instead of trusting the hit
+         list and leaving the scan to EMIT, one lane per line */
+      if (lead_best) a.filter = 1u;
+      hipLaunchKernelGGL(k_lead_commit, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col, (const uint4 *)ow.tmp);
+   }
+   const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
+   uint4 *ecache = (use_fused && need_nh && want == SEEQDEV_WANT_RECORDS) ? ow.tmp : nullptr;   /* COUNT -> EMIT */
+   /* (Tried behind k_pair: a lane-queue kernel -- a wave owns 256 .. 512 hit-list entries staged in LDS and a lane that has
+      finished its line takes the next entry at the next 64-byte block -- 22 % fewer instructions than k_exact1 COUNT, and
+      slower, 296 against 257 us per segment: at 4 waves per SIMD the per-block loads of a lane are not hidden.  Not kept;
+      tag r03-experiment-overlap-postpass holds it, profiles/r03/verify_ab.txt the numbers.) */
+   /* ---- K4: hits per hit line ---- */
+   /* behind the filters (every hit line is a candidate) on text where no byte is skipped: k_verify (seeq_verify.h) -- the lean
+      two-phase exact pass with the scan of its counts inside; the EMIT pass behind it ends the segment */
+   bool emitted = false;                                /* the records are out (k_emit1) */
+   const bool verify = plan.verify;
+   const int seg_flags = (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0);
+   if (verify) {
+      const bool count_any = want != SEEQDEV_WANT_COUNTMATCH && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+      const int var = (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST) ? VERIFY_BEST : count_any ? VERIFY_ANY : VERIFY_ALL;
+      a.nh_sum = s->nh_sum;
+      a.nz_sum = superset && nh_is_count ? s->nh_sum + (s->cap_hitlines / 256 + 2) : nullptr;
+      /* k_nh_top ends the segment unless k_exact1's EMIT pass follows (SQ_ALL records): k_emit1 works from what k_nh_top saved */
+      a.fin = (want == SEEQDEV_WANT_RECORDS && var == VERIFY_ALL) ? 0u : 1u + (uint32_t)seg_flags;
+      /* behind a partition filter every part of an occurrence reports: more than half of the entries are repeats of their line, and
+         k_verify packs them away, 512 entries per workgroup (seeq_verify.h); behind a prefix automaton it does not pay */
+      a.vrange = (use_pair ? pat->pair_parts > 1 : pat->sdfa_parts > 1) ? 512u : 0u;
+      seeq_launch_verify(fw, var, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
+      if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
+      else if (want == SEEQDEV_WANT_RECORDS && ecache)      /* SQ_ALL: the first records from the cache, the others from the overflow lists */
+         seeq_launch_emit_all(fw, grid_hits, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
+      emitted = want == SEEQDEV_WANT_RECORDS && (var != VERIFY_ALL || ecache);
+   }
+   else if (need_nh) {
+      if (use_fused) {
+         const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
+   #define SEEQ_COUNT1(WW, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, WW, -1, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
+         if (fw == 2) { if (a.stream_ch) SEEQ_COUNT1(2, true); else SEEQ_COUNT1(2, false); }
+         else { if (a.stream_ch) SEEQ_COUNT1(1, true); else SEEQ_COUNT1(1, false); }
+   #undef SEEQ_COUNT1
+      }
+      else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, st, a);
+      /* lines with >= 1 verified hit: with 0/1 verdicts that is the scan total (seg_nrec) -- no extra pass */
+      if (leaders) {
+         hipLaunchKernelGGL(k_lead_check, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->lead_flag, lead_wback);
+         if (lead_best) {
+            hipLaunchKernelGGL(k_lead_best, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_key, (const uint4 *)ecache, 0);
+            hipLaunchKernelGGL(k_lead_best, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_key, (const uint4 *)ecache, 1);
+         }
+         else hipLaunchKernelGGL(k_lead_lines, dim3(grid_hits < 512 ? grid_hits : 512), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_flag);
+      }
+      else if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
+      launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
+   }
+   /* ---- K5: records ---- */
+   if (want == SEEQDEV_WANT_RECORDS && !emitted) {
+      if (!verify) hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);      /* (k_verify's last workgroup did) */
+      if (use_fused) {
+         const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
+         const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
+   #define SEEQ_EMIT1(WW, OO, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
+         if (a.stream_ch) {
+            if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST, true); else SEEQ_EMIT1(2, -1, true); }
+            else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST, true); else SEEQ_EMIT1(1, -1, true); }
+         } else {
+            if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST, false); else SEEQ_EMIT1(2, -1, false); }
+            else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST, false); else SEEQ_EMIT1(1, -1, false); }
+         }
+   #undef SEEQ_EMIT1
+      }
+      else {
+         hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, st, a);
+         hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, st, a);    /* k_exact1 writes them itself */
+      }
+   }
+   return 0;
+}
+
+template <int W>
+static int run_segments(seeqdev_scan *s)
+{
+   Counters *c = s->d_cnt;
+   HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), s->stream), EIO);
+   SegRun r;
+   memset(&r, 0, sizeof r);
+   { const int rc = run_setup(s, r); if (rc) return rc; }
+   const seeqdev_pattern *pat = r.pat;
+   const ScanPlan &plan = r.plan;
+   const int options = r.options, want = r.want;
+   const size_t nbytes = s->nbytes, seg_bytes = r.seg_bytes, nseg = r.nseg;
+   const bool use_stream = plan.use_stream, use_fused = plan.use_fused, filter = plan.filter, superset = plan.superset, need_nh = plan.need_nh, nh_is_count = plan.nh_is_count;
    for (size_t sg = 0; sg < nseg; sg++) {
+
       hipEvent_t *ev = s->prof ? s->ev + 4 * sg : NULL;
       uint32_t stream_ntiles = 0;
       bool order2 = false;                                /* the hit list is made by seeq_order.h's kernels */
-      seeqdev_scan::OnePassWs &ow = s->ow;
       hipStream_t st = s->stream;
       ScanArgs a;
       memset(&a, 0, sizeof a);
@@ -1454,196 +1727,12 @@ static int run_segments(seeqdev_scan *s)
       a.window_ok = plan.window_ok ? 1u : 0u;
       a.cnt = c;
 
-      if (use_fused) {
-         /* ---- fused path: newline index + forward scan + per-tile compaction in ONE kernel ---- */
-         FusedArgs f;
-         memset(&f, 0, sizeof f);
-         f.text = a.text; f.nbytes = nbytes; f.seg_base = a.seg_base; f.seg_len = a.seg_len; f.first_seg = a.first_seg;
-         f.tile_bytes = tile_bytes;
-         f.ntiles = (uint32_t)(((uint64_t)a.seg_len + tile_bytes - 1) / tile_bytes);
-         stream_ntiles = f.ntiles;
-         f.eqtab = s->d_eqtab; f.peq = pat->d_peq;
-         f.m = pat->wlen; f.tau = pat->tau; f.options = options; f.want = want;
-         f.tile_cl = ow.tile_cl; f.tile_hits = ow.tile_hits; f.tmp = ow.tmp; f.cap_tmp = (uint32_t)s->cap_hitlines;
-         f.wg_hits = ow.wg_hits; f.wg_part = ow.wg_part; f.wg_lastnl = stream_ll ? ow.wg_lastnl : nullptr;   /* only the window walk (long lines) needs it */
-         f.tile_dirty = f.wg_lastnl ? ow.tile_dirty : nullptr;
-         f.tile_dmask = f.wg_lastnl ? ow.tile_dmask : nullptr;
-         f.cnt = c;
-         f.clk_probe = (s->prof && s->clk_probe && use_pair) ? s->clk_probe + 4 * sg : nullptr;
-         uint32_t pos_bias = 0;
-         if (use_stream) {
-            f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
-            f.ll_filter = plan.ll_filter ? 1u : 0u;
-            f.skip_thr = plan.skip_thr;
-            if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
-            if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
-            /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
-            uint64_t room = 0xFFFFFFF0ull - a.seg_len;
-            if (room > ((uint64_t)1 << 30)) room = (uint64_t)1 << 30;
-            pos_bias = (uint32_t)(a.seg_base < room ? a.seg_base : room) & ~127u;     /* chunk boundaries stay multiples of the chunk */
-            f.pos_bias = pos_bias;
-         }
-         if (ev) { HIP_TRY(hipEventRecord(ev[0], st), EIO); HIP_TRY(hipEventRecord(ev[1], st), EIO); }
-         unsigned fgrid = fused_grid;                     /* persistent: workgroups without a tile just publish zeros */
-         const unsigned nsl = nslices;
-         f.slice_cap = f.cap_tmp / nsl;
-         if (use_stream) {
-            void *kargs[] = {&f};
-            HIP_TRY(hipLaunchKernel(stream_fn, dim3(fgrid), dim3(64 * (unsigned)nw), kargs, dfa_lds, st), EIO);
-         }
-         else if (use_direct && fw == 2) hipLaunchKernelGGL((k_direct<4, 2>), dim3(fgrid), dim3(256), 0, st, f);
-         else hipLaunchKernelGGL((k_direct<4, 1>), dim3(fgrid), dim3(256), 0, st, f);
-         if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
-         /* read-length lines behind k_pair / k_stream: the three launches of seeq_order.h; else (long lines, k_direct) the seven of before */
-         const uint32_t order_nb = (f.ntiles + SEEQ_ORDER_BLOCK - 1) / SEEQ_ORDER_BLOCK;
-         order2 = plan.order2 && order_nb <= SEEQ_ORDER_MAX_BLOCKS && 2 * (size_t)order_nb <= s->cap_scan_ws;
-         if (order2) {
-            const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
-            seeq_launch_tiles_post(st, f, (uint32_t)nsl, s->scan_ws, order_nb);
-            seeq_launch_order(rgrid, st, f, (uint32_t)nsl, (const uint32_t *)s->scan_ws, order_nb, s->ent);
-         }
-         else hipLaunchKernelGGL(k_fused_post, dim3(1), dim3(256), 0, st, f, (uint32_t)nsl);
-         if (!order2 && (want != SEEQDEV_WANT_COUNTLINES || superset)) {
-            launch_scanset(s, st, f.tile_hits, f.tile_cl, f.tile_dirty, f.ntiles, nullptr, nullptr, f.tile_dirty ? &c->seg_dirty_tiles : nullptr);
-            const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
-            if (use_stream) hipLaunchKernelGGL(k_stream_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line, s->nh, s->hit_col);
-            else hipLaunchKernelGGL(k_fused_reorder, dim3(rgrid), dim3(256), 0, st, f, (uint32_t)nsl, s->hit_start, s->hit_line);
-         }
-         a.seg_base -= pos_bias;                           /* the exact pass addresses lines through hit_start */
-         a.pos_bias = pos_bias;
-         a.tile_dirty = f.tile_dirty; a.tile_dmask = f.tile_dmask; a.stream_ntiles = f.ntiles; a.stream_tile_bytes = tile_bytes;
-         /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
-            read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
-         a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;
-         a.walk_ext = plan.walk_ext;
-      } else {
-      /* ---- K0: newline index ---- */
-      if (ev) HIP_TRY(hipEventRecord(ev[0], st), EIO);
-      if (single) {
-         hipLaunchKernelGGL(k_single_line, dim3(1), dim3(1), 0, st, a);
-      } else {
-         hipLaunchKernelGGL(k_nl_count, dim3(a.ntiles), dim3(WG), 0, st, a);
-         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(WG), 0, st, a.tile_cnt, a.ntiles, &c->seg_nlines);
-         hipLaunchKernelGGL(k_index_finalize, dim3(1), dim3(1), 0, st, a);
-         hipLaunchKernelGGL(k_nl_write, dim3(a.ntiles), dim3(WG), 0, st, a);
-      }
-      /* ---- K1: forward scan ---- */
-      if (ev) HIP_TRY(hipEventRecord(ev[1], st), EIO);
-      hipLaunchKernelGGL(k_forward<W>, dim3(grid_lines), dim3(WG), 0, st, a);
-      if (ev) HIP_TRY(hipEventRecord(ev[2], st), EIO);
-      /* ---- K2: ranks of hit lines (and FASTA headers) ---- */
-      launch_scan<1>(s, st, a.hitmask, a.wave_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nhitlines);
-      if (fasta) launch_scan<1>(s, st, a.hdrmask, a.hdr_off, s->cap_chunks, &c->seg_nlines, 63u, 6u, &c->seg_nheaders);
-      }
+      if (use_fused) { if (seg_onepass(s, r, a, sg, ev, order2, stream_ntiles)) return -1; }
+      else if (seg_index_forward<W>(s, r, a, ev)) return -1;
       if (want != SEEQDEV_WANT_COUNTLINES || superset) {
-         /* ---- K3: compaction ---- */
-         if (!use_fused) hipLaunchKernelGGL(k_compact, dim3(grid_lines), dim3(WG), 0, st, a);
-         if (!use_fused) hipLaunchKernelGGL(k_seg_mid, dim3(1), dim3(1), 0, st, a);   /* the fused paths: done by k_fused_post */
-         const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
-         unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
-         if (grid_hits == 0) grid_hits = 1;
-         if (order2) seeq_launch_bounds2(grid_hits, st, a, (const uint4 *)s->ent, s->hit_col);
-         else if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col,
-                                            (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
-         if (s->multi_active) {
-            /* several patterns: the candidate list is the union's -- pattern sets per line, a list per pattern, the exact pass per pattern */
-            { const int mr = multi_post(s, a, st); if (mr > 0) return -2; if (mr) return -1; }      /* (1: a launch was refused -- a scan per pattern) */
-            hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, 3);
-            if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
-            HIP_TRY(hipGetLastError(), EIO);
-            continue;
-         }
-         /* long lines, every hit counted: candidates far behind the one before them get a lane of their own (seeq_stream.h, leaders) */
-         const bool lead_best = plan.lead_best, leaders = plan.leaders;
-         const uint32_t lead_wback = a.skip_back > 32u ? a.skip_back : 32u;
-         if (leaders) {
-            if (s->cap_hitlines > s->cap_lead) {
-               if (ws_alloc((void **)&s->lead_fidx, s->cap_hitlines * sizeof(uint32_t))) return -1;
-               if (ws_alloc((void **)&s->lead_flag, s->cap_hitlines * sizeof(uint32_t))) return -1;
-               if (ws_alloc((void **)&s->lead_wend, s->cap_hitlines * sizeof(uint32_t))) return -1;
-               if (ws_alloc((void **)&s->lead_key, s->cap_hitlines * sizeof(unsigned long long))) return -1;
-               s->cap_lead = s->cap_hitlines;
-            }
-            const unsigned nbl = (unsigned)(s->cap_hitlines / LEAD_BLOCK + 1);
-            hipLaunchKernelGGL(k_lead_reduce, dim3(nbl), dim3(256), 0, st, a, s->scan_ws);
-            hipLaunchKernelGGL(k_lead_top, dim3(1), dim3(256), 0, st, a, s->scan_ws);
-            hipLaunchKernelGGL(k_lead_apply, dim3(nbl), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->scan_ws, s->lead_fidx, s->lead_flag, ow.tmp, lead_wback, lead_best ? s->lead_key : (unsigned long long *)nullptr);
-            a.walk_end = s->lead_wend;
-            /* SQ_BEST: COUNT has to walk every group itself (and leave each group's best hit in the cache) instead of trusting the hit
-               list and leaving the scan to EMIT, one lane per line */
-            if (lead_best) a.filter = 1u;
-            hipLaunchKernelGGL(k_lead_commit, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col, (const uint4 *)ow.tmp);
-         }
-         const uint32_t *hcol = use_stream ? s->hit_col : nullptr;      /* first-hit columns: the exact pass may skip ahead */
-         uint4 *ecache = (use_fused && !generic_exact && need_nh && want == SEEQDEV_WANT_RECORDS) ? ow.tmp : nullptr;   /* COUNT -> EMIT */
-         /* (Tried behind k_pair: a lane-queue kernel -- a wave owns 256 .. 512 hit-list entries staged in LDS and a lane that has
-            finished its line takes the next entry at the next 64-byte block -- 22 % fewer instructions than k_exact1 COUNT, and
-            slower, 296 against 257 us per segment: at 4 waves per SIMD the per-block loads of a lane are not hidden.  Not kept;
-            tag r03-experiment-overlap-postpass holds it, profiles/r03/verify_ab.txt the numbers.) */
-         /* ---- K4: hits per hit line ---- */
-         /* behind the filters (every hit line is a candidate) on text where no byte is skipped: k_verify (seeq_verify.h) -- the lean
-            two-phase exact pass with the scan of its counts inside; the EMIT pass behind it ends the segment */
-         bool emitted = false;                                /* the records are out (k_emit1) */
-         const bool verify = plan.verify;
-         const int seg_flags = (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0);
-         if (verify) {
-            const bool count_any = want != SEEQDEV_WANT_COUNTMATCH && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
-            const int var = (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST) ? VERIFY_BEST : count_any ? VERIFY_ANY : VERIFY_ALL;
-            a.nh_sum = s->nh_sum;
-            a.nz_sum = superset && nh_is_count ? s->nh_sum + (s->cap_hitlines / 256 + 2) : nullptr;
-            /* k_nh_top ends the segment unless k_exact1's EMIT pass follows (SQ_ALL records): k_emit1 works from what k_nh_top saved */
-            a.fin = (want == SEEQDEV_WANT_RECORDS && var == VERIFY_ALL) ? 0u : 1u + (uint32_t)seg_flags;
-            /* behind a partition filter every part of an occurrence reports: more than half of the entries are repeats of their line, and
-               k_verify packs them away, 512 entries per workgroup (seeq_verify.h); behind a prefix automaton it does not pay */
-            a.vrange = (use_pair ? pat->pair_parts > 1 : pat->sdfa_parts > 1) ? 512u : 0u;
-            seeq_launch_verify(fw, var, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
-            if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
-            else if (want == SEEQDEV_WANT_RECORDS && ecache && !s->knobs.old_emit_all)      /* SQ_ALL: the first records from the cache, the others from the overflow lists */
-               seeq_launch_emit_all(fw, grid_hits, grid_hits, st, a, (const uint32_t *)s->d_eqtab, hcol, ecache);
-            emitted = want == SEEQDEV_WANT_RECORDS && (var != VERIFY_ALL || (ecache && !s->knobs.old_emit_all));
-         }
-         else if (need_nh) {
-            if (use_fused && !generic_exact) {
-               const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
-#define SEEQ_COUNT1(WW, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, WW, -1, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
-               if (fw == 2) { if (a.stream_ch) SEEQ_COUNT1(2, true); else SEEQ_COUNT1(2, false); }
-               else { if (a.stream_ch) SEEQ_COUNT1(1, true); else SEEQ_COUNT1(1, false); }
-#undef SEEQ_COUNT1
-            }
-            else hipLaunchKernelGGL((k_exact<W, SQ_MODE_COUNT>), dim3(grid_hits), dim3(WG), 0, st, a);
-            /* lines with >= 1 verified hit: with 0/1 verdicts that is the scan total (seg_nrec) -- no extra pass */
-            if (leaders) {
-               hipLaunchKernelGGL(k_lead_check, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->hit_col, (const uint32_t *)s->lead_flag, lead_wback);
-               if (lead_best) {
-                  hipLaunchKernelGGL(k_lead_best, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_key, (const uint4 *)ecache, 0);
-                  hipLaunchKernelGGL(k_lead_best, dim3(grid_hits), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_key, (const uint4 *)ecache, 1);
-               }
-               else hipLaunchKernelGGL(k_lead_lines, dim3(grid_hits < 512 ? grid_hits : 512), dim3(256), 0, st, a, (const uint32_t *)s->lead_fidx, s->lead_flag);
-            }
-            else if (superset && nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
-            launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
-         }
-         /* ---- K5: records ---- */
-         if (want == SEEQDEV_WANT_RECORDS && !emitted) {
-            if (!verify) hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);      /* (k_verify's last workgroup did) */
-            if (use_fused && !generic_exact) {
-               const uint32_t *eqp = (const uint32_t *)s->d_eqtab;
-               const int mo = (options & 3) == SQ_COUNT ? SQ_FIRST : (options & 3);
-#define SEEQ_EMIT1(WW, OO, WK) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, WW, OO, WK>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache)
-               if (a.stream_ch) {
-                  if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST, true); else SEEQ_EMIT1(2, -1, true); }
-                  else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST, true); else SEEQ_EMIT1(1, -1, true); }
-               } else {
-                  if (fw == 2) { if (mo == SQ_BEST) SEEQ_EMIT1(2, SQ_BEST, false); else SEEQ_EMIT1(2, -1, false); }
-                  else { if (mo == SQ_BEST) SEEQ_EMIT1(1, SQ_BEST, false); else SEEQ_EMIT1(1, -1, false); }
-               }
-#undef SEEQ_EMIT1
-            }
-            else {
-               hipLaunchKernelGGL((k_exact<W, SQ_MODE_EMIT>), dim3(grid_hits), dim3(WG), 0, st, a);
-               hipLaunchKernelGGL(k_rec_offsets, dim3(grid_hits), dim3(WG), 0, st, a);    /* k_exact1 writes them itself */
-            }
-         }
+         const int pr = seg_post<W>(s, r, a, ev, order2, stream_ntiles);
+         if (pr < 0) return pr;
+         if (pr > 0) continue;
       }
       if (!a.fin) hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, (need_nh ? 1 : 0) | (superset && !nh_is_count ? 2 : 0));      /* (a.fin: the segment's last launch ended it) */
       if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
@@ -1671,7 +1760,7 @@ static int run_packed(seeqdev_scan *s)
    const uint32_t L = b.read_len;
    /* the exact pass reads the candidates' windows from the batch itself (seeq_verify_packed.h) -- no staging text -- unless SQ_ALL records are
       wanted (k_emit_all recovers their starts from text) or the round-3 exact pass is asked for */
-   const bool direct = !s->knobs.old_verify && !s->knobs.packed_stage && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
+   const bool direct = !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
    const uint32_t pitch = (L + 1u + 15u) & ~15u;            /* bytes per line of the staging text (L <= 256: the newline's word exists for every lane count up to 17; 16 lanes serve L <= 255, L = 256 below) */
    /* workspace: per read of a segment, per candidate */
    size_t PACKED_SEG_READS = s->pk_seg_reads;
@@ -1703,30 +1792,7 @@ static int run_packed(seeqdev_scan *s)
       if (nb > s->cap_scan_ws) { if (ws_alloc((void **)&s->scan_ws, nb * sizeof(uint32_t))) return -1; s->cap_scan_ws = nb; }
    }
    /* EQ tables of the exact pass (as run_segments makes them) */
-   if (s->eq_pat_id != pat->id || s->eq_options != options) {
-      const int Wp = pat->words;
-      for (int dir = 0; dir < 2; dir++)
-         for (int bb = 0; bb < 256; bb++) {
-            const uint8_t cls = sq_class_of((uint32_t)bb, options);
-            uint64_t v;
-            if (cls < 5) {
-               const uint32_t *q = pat->h_peq + (dir * 5 + cls) * Wp;
-               const uint64_t col = (uint64_t)q[0] | (Wp > 1 ? (uint64_t)q[1] << 32 : 0);
-               v = col << (32 * fw - pat->wlen);
-            } else {
-               v = cls == SQC_TERM ? FUSED_FLAG_TERM : FUSED_FLAG_SKIP;
-            }
-            uint32_t *dst = s->h_eqtab + (size_t)(dir * 256 + bb) * fw;
-            dst[0] = (uint32_t)v;
-            if (fw == 2) dst[1] = (uint32_t)(v >> 32);
-         }
-      memcpy(s->h_eqtab + (size_t)512 * fw, s->h_eqtab, (size_t)256 * fw * sizeof(uint32_t));
-      s->h_eqtab[(size_t)512 * fw + (size_t)'\n' * fw] |= 3u;
-      HIP_TRY(hipMemcpyAsync(s->d_eqtab, s->h_eqtab, (size_t)768 * fw * sizeof(uint32_t), hipMemcpyHostToDevice, st), EIO);
-      HIP_TRY(hipStreamSynchronize(st), EIO);
-      s->eq_pat_id = pat->id;
-      s->eq_options = options;
-   }
+   if (eq_tables_upload(s, pat, options, fw)) return -1;
    HIP_TRY(hipMemsetAsync(c, 0, sizeof(Counters), st), EIO);
    s->clk_valid = false;                                    /* (the packed walk reads no clock) */
    /* four bases per gather over the quad table (seeq_dfa.h section 3b) when the pattern has one and the false candidates it adds
@@ -1803,8 +1869,9 @@ static int run_packed(seeqdev_scan *s)
       const uint32_t *hcol = s->hit_col;
       uint4 *ecache = want == SEEQDEV_WANT_RECORDS ? s->ow.tmp : nullptr;
       const int seg_flags = 1 | (!nh_is_count ? 2 : 0);
-      if (!s->knobs.old_verify) {
-         /* the exact pass of k_pair's candidates (seeq_verify.h): the staging text holds ASCII lines, no byte of them is skipped */
+      {
+         /* the exact pass of the candidates: k_verify_packed on the batch itself, or (SQ_ALL records) k_verify over the staging text -- ASCII lines,
+            no byte of them is skipped (seeq_verify.h) */
          const bool count_any = want != SEEQDEV_WANT_COUNTMATCH && !(want == SEEQDEV_WANT_RECORDS && match_opt == SQ_ALL);
          const int var = (want == SEEQDEV_WANT_RECORDS && match_opt == SQ_BEST) ? VERIFY_BEST : count_any ? VERIFY_ANY : VERIFY_ALL;
          a.nh_sum = s->nh_sum;
@@ -1815,25 +1882,9 @@ static int run_packed(seeqdev_scan *s)
          else seeq_launch_verify(fw, var, grid_hits, st, a, eqp, hcol, ecache);
          if (want == SEEQDEV_WANT_RECORDS && var != VERIFY_ALL) seeq_launch_emit1(grid_hits, st, a, ecache);
          else if (want == SEEQDEV_WANT_RECORDS) {
-            if (!s->knobs.old_emit_all) seeq_launch_emit_all(fw, grid_hits, grid_hits, st, a, eqp, hcol, ecache);
-            else if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-            else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
+            seeq_launch_emit_all(fw, grid_hits, grid_hits, st, a, eqp, hcol, ecache);
             hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, seg_flags);
          }
-      } else {
-      if (fw == 2) hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-      else hipLaunchKernelGGL((k_exact1<SQ_MODE_COUNT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-      if (nh_is_count) hipLaunchKernelGGL(k_count_nonzero, dim3(grid_hits < 512 ? grid_hits : 512), dim3(WG), 0, st, a);
-      launch_scan<0>(s, st, a.nh, a.nh, s->cap_hitlines, &c->seg_nhitlines, 0u, 0u, &c->seg_nrec);
-      if (want == SEEQDEV_WANT_RECORDS) {
-         hipLaunchKernelGGL(k_rec_check, dim3(1), dim3(1), 0, st, a);
-         const int mo = match_opt == SQ_COUNT ? SQ_FIRST : match_opt;
-         if (fw == 2) { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-                        else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 2, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
-         else { if (mo == SQ_BEST) hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, SQ_BEST, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache);
-                else hipLaunchKernelGGL((k_exact1<SQ_MODE_EMIT, 1, -1, false>), dim3(grid_hits), dim3(WG), 0, st, a, eqp, hcol, ecache); }
-      }
-      hipLaunchKernelGGL(k_seg_end, dim3(1), dim3(1), 0, st, a, seg_flags);
       }
       if (ev) HIP_TRY(hipEventRecord(ev[3], st), EIO);
       HIP_TRY(hipGetLastError(), EIO);

@@ -21,8 +21,9 @@
  *     a chain reports its own first pair as a candidate (the warm-up states OR-ed together, bit 0 tested once).
  *   - What else a tile needs from its text -- the alphabet check and the newline masks -- is computed word by word
  *     BETWEEN a step's two gathers and the instructions that need their results, i.e. in the shadow of the LDS latency
- *     the walk is made of (fast check: upper case A C G T N and newlines only -- v_perm + v_sad_u8 per word; a tile that
- *     fails it takes the exact check of k_stream over its text fetched again; newline flags: v_perm + v_dot4 per word).
+ *     the walk is made of (fast check: upper case A C G T N and newlines only -- v_perm + v_sad_u8 per word; newline flags:
+ *     v_perm + v_dot4 per word; a wave that meets a tile which fails the check walks on without both and makes exact newline
+ *     masks from the tile's registers: DM in the kernel, round 5 -- FASTQ records stay on this kernel).
  *     With the gathers halved the kernel is no longer held by the LDS unit alone (60 % busy, of which half bank conflicts):
  *     it sits 1.2 - 1.4 x above both the memory system's floor and the gather unit's at once.
  *
@@ -40,7 +41,8 @@
  * Everything k_pair reports is a CANDIDATE (ScanArgs.filter): the exact pass (k_exact1) verifies each one -- under
  * SQ_FAIL and SQ_CONVERT alike, since aliasing is harmless for a superset (SQ_IGNORE, where a skipped byte stretches a
  * match, stays with k_stream).  The alphabet check and Counters.dirty are kept: when the text holds a byte that could
- * end a line early, the exact pass starts at the beginning of the line instead of before the candidate.
+ * end a line early, the exact pass looks at the bytes between the line's start and a candidate's window before it trusts
+ * the window (verify_prefix_dirty, seeq_verify.h).
  * Bookkeeping (newline masks, line ranks, line starts, slices, FASTA headers) is k_stream's.
  */
 #ifndef SEEQ_PAIR_H_
@@ -51,7 +53,7 @@
 #define PAIR_X2(K) \
    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K : "=v"(ada) : "v"(sa), "v"(ta)); \
    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #K : "=v"(adb) : "v"(sb), "v"(tb)); \
-   if (EXP != 2) { sa = *(stream_lds_cu16 *)(uintptr_t)ada; sb = *(stream_lds_cu16 *)(uintptr_t)adb; } else { sa = ada & 0x7FE0u; sb = adb & 0x7FE0u; } \
+   sa = *(stream_lds_cu16 *)(uintptr_t)ada; sb = *(stream_lds_cu16 *)(uintptr_t)adb; \
    __builtin_amdgcn_sched_barrier(0);
 
 /* the two pair indices of a text word, in bytes 1 and 3: {code of the first byte, code of the second} << 1 */
@@ -74,7 +76,6 @@ __device__ __forceinline__ void pair_chk(uint32_t w, uint32_t &bad, uint32_t &nm
 }
 
 /* four warm-up bytes of each chain: walk; the states of a chain are OR-ed into its `seen` (bit 0: the walk accepted) */
-template <int EXP>
 __device__ __forceinline__ void pair_warm4x2(uint32_t &sa, uint32_t wa, uint32_t &sb, uint32_t wb, uint32_t &seena, uint32_t &seenb)
 {
    const uint32_t ta = pair_prep(wa), tb = pair_prep(wb);
@@ -86,7 +87,7 @@ __device__ __forceinline__ void pair_warm4x2(uint32_t &sa, uint32_t wa, uint32_t
 
 /* four owned bytes of each chain: walk + pair masks (first pair of a chain ends up in bit 0), and the per-word checks of
  * both words between the gathers and their use */
-template <int EXP, bool CHK>
+template <bool CHK>
 __device__ __forceinline__ void pair_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &nma, uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t &nmb,
                                             uint32_t &bad, bool first_of_two)
 {
@@ -96,14 +97,14 @@ __device__ __forceinline__ void pair_own4x2(uint32_t &sa, uint32_t wa, uint32_t 
       behind the walk, with every state and every intermediate kept -- spilled -- until then) */
    PAIR_X2(1)
    asm volatile("" : "+v"(wa));
-   if (EXP != 4 && CHK) pair_chk(wa, bad, nma, first_of_two);
+   if (CHK) pair_chk(wa, bad, nma, first_of_two);
    asm volatile("" : "+v"(bad), "+v"(nma));
    __builtin_amdgcn_sched_barrier(0);
    hma = __builtin_amdgcn_alignbit(sa, hma, 1); hmb = __builtin_amdgcn_alignbit(sb, hmb, 1);
    asm volatile("" : "+v"(hma), "+v"(hmb));
    PAIR_X2(3)
    asm volatile("" : "+v"(wb));
-   if (EXP != 4 && CHK) pair_chk(wb, bad, nmb, first_of_two);
+   if (CHK) pair_chk(wb, bad, nmb, first_of_two);
    asm volatile("" : "+v"(bad), "+v"(nmb));
    __builtin_amdgcn_sched_barrier(0);
    hma = __builtin_amdgcn_alignbit(sa, hma, 1); hmb = __builtin_amdgcn_alignbit(sb, hmb, 1);
@@ -116,71 +117,25 @@ __device__ __forceinline__ uint32_t pair_word8(const fused_v4u &p, const fused_v
    return k == 0 ? p.x : k == 1 ? p.y : k == 2 ? p.z : k == 3 ? p.w : k == 4 ? q.x : k == 5 ? q.y : k == 6 ? q.z : q.w;
 }
 
-/* 16 bytes of text at byte `off` of the buffer (bytes at or beyond `lim` read as '\n': only the segment's last tile) */
-__device__ __forceinline__ fused_v4u pair_load16(const FusedArgs &a, uint64_t off, uint64_t lim, bool partial)
-{
-   if (!partial) return *reinterpret_cast<const fused_v4u_unaligned *>(a.text + off);
-   return dfa_load16(a.text, off, lim);
-}
-
 typedef uint32_t pair_u32_unaligned __attribute__((aligned(1)));
-
-/* PF (round 4, the experiment the round-3 review asked for; SEEQ_PAIR_PF=1): the NEXT tile's text requested before the walk of this one,
- * straight into LDS (global_load_lds_dwordx4: no registers, the wave's eight 1 KiB rows + a row for the words before the tile), read back
- * into the text registers when its turn comes.  The staging rows sit above the table: 55 KB + 12 waves x 8.25 KB = 154 KB, one workgroup of
- * 12 waves per CU -- 24 walks per CU where the register kernel holds 64.
- * Measured (100 M x 150 bp, ms per 3.75 GiB launch, the buffer's fast / slow pages -- DESIGN.md section 5 (i)):
- *    the register kernel                                                0.77 / 0.92
- *    PF, every lane requesting the pieces of ITS 128-byte line          0.95 / 1.06   (the register loads' pattern: there the eight requests
- *                                                                                      of a lane are merged into one fetch of its line, a DMA's are not)
- *    PF, coalesced requests (1 KiB per instruction, source swizzle)     0.78 / 0.875
- * So with full overlap of the loads and 3/8 of the walks in flight it ties the register kernel on fast pages and is 5 % ahead on slow ones:
- * not adopted (the default stays the register kernel), kept as a tested variant.  (A thirteenth wave -- the words before the tile by an ordinary
- * load into a register of their own, 8 KB of staging per wave -- was no faster: 0.865 - 0.945 beside the register kernel's 0.85 - 0.93 on one box.) */
-#define PAIR_STAGE_BYTES 8448u
-typedef __attribute__((address_space(3))) const fused_v4u pair_lds_cv4u;
-__device__ __forceinline__ void pair_glds16(const void *gsrc, uint32_t lds_dst)
-{
-   uint32_t keep;
-   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void pair_glds4(const void *gsrc, uint32_t lds_dst)
-{
-   uint32_t keep;
-   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-/* the whole tile at t0 (not the segment's cut-short last one) on its way into the wave's staging rows */
-__device__ __forceinline__ void pair_prefetch_tile(const FusedArgs &a, uint64_t t0, uint32_t sbase)
-{
-   uint32_t lid;
-   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
-   /* COALESCED requests: instruction q moves the tile's q-th KiB, lane l the 16 bytes at slot l of it -- but inside every 128-byte line
-      (eight slots) the pieces are rotated by the line's number (slot = 8 * line + (piece ^ line)), so that the read-back of piece r by the
-      eight lanes of a row group -- one line each -- touches eight different bank groups (the swizzle sits on the SOURCE address: the
-      LDS image of an LDS-DMA is lane-linear) */
-   const uint8_t *p = a.text + t0 + (uint64_t)((lid >> 3) * 128u + (((lid & 7u) ^ (lid >> 3)) & 7u) * 16u);
-#pragma unroll
-   for (int q = 0; q < 8; q++) pair_glds16(p + 1024 * q, sbase + 1024u * (uint32_t)q);
-   pair_glds4(a.text + (t0 >= 32 ? t0 - 32 : 0) + ((lid & 7u) << 2), sbase + 8192u);
-}
 
 /* The walk of one tile: warm-up of both chains, then their 64 owned bytes each; CHK: the fast alphabet check and the fast newline masks
  * ride along (nmask[], bad); else the caller makes the masks. */
-template <int WU, int EXP, bool CHK>
+template <int WU, bool CHK>
 __device__ __forceinline__ void pair_walk(const fused_v4u (&v)[8], uint32_t halo, bool halo_nl, uint32_t (&hm)[2], uint32_t (&nmask)[4], uint32_t &tile_bad)
 {
    constexpr int NQ = 8, NM = 4;
    uint32_t sa = 0, sb = 0, hma = 0, hmb = 0, seena = 0, seenb = 0, bad = 0, nma = 0, nmb = 0;
 #pragma unroll
    for (int k = 8 - WU; k < 8; k++)
-      pair_warm4x2<EXP>(sa, stream_from_prev_lane(pair_word8(v[NQ - 2], v[NQ - 1], k), halo_nl ? 0x0A0A0A0Au : (uint32_t)__builtin_amdgcn_readlane((int)halo, k)),
+      pair_warm4x2(sa, stream_from_prev_lane(pair_word8(v[NQ - 2], v[NQ - 1], k), halo_nl ? 0x0A0A0A0Au : (uint32_t)__builtin_amdgcn_readlane((int)halo, k)),
                         sb, pair_word8(v[NQ / 2 - 2], v[NQ / 2 - 1], k), seena, seenb);
 #pragma unroll
    for (int q = 0; q < NQ / 2; q++) {
-      pair_own4x2<EXP, CHK>(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, bad, true);
-      pair_own4x2<EXP, CHK>(sa, v[q].y, hma, nma, sb, v[q + NQ / 2].y, hmb, nmb, bad, false);
-      pair_own4x2<EXP, CHK>(sa, v[q].z, hma, nma, sb, v[q + NQ / 2].z, hmb, nmb, bad, true);
-      pair_own4x2<EXP, CHK>(sa, v[q].w, hma, nma, sb, v[q + NQ / 2].w, hmb, nmb, bad, false);
+      pair_own4x2<CHK>(sa, v[q].x, hma, nma, sb, v[q + NQ / 2].x, hmb, nmb, bad, true);
+      pair_own4x2<CHK>(sa, v[q].y, hma, nma, sb, v[q + NQ / 2].y, hmb, nmb, bad, false);
+      pair_own4x2<CHK>(sa, v[q].z, hma, nma, sb, v[q + NQ / 2].z, hmb, nmb, bad, true);
+      pair_own4x2<CHK>(sa, v[q].w, hma, nma, sb, v[q + NQ / 2].w, hmb, nmb, bad, false);
       if (CHK && (q & 1)) { nmask[q >> 1] = nma; nmask[(q >> 1) + NM / 2] = nmb; nma = 0; nmb = 0; }
    }
    tile_bad = bad;
@@ -190,13 +145,10 @@ __device__ __forceinline__ void pair_walk(const fused_v4u (&v)[8], uint32_t halo
 }
 
 /* WU: warm-up dwords (4 .. 8); FA: FASTA input (header lines: see k_stream) */
-/* EXP (profiles/r03, SEEQ_PAIR_EXP: timing only, the results are void): 0 the kernel; 2 no LDS gathers; 3 no bookkeeping;
- * 4 no per-word checks -- what each part of the kernel costs */
-template <int WU, bool FA, int EXP = 0, bool PF = false>
-__global__ __launch_bounds__(64 * (PF ? 12 : STREAM_NW), PF ? 3 : 8) void k_pair(FusedArgs a)
+template <int WU, bool FA>
+__global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
 {
-   constexpr int NW = PF ? 12 : STREAM_NW;
-   static_assert(!PF || !FA, "the FASTA variant reads text inside its loop: no prefetch variant of it");
+   constexpr int NW = STREAM_NW;
    constexpr int CH = 128;
    constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
    constexpr int NM = CH / 32;                            /* newline mask registers per lane */
@@ -224,18 +176,16 @@ __global__ __launch_bounds__(64 * (PF ? 12 : STREAM_NW), PF ? 3 : 8) void k_pair
    const uint64_t last = a.nbytes - 1;
 
    /* persistent grid: wave w of the grid takes tiles w, w + waves, ....  (Requesting the next tile's text early was tried
-      three ways -- piece by piece into the registers the walk has passed, all of it right after the walk, double-buffered
-      in 128 registers at half the occupancy: 1.06 / 0.92 / 0.81 ms per launch against 0.78 without.  A lane's eight
-      pieces lie inside one 128-byte line and only loads issued back to back are merged into one fetch of it; and with
-      every load behind a wave-uniform branch awaited where the branch ends, or a spilled value reloaded through the same
-      in-order counter, the early request waits anyway.  Without the bookkeeping the kernel runs at 0.645 ms per launch
-      (5.9 TB/s; a plain read sweep of this layout: 6.2): DESIGN.md section 5.) */
+      four ways -- piece by piece into the registers the walk has passed, all of it right after the walk, double-buffered
+      in 128 registers at half the occupancy, and through LDS with global_load_lds_dwordx4 at 12 waves per CU: 1.06 / 0.92 /
+      0.81 / 0.78 ms per launch against 0.77 - 0.78 without.  A lane's eight pieces lie inside one 128-byte line and only loads
+      issued back to back are merged into one fetch of it; and with every load behind a wave-uniform branch awaited where the
+      branch ends, or a spilled value reloaded through the same in-order counter, the early request waits anyway.  Without the
+      bookkeeping the kernel runs at 0.645 ms per launch (5.9 TB/s; a plain read sweep of this layout: 6.2): DESIGN.md
+      section 5; the variants are in the history -- tags r03-experiment-*, r05-before-prune.) */
    fused_v4u v[NQ];
    uint32_t halo = 0;                                     /* lanes 0..7: the eight words before the tile (lane 0's warm-up comes from them) */
    uint32_t tile = gwave;
-   const uint32_t sbase = PF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.dfa_rows * 16u + (uint32_t)wave * PAIR_STAGE_BYTES)) : 0u;      /* my staging rows (LDS byte address: the table starts at 0) */
-   const bool cut_short = (a.seg_len % TB) != 0;
-   if (PF && tile < a.ntiles && !(tile + 1 == a.ntiles && cut_short)) pair_prefetch_tile(a, a.seg_base + (uint64_t)tile * TB, sbase);
    while (tile < a.ntiles) {
       const uint64_t t0 = a.seg_base + (uint64_t)tile * TB;
       const bool partial = tile + 1 == a.ntiles && (a.seg_len % TB) != 0;
@@ -243,17 +193,6 @@ __global__ __launch_bounds__(64 * (PF ? 12 : STREAM_NW), PF ? 3 : 8) void k_pair
       uint32_t lane_off = (uint32_t)lane * CH;
       asm volatile("" : "+v"(lane_off));                  /* (see k_stream: keeps the per-lane 64-bit addresses out of the loop-invariant set) */
       const uint64_t my = t0 + lane_off;
-      if (PF && !partial) {
-         /* my tile has been on its way since before the last walk: wait for it, take it into the registers, send for the next one */
-         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-         uint32_t lid;
-         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
-#pragma unroll
-         for (int q = 0; q < NQ; q++) v[q] = *(pair_lds_cv4u *)(uintptr_t)(sbase + (lid >> 3) * 1024u + (lid & 7u) * 128u + ((((uint32_t)q ^ lid) & 7u) << 4));
-         halo = *(fused_lds_cu32 *)(uintptr_t)(sbase + 8192u + (lid << 2));
-         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(halo), "+v"(v[0].x), "+v"(v[NQ - 1].w) :: "memory");
-         if (next < a.ntiles && !(next + 1 == a.ntiles && cut_short)) pair_prefetch_tile(a, a.seg_base + (uint64_t)next * TB, sbase);
-      } else
       {
          if (!partial) {                                  /* (all nine in one block, back to back: the eight pieces are merged into one fetch of each 128-byte line) */
             const uint8_t *p = a.text + my;
@@ -281,17 +220,12 @@ __global__ __launch_bounds__(64 * (PF ? 12 : STREAM_NW), PF ? 3 : 8) void k_pair
       uint32_t hm[2], nmask[NM];
       if (!dmode) {
          uint32_t tile_bad;
-         pair_walk<WU, EXP, true>(v, halo, halo_nl, hm, nmask, tile_bad);
-         if (EXP == 3) {
-            wv_hitlines += (uint32_t)__popc(hm[0] ^ hm[1] ^ nmask[0] ^ nmask[1] ^ nmask[2] ^ nmask[3]) + tile_bad;
-            tile = next;
-            continue;
-         }
+         pair_walk<WU, true>(v, halo, halo_nl, hm, nmask, tile_bad);
          /* the fast check failed somewhere in the tile (wave-uniform): a byte that is not an upper-case base, N or a newline */
          dmode = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(tile_bad != 0) != 0 ? 1 : 0);
       } else {
          uint32_t unused;
-         pair_walk<WU, EXP, false>(v, halo, halo_nl, hm, nmask, unused);
+         pair_walk<WU, false>(v, halo, halo_nl, hm, nmask, unused);
       }
       /* DM (round 5): text with bytes outside { A C G T N \n } -- FASTQ quality lines, lower case.  Such a byte may alias onto the
          newline column ('+', ':', 'J' ...), so the newline masks are made exactly, from the registers, which still hold the tile

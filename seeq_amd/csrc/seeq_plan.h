@@ -17,27 +17,19 @@
 #include <stdio.h>
 #include <string.h>
 
-/* Experiment / test knobs, read from the environment ONCE per scan context (seeqdevScanNew). */
+/* Test knobs, read from the environment ONCE per scan context (seeqdevScanNew).  (Round 5 removed the knobs that kept superseded kernels and
+   timing-only experiments compiled in -- SEEQ_VERIFY / SEEQ_ORDER / SEEQ_EMIT_ALL = old, SEEQ_NO_SKIPCOUNT, SEEQ_NO_LL_FILTER, SEEQ_PAIR_PF, SEEQ_PAIR_EXP,
+   SEEQ_DFA_WGS, SEEQ_EXACT, SEEQ_PACKED_STAGE: tag r05-before-prune builds them.) */
 struct ScanKnobs {
    int  kernel;          /* SEEQ_FUSED_KERNEL: 0 auto, 1 "stream" (k_stream, never k_pair), 2 "direct", 3 "pair" (k_pair wherever the pattern has a pair automaton, selective or not) */
-   int  wgs_per_cu;      /* SEEQ_DFA_WGS: cap on k_stream workgroups per CU (0 = occupancy) */
    int  tile_bytes;      /* SEEQ_TILE_BYTES: k_direct region size */
-   bool exact_generic;   /* SEEQ_EXACT=generic: k_exact<W> behind the one-pass kernels */
    bool no_filter;       /* SEEQ_NO_FILTER=1: complete automata only */
    int  min_wu;          /* SEEQ_STREAM_WU=6|8: at least this many warm-up dwords (tests: the 16-byte warm-up off) */
-   int  pair_exp;        /* SEEQ_PAIR_EXP=2..4, builds with -DSEEQ_EXPERIMENTS only: k_pair without its gathers / bookkeeping / per-word checks (timing only) */
    bool no_window;       /* SEEQ_NO_WINDOW=1: behind k_pair the exact pass scans a candidate line to its end, as behind the other filters */
    bool no_myers;        /* SEEQ_NO_MYERS=1: long lines without an automaton go to the generic path (one line per lane) as before */
    bool no_leaders;      /* SEEQ_NO_LEADERS=1: long lines are walked by one lane each whatever the number of their candidates (A/B, tests) */
-   bool no_ll_filter;    /* SEEQ_NO_LL_FILTER=1: long lines never take a partition filter (k_stream's Myers mode instead), as before round 4 */
-   bool no_skipcount;    /* SEEQ_NO_SKIPCOUNT=1: SQ_IGNORE, every chain with a skipped byte in its warm-up window makes up a candidate, as before round 4 */
-   bool old_order;       /* SEEQ_ORDER=old: k_fused_post + k_scanset_* + k_stream_reorder + k_stream_bounds on read-length lines too, as before round 4 (A/B, tests) */
-   bool old_verify;      /* SEEQ_VERIFY=old: k_exact1<COUNT> + the three-launch scan behind the filters, as before round 4 (A/B, tests) */
-   bool pair_pf;         /* SEEQ_PAIR_PF=1: k_pair's variant that prefetches the next tile into LDS (experiment) */
    bool no_packed_quad;  /* SEEQ_PACKED_QUAD=0: the packed walk over the pair table even where the pattern has a quad table (A/B, tests) */
-   bool old_emit_all;    /* SEEQ_EMIT_ALL=old: SQ_ALL records behind k_verify through k_exact1's EMIT pass, one lane per line (A/B, tests) */
    bool no_sub;          /* SEEQ_STREAM_SUB=0: SQ_CONVERT text with non-DNA bytes is re-run on the per-line kernels (as SQ_IGNORE) */
-   bool packed_stage;    /* SEEQ_PACKED_STAGE=1: packed batches: candidates unpacked to a staging text for the exact pass, as before k_verify_packed (A/B, tests) */
    bool explain;         /* SEEQ_EXPLAIN=1: every scan prints its plan on stderr */
 };
 
@@ -69,7 +61,7 @@ struct ScanPlan {
    bool stream_ll;         /* long-line variant: bookkeeping for the window walk */
    int  stream_sub;        /* 0, 1 SQ_CONVERT, 2 SQ_IGNORE */
    int  stream_wu;         /* warm-up dwords of the scan kernel */
-   bool superset, need_nh, nh_is_count, generic_exact;
+   bool superset, need_nh, nh_is_count;
    bool window_ok;         /* k_pair: the exact pass scans candidate windows */
    bool ll_filter;         /* k_stream's long-line variant over a partition filter */
    bool leaders;           /* long lines: candidates far behind the one before them get lanes of their own */
@@ -136,7 +128,7 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
                profiles/r04_chrom_sweep.txt); the walk runs on m + tau + 2 columns behind a candidate's chunk (walk_ext: at most a
                block, so that a leader's fresh start still lies behind the walk before it) */
             const double ll_pacc_max = p.fw == 1 ? 0.0014 : 0.0032;
-            if (long_lines ? (kn.no_ll_filter || au.sdfa_pacc > ll_pacc_max || in.wlen + in.tau + 2 > 64) : au.sdfa_pacc * in.avg_line > 0.25) p.use_stream = false;
+            if (long_lines ? (au.sdfa_pacc > ll_pacc_max || in.wlen + in.tau + 2 > 64) : au.sdfa_pacc * in.avg_line > 0.25) p.use_stream = false;
          }
       }
    }
@@ -178,17 +170,16 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
    p.path = p.use_fused ? (p.use_pair ? 6 : p.use_myers ? 7 : p.use_stream ? 5 : 3) : 1;
    p.superset = p.use_stream;                             /* the scan kernel's hit lines are candidates: nh[] decides */
    if (p.superset) p.need_nh = true;
-   p.generic_exact = !p.superset && kn.exact_generic;     /* A/B knob */
    /* ---- the post-pass ---- */
    p.skip_back = (uint32_t)(in.wlen + in.tau - 1) + (p.use_pair ? 1u : 0u);      /* (k_pair reports the second byte of a pair) */
    p.window_ok = p.use_pair && !in.no_window && !kn.no_window;
    p.ll_filter = p.use_fused && p.use_stream && p.stream_ll && p.filter && !p.use_pair && !p.use_myers;
    p.walk_ext = p.ll_filter ? (uint32_t)(in.wlen + in.tau + 2) : 0u;
-   p.skip_thr = (p.use_fused && p.use_stream && !p.use_pair && !p.use_myers && p.stream_sub == 2 && au.sdfa_parts == 1 && !kn.no_skipcount) ? (uint32_t)(in.wlen - in.tau) : 0u;
+   p.skip_thr = (p.use_fused && p.use_stream && !p.use_pair && !p.use_myers && p.stream_sub == 2 && au.sdfa_parts == 1) ? (uint32_t)(in.wlen - in.tau) : 0u;
    p.lead_best = want == PLAN_WANT_RECORDS && match_opt == PLAN_SQ_BEST;      /* (one record per line: the groups' best hits are reduced per line) */
-   p.leaders = p.use_stream && p.stream_ll && (p.nh_is_count || p.lead_best) && p.use_fused && !p.generic_exact && !kn.no_leaders && !in.no_leaders && !in.multi_active;
-   p.order2 = p.use_fused && p.use_stream && !p.stream_ll && !kn.old_order;
-   p.verify = p.need_nh && p.use_fused && !p.generic_exact && p.filter && !p.stream_ll && !kn.old_verify && !in.multi_active &&
+   p.leaders = p.use_stream && p.stream_ll && (p.nh_is_count || p.lead_best) && p.use_fused && !kn.no_leaders && !in.no_leaders && !in.multi_active;
+   p.order2 = p.use_fused && p.use_stream && !p.stream_ll;
+   p.verify = p.need_nh && p.use_fused && p.filter && !p.stream_ll && !in.multi_active &&
               (options & (PLAN_SQ_IGNORE | PLAN_SQ_STREAM)) == 0;
    return p;
 }
@@ -206,7 +197,7 @@ static inline void seeq_plan_print(FILE *f, const PlanIn &in, const PlanAutomata
            au.sdfa_state == 1 ? "yes" : au.sdfa_state == 0 ? "not asked" : "none", au.sdfa_parts, au.sdfa_warm, au.sdfa_pacc,
            au.pair_state == 1 ? "yes" : au.pair_state == 0 ? "not asked" : "none", au.pair_warm, au.pair_pacc,
            p.order2 ? "k_tiles_post + k_order + k_bounds2" : p.use_fused ? "k_fused_post + k_scanset_* + reorder + bounds" : "k_compact",
-           p.verify ? "k_verify + k_nh_top" : p.need_nh ? (p.generic_exact ? "k_exact<COUNT> + scan" : "k_exact1<COUNT> + scan") : "no count pass",
+           p.verify ? "k_verify + k_nh_top" : p.need_nh ? "k_exact1<COUNT> + scan" : "no count pass",
            p.window_ok ? " on candidate windows" : "", p.leaders ? " [leaders]" : "", p.skip_back, p.skip_thr ? ", skip count" : "");
 }
 

@@ -143,6 +143,29 @@ __device__ __forceinline__ void stream_myers_step4(const fused_eq_t<W> (&ev)[4],
    }
 }
 
+/* Round 5: the same four bytes where NO lane of the wave holds a flagged byte (no newline, no terminator: on chromosome-long lines that is
+ * nearly every word) -- the column steps and ONE instruction per byte beside them: v_alignbit shifts the sign of tau - score into a stream
+ * (k_verify's trick, seeq_verify.h); the dead / first-hit-of-the-line logic runs once per word on the four bits.  18.75 VALU per text byte
+ * instead of 32 (PMC, profiles/r05/pmc_myers.txt: the per-byte flag logic was 17 of the 32, and the kernel issued VALU instructions in 76 %
+ * of its 4-cycle slots -- it was not short of issue rate but long on instructions).  `dead` cannot change here (no flag), `seen` only grows. */
+template <int W, bool OWN>
+__device__ __forceinline__ void stream_myers_fast4(const fused_eq_t<W> (&ev)[4], fused_state_t<W> &st, uint32_t tau, uint32_t dead, uint32_t &seen, uint32_t &hm)
+{
+   uint32_t L = 0;
+#pragma unroll
+   for (int cc = 0; cc < 4; cc++) {
+      st.step(ev[cc]);
+      if (OWN) L = __builtin_amdgcn_alignbit(L, tau - st.score, 31);      /* bit = 1: score > tau; first byte ends up in bit 3 */
+   }
+   if (OWN) {
+      uint32_t r4 = ~L & 0xFu;                                         /* scores <= tau */
+      r4 = (dead | seen) ? 0u : r4;                                    /* only the FIRST such position of a line reports, and none behind a byte that ended it */
+      const uint32_t first = r4 ? 1u << (31u - (uint32_t)__builtin_clz(r4)) : 0u;
+      hm = (hm << 4) | first;
+      seen |= r4 ? 1u : 0u;
+   }
+}
+
 /* word k (0..31) of a lane's 128-byte chunk */
 __device__ __forceinline__ uint32_t stream_word32(const fused_v4u (&v)[8], int k)
 {
@@ -346,8 +369,15 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
                stream_myers_lookup4<MW>(wn, eqb, ev[(k + 1) & 1]);
             }
             if (k == WU) { seen = 0; hm = 0; }              /* every chain reports the first hit of a line inside its OWN bytes */
-            if (k < WU) stream_myers_step4<MW, false>(ev[k & 1], st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);
-            else stream_myers_step4<MW, true>(ev[k & 1], st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);
+            /* a flagged byte (newline, terminator) in this word of ANY lane: the per-byte logic; else the lean steps (wave-uniform branch) */
+            const fused_eq_t<MW> (&e4)[4] = ev[k & 1];
+            if (__any(((e4[0].w0 | e4[1].w0 | e4[2].w0 | e4[3].w0) & 3u) != 0u)) {
+               if (k < WU) stream_myers_step4<MW, false>(e4, st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);
+               else stream_myers_step4<MW, true>(e4, st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);
+            } else {
+               if (k < WU) stream_myers_fast4<MW, false>(e4, st, (uint32_t)a.tau, dead, seen, hm);
+               else stream_myers_fast4<MW, true>(e4, st, (uint32_t)a.tau, dead, seen, hm);
+            }
             if (k >= WU && ((k - WU) & 7) == 7) { hmask[(k - WU) >> 3] = hm; hm = 0; }
          }
       } else {

@@ -75,15 +75,6 @@ def test_packed_vs_oracle(gpu, capi, oracle):
                 assert not g2["quad"] and np.array_equal(g2["records"].astype(np.uint64), exp["records"]), (pattern, tau, L, mo, "pair table")
         if (pattern, tau) == ("GATGTAGCGCGATTAGCCTG", 3):
             assert got["quad"], "the headline pattern has a 95-state two-part filter: the quad table serves it"
-        # the same through the staging text (SEEQ_PACKED_STAGE=1: candidates unpacked for the exact pass, as before k_verify_packed)
-        os.environ["SEEQ_PACKED_STAGE"] = "1"
-        try:
-            for mo in (SQ_FIRST, SQ_BEST):
-                exp = oracle.buffer_scan(pattern, tau, text, mo)
-                got = _packed_scan(dev, torch, pat, text, L, mo, dev.WANT_RECORDS)
-                assert got["kernel"] == "k_packed" and np.array_equal(got["records"].astype(np.uint64), exp["records"]), (pattern, tau, L, mo, "staged")
-        finally:
-            os.environ.pop("SEEQ_PACKED_STAGE", None)
         expa = oracle.buffer_scan(pattern, tau, text, SQ_ALL)
         c1 = _packed_scan(dev, torch, pat, text, L, 0, dev.WANT_COUNTLINES)
         c2 = _packed_scan(dev, torch, pat, text, L, 0, dev.WANT_COUNTMATCH)
