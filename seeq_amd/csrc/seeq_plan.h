@@ -121,13 +121,13 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
          if (au.sdfa_state == 0) ensure(ctx, 0, kn.no_filter ? 1 : 0, &au);
          p.use_stream = au.sdfa_state == 1 && in.seg_bytes % (64u * (unsigned)stream_ch) == 0;
          if (p.use_stream && au.sdfa_parts > 1) {
-            /* a filter: worth it while few lines are false candidates (each costs a whole-line exact scan).  On long lines (round 4)
-               the rate is judged per BYTE: a candidate costs the window walk ~170 columns, the Myers mode steps every byte -- the
-               filter wins below 1.4 (one-word column) / 3.2 (two words) candidates per KB (measured on the published sweep's shape,
-               3.2 GB: filter walk 1.2 ms + 3.3 ms per candidate-per-KB; the Myers mode 6 ms with one word, 11.5 - 13.5 ms with two:
-               profiles/r04_chrom_sweep.txt); the walk runs on m + tau + 2 columns behind a candidate's chunk (walk_ext: at most a
-               block, so that a leader's fresh start still lies behind the walk before it) */
-            const double ll_pacc_max = p.fw == 1 ? 0.0014 : 0.0032;
+            /* a filter: worth it while few lines are false candidates (each costs a whole-line exact scan).  On long lines the rate is judged per
+               BYTE: a candidate costs the window walk ~170 columns, the Myers mode steps every byte -- measured on the published sweep's shape
+               (3.2 GB): the filter walk 1.2 ms + 3.3 ms per candidate-per-KB; the Myers mode 3.1 ms with one word, 4.6 ms with two (round 5: its loop
+               unrolled at last, lean steps; 6 / 11.5 - 13.5 ms before, when the filter won below 1.4 / 3.2 candidates per KB) -- so the filter wins
+               below 0.58 / 1.0 candidates per KB (profiles/r05_chrom_sweep.txt); the walk runs on m + tau + 2 columns behind a candidate's chunk
+               (walk_ext: at most a block, so that a leader's fresh start still lies behind the walk before it) */
+            const double ll_pacc_max = p.fw == 1 ? 0.00058 : 0.0010;
             if (long_lines ? (au.sdfa_pacc > ll_pacc_max || in.wlen + in.tau + 2 > 64) : au.sdfa_pacc * in.avg_line > 0.25) p.use_stream = false;
          }
       }

@@ -429,16 +429,26 @@ def test_cli_pipelined_ingest_lanes_and_devices(gpu, capi):
              ("reads_small.txt", ["-d", "3", "-i", "-l", PAT20]), ("reads_small.txt", ["-d", "3", "-a", "-l", "-p", "-k", PAT20]),
              ("fasta_small.txt", ["-d", "3", "-b", PAT20]), ("fasta_small.txt", ["-d", "3", "-c", PAT20]),
              ("fasta_small.txt", ["-d", "3", "-l", "-p", PAT20]), ("fastq_small.txt", ["-d", "3", "-x", "1", "-a", "-f", PAT20])]
+    from concurrent.futures import ThreadPoolExecutor
+    variants = (("700", "1", None), ("4096", "2", None), ("1500", "2", "0,0"), ("3000", "4", "0,0,0"), ("65536", "3", "all"))
+
+    def run(job):                                           # (three CLI processes at a time: each is mostly process and HIP start-up)
+        (name, args), v = job
+        env = dict(os.environ)
+        if v:
+            env.update(SEEQ_CHUNK_BYTES=v[0], SEEQ_LANES=v[1])
+            if v[2]:
+                env["SEEQ_DEVICES"] = v[2]
+        return subprocess.run([capi.CLI_PATH] + args + [os.path.join(GOLDEN, name)], capture_output=True, env=env)
+    jobs = [(c, v) for c in cases for v in (None,) + variants]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        res = dict(zip([(c[0], tuple(c[1]), v) for c, v in jobs], pool.map(run, jobs)))
     for name, args in cases:
-        path = os.path.join(GOLDEN, name)
-        ref = subprocess.run([capi.CLI_PATH] + args + [path], capture_output=True)
+        ref = res[(name, tuple(args), None)]
         assert ref.returncode == 0
-        for chunk, lanes, devs in (("700", "1", None), ("4096", "2", None), ("1500", "2", "0,0"), ("3000", "4", "0,0,0"), ("65536", "3", "all")):
-            env = dict(os.environ, SEEQ_CHUNK_BYTES=chunk, SEEQ_LANES=lanes)
-            if devs:
-                env["SEEQ_DEVICES"] = devs
-            r = subprocess.run([capi.CLI_PATH] + args + [path], capture_output=True, env=env)
-            assert r.returncode == 0 and r.stdout == ref.stdout, (name, args, chunk, lanes, devs, r.stderr[-500:])
+        for v in variants:
+            r = res[(name, tuple(args), v)]
+            assert r.returncode == 0 and r.stdout == ref.stdout, (name, args, v, r.stderr[-500:])
 
 
 def test_cli_pipeline_on_a_generated_file(gpu, capi, oracle, tmp_path):
@@ -572,9 +582,15 @@ def test_cli_known_answers(gpu, capi):
 
 
 def test_cli_golden_outputs(gpu, capi, cli_cases):
-    """Byte-identical stdout with the reference CLI on the committed input files (135 invocations)."""
-    for c in cli_cases:
-        r = subprocess.run([capi.CLI_PATH] + c["args"] + [os.path.join(GOLDEN, c["file"])], capture_output=True)
+    """Byte-identical stdout with the reference CLI on the committed input files (135 invocations; four CLI processes at a time -- a
+    run is 0.35 s of process and HIP start-up: the box allows six processes on its GPU)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(c):
+        return subprocess.run([capi.CLI_PATH] + c["args"] + [os.path.join(GOLDEN, c["file"])], capture_output=True)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(run, cli_cases))
+    for c, r in zip(cli_cases, results):
         out = r.stdout.decode("latin-1")
         if "stdout" in c:
             assert out == c["stdout"], (c["file"], c["args"])
