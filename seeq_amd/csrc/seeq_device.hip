@@ -1368,7 +1368,7 @@ static int run_setup(seeqdev_scan *s, SegRun &r)
          if (use_pair) {
 #define SEEQ_PAIR_FN(...) (stream_wu == 4 ? (const void *)k_pair<4, __VA_ARGS__> : stream_wu == 5 ? (const void *)k_pair<5, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_pair<6, __VA_ARGS__> \
                           : stream_wu == 7 ? (const void *)k_pair<7, __VA_ARGS__> : (const void *)k_pair<8, __VA_ARGS__>)
-            stream_fn = fasta ? SEEQ_PAIR_FN(true) : SEEQ_PAIR_FN(false);
+            stream_fn = fasta ? SEEQ_PAIR_FN(true) : plan.ig ? SEEQ_PAIR_FN(false, true) : SEEQ_PAIR_FN(false);
             dfa_lds = (size_t)pat->pair_units * 16;
 #undef SEEQ_PAIR_FN
          }
@@ -1468,7 +1468,7 @@ static int seg_onepass(seeqdev_scan *s, const SegRun &r, ScanArgs &a, size_t sg,
       f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
       f.ll_filter = plan.ll_filter ? 1u : 0u;
       f.skip_thr = plan.skip_thr;
-      if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; }
+      if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; f.ig_thr = plan.ig ? (uint32_t)(pat->wlen - pat->tau) : 0u; }
       if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
       /* A hit line can start before the segment: hit offsets of this segment are relative to seg_base - pos_bias */
       uint64_t room = 0xFFFFFFF0ull - a.seg_len;
@@ -1490,6 +1490,21 @@ static int seg_onepass(seeqdev_scan *s, const SegRun &r, ScanArgs &a, size_t sg,
    /* read-length lines behind k_pair / k_stream: the three launches of seeq_order.h; else (long lines, k_direct) the seven of before */
    const uint32_t order_nb = (f.ntiles + SEEQ_ORDER_BLOCK - 1) / SEEQ_ORDER_BLOCK;
    order2 = plan.order2 && order_nb <= SEEQ_ORDER_MAX_BLOCKS && 2 * (size_t)order_nb <= s->cap_scan_ws;
+   if (plan.ig) {
+      /* SQ_IGNORE behind k_pair: the line markers travel in the ordered entries (seeq_order.h) -- the older ordering kernels know nothing of them */
+      if (!order2) { snprintf(g_last_error, sizeof g_last_error, "SQ_IGNORE on k_pair needs the three-launch ordering (segment too large for its block sums)"); seeqerr = 0; errno = EIO; return -1; }
+      a.ig_thr = f.ig_thr; a.ig_ent = (const uint4 *)s->ent;
+      {  /* the base the pattern's plain positions hold most often (ties: T first -- the rarest byte of FASTQ quality lines): an occurrence keeps all but tau copies */
+         static const char base_of_key[9] = {0, 'A', 'C', 0, 'G', 0, 0, 0, 'T'};
+         int cnt[4] = {0, 0, 0, 0}, best = 3;
+         for (int i = 0; i < pat->wlen; i++) { const int kb = pat->keys[i] & 0x1F; if (kb == 1) cnt[0]++; else if (kb == 2) cnt[1]++; else if (kb == 4) cnt[2]++; else if (kb == 8) cnt[3]++; }
+         for (int b = 2; b >= 0; b--) if (cnt[b] > cnt[best]) best = b;
+         const int need = cnt[best] - pat->tau;
+         a.ig_need = need > 0 ? (uint32_t)need : 0u;
+         a.ig_bval = (uint32_t)(unsigned char)base_of_key[1 << best];
+         a.ig_bmask = best == 3 ? 0xDEu : 0xDFu;           /* T: U and either case too */
+      }
+   }
    if (order2) {
       const unsigned rgrid = nsl / 4 + 1 < 2048 ? nsl / 4 + 1 : 2048;       /* one wave per slice, strided */
       seeq_launch_tiles_post(st, f, (uint32_t)nsl, s->scan_ws, order_nb);
@@ -1583,7 +1598,7 @@ static int seg_post(seeqdev_scan *s, const SegRun &r, ScanArgs &a, hipEvent_t *e
    const size_t hit_blocks = (s->cap_hitlines + WG - 1) / WG;
    unsigned grid_hits = (unsigned)(hit_blocks < (size_t)ncu * 16 ? hit_blocks : (size_t)ncu * 16);
    if (grid_hits == 0) grid_hits = 1;
-   if (order2) seeq_launch_bounds2(grid_hits, st, a, (const uint4 *)s->ent, s->hit_col);
+   if (order2) seeq_launch_bounds2(grid_hits, st, a, s->ent, s->hit_col);
    else if (use_stream) hipLaunchKernelGGL(k_stream_bounds, dim3(grid_hits), dim3(256), 0, st, a, s->hit_col,
                                       (const uint32_t *)ow.tile_cl, stream_ntiles, tile_bytes);   /* hit position -> line start; repeats dropped */
    if (s->multi_active) {

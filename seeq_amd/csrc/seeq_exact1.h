@@ -213,9 +213,17 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
             candidate), and a column started skip_back >= m + tau - 1 bytes earlier has the line's own scores from there */
          /* (not trusted: no byte outside the alphabet up to the candidate itself -- a skipped byte inside the warm-up
             columns, SQ_IGNORE, would leave the fresh column short of real characters) */
-         if (col > a.skip_back && (trusted || exact1_clean(a, off, off + col))) pos = col - a.skip_back;
+         /* k_pair under SQ_IGNORE (round 5, seeq_pair.h IG): a line that holds a skipped byte and enough other characters for an occurrence has a
+            MARKER among its entries -- this one or a repeat of the line behind it -- and is scanned from its first byte to its end; a line without
+            one holds no skipped byte (or too few characters for any occurrence): its windows are what they are under SQ_FAIL */
+         bool ig_whole = false;
+         if (a.ig_ent) {
+            ig_whole = (a.ig_ent[kk].w & 6u) == 2u;
+            for (uint32_t j = k + 1; !ig_whole && j < nhl && a.hit_start[j] == 0xFFFFFFFFu && a.hit_line[j] == a.hit_line[kk]; j++) ig_whole = (a.ig_ent[j].w & 6u) == 2u;
+         }
+         if (col > a.skip_back && !ig_whole && (trusted || a.ig_ent || exact1_clean(a, off, off + col))) pos = col - a.skip_back;
          /* (COUNT only: nh[] holds offsets by the time EMIT runs; an EMIT that scans again scans on -- and finds nothing more) */
-         if (MODE == SQ_MODE_COUNT && a.window_ok) {
+         if (MODE == SQ_MODE_COUNT && a.window_ok && !ig_whole) {
             /* the line's further candidates are the repeats behind this entry (a third of the hit lines has one: an occurrence
                near the end of a chain is seen by the next chain's warm-up, which then reports its own first pair): the scan
                runs from before the first candidate to behind the last one */
@@ -224,7 +232,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
                unbounded = lastcol == 0xFFFFFFFFu ? 2u : 0u;
                lastcol += a.skip_back - (m + tau1 - 1u);
             }
-            else for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu; j++) lastcol = hit_col[j] - hs;
+            else for (uint32_t j = k + 1; j < nhl && a.hit_start[j] == 0xFFFFFFFFu && (!a.ig_ent || a.hit_line[j] == a.hit_line[kk]); j++) lastcol = hit_col[j] - hs;      /* (ig_ent: a marker k_bounds2 dropped looks like a repeat -- of ANOTHER line) */
             if (!unbounded) stop_at = lastcol + m + tau1 + 1u;
          }
          /* the line ends in this segment: a newline at or after its start, or the buffer ends with the segment */

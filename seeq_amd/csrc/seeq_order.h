@@ -66,7 +66,9 @@ __device__ __forceinline__ void order_block_prefix(const uint32_t *bsum, uint32_
 }
 
 /* entries: {segment-relative (biased) position: the line's start, or the candidate itself when the line starts before its tile;
-            1-based counted line number; bit 0: unresolved, bits 1..: the candidate's column in its line (resolved entries); 0} */
+            1-based counted line number; bit 0: unresolved, bits 1..: the candidate's column in its line (resolved entries);
+            bit 1: a line MARKER (k_pair under SQ_IGNORE: the line holds a skipped byte -- scan it whole), bit 0: ... that stands on a candidate of the walk,
+            bit 2 (set by k_bounds2): ... that did not hold -- a marker no more} */
 __global__ __launch_bounds__(256) void k_order(FusedArgs f, uint32_t nslices, const uint32_t *bsum, uint32_t nb, uint4 *ent)
 {
    __shared__ uint32_t s_ph[ORDER_MAX_BLOCKS], s_pc[ORDER_MAX_BLOCKS], s_wave[4];
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_order(FusedArgs f, uint32_t nslices, co
          for (int u = 0; u < 4; u++) e[u] = i0 + 64u * u < n ? slice[i0 + 64u * u] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
          for (int u = 0; u < 4; u++) {
-            const uint32_t tile = e[u].x & 0x7FFFFFFFu;
+            const uint32_t tile = e[u].x & 0x1FFFFFFFu;          /* (bit 31: unresolved, bit 30: a line marker of k_pair under SQ_IGNORE, bit 29: ... on a candidate) */
             const bool ok = i0 + 64u * u < n;
             th[u] = ok ? f.tile_hits[tile] + s_ph[tile / ORDER_SCAN_BLOCK] : 0u;
             tc[u] = ok ? f.tile_cl[tile] + s_pc[tile / ORDER_SCAN_BLOCK] : 0u;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void k_order(FusedArgs f, uint32_t nslices, co
          for (int u = 0; u < 4; u++) {
             if (i0 + 64u * u >= n) continue;
             const uint32_t dst = th[u] + (e[u].y & 0x1FFFu);
-            ent[dst] = make_uint4(e[u].z, lines0 + tc[u] + e[u].w + 1u /* reference seeq.c:377 */, (e[u].x >> 31) | (((e[u].y >> 13) & 0x3FFFFu) << 1), 0u);
+            ent[dst] = make_uint4(e[u].z, lines0 + tc[u] + e[u].w + 1u /* reference seeq.c:377 */, (e[u].x >> 31) | (((e[u].y >> 13) & 0x3FFFFu) << 1), (e[u].x >> 29) & 3u);
          }
       }
    }
@@ -130,7 +132,60 @@ __device__ __forceinline__ uint64_t order_line_start(const uint8_t *text, uint64
    return 0;
 }
 
-__global__ __launch_bounds__(256) void k_bounds2(ScanArgs a, const uint4 *ent, uint32_t *hit_col)
+/* SQ_IGNORE, a line MARKER of k_pair (seeq_pair.h IG): its line starts at text[q] and runs to the next newline (or the buffer's end).  Can a skipped
+ * byte hide an occurrence in it?  Only if the line holds (1) a skipped byte (libseeq.c:265-266: anything but A C G T U N in either case), (2) at least
+ * m - tau characters that are not skipped, and (3) -- the frequency bound -- at least n_b - tau copies of the base b the pattern's plain positions hold
+ * most often (ScanArgs.ig_bval / ig_bmask / ig_need: an occurrence with <= tau errors keeps all but tau of them; FASTQ quality lines, which hold a few
+ * A C G but no T, fail it for every pattern with tau + 1 T's).  k_pair has checked (1) and (2) for the lines it could see whole; all three are checked
+ * here, four bytes at a time. */
+/* the counts of up to four bytes in front of a newline: w = the word, nby = its bytes that count (0 .. 4) */
+__device__ __forceinline__ void order_marker_word(uint32_t w, uint32_t nby, uint32_t bm, uint32_t bv, uint32_t &ns, uint32_t &nb)
+{
+   const uint32_t keepm = nby >= 4u ? 0xFFFFFFFFu : (1u << (8u * nby)) - 1u;
+   const uint32_t idx = (w & 0x0E0E0E0Eu) >> 1;
+   const uint32_t y = ((w & __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDEDFDFu, idx)) ^ __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx)) & keepm;
+   ns += (uint32_t)__popc((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);                        /* bytes outside the alphabet */
+   const uint32_t z = ((w & bm) ^ bv) | ~keepm;
+   nb += (uint32_t)__popc(~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u);                       /* copies of the base */
+}
+
+__device__ __forceinline__ bool order_marker_holds(const ScanArgs &a, uint64_t q)
+{
+   const uint8_t *text = a.text;
+   uint32_t ns = 0, nb = 0, len = 0;
+   const uint32_t bm = a.ig_bmask * 0x01010101u, bv = a.ig_bval * 0x01010101u;
+   uint64_t p = q;
+   for (; p + 16 <= a.nbytes; p += 16) {                   /* sixteen bytes a step, to the line's newline (a marker may stand anywhere in its line) */
+      const fused_v4u v = *reinterpret_cast<const fused_v4u_unaligned *>(text + p);
+      const uint32_t f0 = nl_flags(v.x), f1 = nl_flags(v.y), f2 = nl_flags(v.z), f3 = nl_flags(v.w);
+      if ((f0 | f1 | f2 | f3) == 0u) {
+         order_marker_word(v.x, 4u, bm, bv, ns, nb); order_marker_word(v.y, 4u, bm, bv, ns, nb);
+         order_marker_word(v.z, 4u, bm, bv, ns, nb); order_marker_word(v.w, 4u, bm, bv, ns, nb);
+         len += 16u;
+         if (len > (1u << 20)) return true;                 /* (a line of a megabyte: not this kernel's text -- the exact pass decides) */
+         continue;
+      }
+      /* the newline is among these sixteen: the bytes in front of it */
+      const uint32_t wf = f0 ? 0u : f1 ? 1u : f2 ? 2u : 3u;
+      const uint32_t fw = f0 ? f0 : f1 ? f1 : f2 ? f2 : f3;
+      const uint32_t nby = (uint32_t)__builtin_ctz(fw) >> 3;
+      order_marker_word(v.x, wf > 0u ? 4u : nby, bm, bv, ns, nb);
+      if (wf >= 1u) order_marker_word(v.y, wf > 1u ? 4u : nby, bm, bv, ns, nb);
+      if (wf >= 2u) order_marker_word(v.z, wf > 2u ? 4u : nby, bm, bv, ns, nb);
+      if (wf >= 3u) order_marker_word(v.w, nby, bm, bv, ns, nb);
+      len += 4u * wf + nby;
+      return ns != 0u && len - ns >= a.ig_thr && nb >= a.ig_need;
+   }
+   for (; p < a.nbytes && text[p] != '\n'; p++) {
+      const uint32_t ch = text[p], up = ch & 0xDFu;
+      if (!(up == 'A' || up == 'C' || up == 'G' || up == 'T' || up == 'U' || up == 'N')) ns++;
+      if (((ch & a.ig_bmask) ^ a.ig_bval) == 0u) nb++;
+      len++;
+   }
+   return ns != 0u && len - ns >= a.ig_thr && nb >= a.ig_need;
+}
+
+__global__ __launch_bounds__(256) void k_bounds2(ScanArgs a, uint4 *ent, uint32_t *hit_col)
 {
    Counters *c = a.cnt;
    const uint32_t nhl = c->seg_nhitlines;
@@ -142,15 +197,45 @@ __global__ __launch_bounds__(256) void k_bounds2(ScanArgs a, const uint4 *ent, u
       const uint32_t prev = k ? ent[k - 1].y : prev0;
       const uint32_t unresolved = e.z & 1u, col = e.z >> 1;
       a.hit_line[k] = e.y;
-      if (e.y == prev) {                                  /* a repeat: keep the candidate's position for the exact pass's window */
+      /* SQ_IGNORE: the entry before me may be a line marker that its own thread DROPS (a marker made unseen for a line that turns out to hold no
+         skipped byte: it stands on the tile's last pair, IN FRONT of what the next tile finds in the line) -- then I am the line's first entry,
+         not its repeat.  Its verdict is recomputed here (its thread's lies in bit 2 of its word 3, which may not be written yet). */
+      uint32_t repeat = e.y == prev ? 1u : 0u;
+      if (repeat && k != 0u && a.ig_thr != 0u) {
+         const uint4 pe = ent[k - 1];
+         const uint32_t pprev = k > 1u ? ent[k - 2].y : prev0;
+         if ((pe.w & 3u) == 2u && pprev != pe.y) {        /* a pure marker, the first entry of this line */
+            const uint64_t pq = (pe.z & 1u) ? order_line_start(a.text, a.seg_base + pe.x) : a.seg_base + pe.x;
+            const uint32_t pholds = (pq < a.seg_base || order_marker_holds(a, pq)) ? 1u : 0u;
+            if (!pholds) repeat = 0u;
+         }
+      }
+      if (repeat) {                                       /* a repeat: keep the candidate's position for the exact pass's window */
          hit_col[k] = unresolved ? e.x : e.x + col;
          /* windows: the line's first candidate belongs to the segment before this one, whose exact pass could not know of this
-            one -- the run is void, the next one scans candidate lines to their ends (seeqdevScanFetch) */
-         if (a.window_ok && e.y == prev0) atomicOr(&c->overflow, 128u);
+            one -- the run is void, the next one scans candidate lines to their ends (seeqdevScanFetch).  (SQ_IGNORE: every segment's first
+            line end comes with a marker made unseen -- it counts only when the line really holds a skipped byte and enough characters.) */
+         if (a.window_ok && e.y == prev0) {
+            bool voids = true;
+            if (a.ig_thr && (e.w & 2u) && unresolved) {
+               const uint64_t hp0 = a.seg_base + e.x;
+               voids = hp0 < a.nbytes && order_marker_holds(a, order_line_start(a.text, hp0));
+            }
+            if (voids) atomicOr(&c->overflow, 128u);
+         }
          a.hit_start[k] = 0xFFFFFFFFu;
          continue;
       }
-      if (!unresolved) { a.hit_start[k] = e.x; hit_col[k] = col; continue; }
+      if (!unresolved) {
+         /* (SQ_IGNORE: a marker k_pair made with the line in sight has passed its counts there; the frequency bound is checked here) */
+         uint32_t keep = 1u;
+         if (a.ig_need != 0u && (e.w & 2u) != 0u) {
+            const uint32_t holds = order_marker_holds(a, a.seg_base + e.x) ? 1u : 0u;
+            if (!holds) { keep = e.w & 1u; ent[k].w = e.w | 4u; }
+         }
+         a.hit_start[k] = keep ? e.x : 0xFFFFFFFFu; hit_col[k] = keep ? col : 0u;
+         continue;
+      }
       const uint64_t hp = a.seg_base + e.x;               /* a byte of the line (inside the segment); never '\n' */
       if (hp >= a.nbytes || hp < segb || hp >= segb + a.seg_len) {       /* cannot be: an entry the scan kernel never wrote -- fail loudly, touch nothing */
          atomicOr(&c->overflow, 64u);
@@ -159,11 +244,22 @@ __global__ __launch_bounds__(256) void k_bounds2(ScanArgs a, const uint4 *ent, u
          continue;
       }
       const uint64_t q = order_line_start(a.text, hp);
-      if (q < a.seg_base) { atomicOr(&c->overflow, 8u); a.hit_start[k] = 0xFFFFFFFFu; hit_col[k] = 0u; }
-      else {
-         hit_col[k] = (uint32_t)(hp - q);
-         a.hit_start[k] = (uint32_t)(q - a.seg_base);
+      /* k_pair under SQ_IGNORE named this line unseen (it began before the candidate's tile): without a skipped byte in it, or with fewer than
+         m - tau other characters, there is nothing a skipped byte could hide -- the marker goes (were it a repeat of its line it would not be
+         here).  (Evaluated BEFORE the branches below: as the condition of an `else if` between them the loop of order_marker_holds made the
+         gfx950 build store the start in hit_col and nothing in hit_start -- gone with a printf in the branch; ROCm 7.2.0.) */
+      uint32_t keep = 1u, holds = 1u;
+      if (a.ig_thr != 0u && (e.w & 2u) != 0u && q >= a.seg_base) holds = order_marker_holds(a, q) ? 1u : 0u;
+      if (!holds) {
+         keep = e.w & 1u;                                 /* (the marker stood on a candidate of the walk: that stays, as under SQ_FAIL) */
+         ent[k].w = e.w | 4u;                             /* (bit 2: a marker no more) */
       }
+      uint32_t out_start, out_col;
+      if (q < a.seg_base) { atomicOr(&c->overflow, 8u); out_start = 0xFFFFFFFFu; out_col = 0u; }
+      else if (!keep) { out_start = 0xFFFFFFFFu; out_col = 0u; }
+      else { out_start = (uint32_t)(q - a.seg_base); out_col = (uint32_t)(hp - q); }
+      a.hit_start[k] = out_start;
+      hit_col[k] = out_col;
    }
 }
 

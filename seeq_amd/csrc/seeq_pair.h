@@ -119,6 +119,38 @@ __device__ __forceinline__ uint32_t pair_word8(const fused_v4u &p, const fused_v
 
 typedef uint32_t pair_u32_unaligned __attribute__((aligned(1)));
 
+/* SQ_IGNORE (IG, round 5): the bytes of 32 characters that the reference SKIPS (libseeq.c:265-266; seeqcore.h:89-111: everything but A C G T U N in
+ * either case, the newline and -- flagged here too, which only makes the rule below more careful -- NUL), as a mask, first character = bit 31: per
+ * word the canonical byte of its table column under the column's fold mask (column 2 folds bit 0 as well: T and U), a non-zero byte = skipped. */
+__device__ __forceinline__ uint32_t pair_skip_mask32(const fused_v4u &a, const fused_v4u &b)
+{
+   const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+   uint32_t sm = 0;
+#pragma unroll
+   for (int k = 0; k < 8; k += 2) {
+      uint32_t f[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+         const uint32_t x = w[k + u];
+         const uint32_t idx = (x & 0x0E0E0E0Eu) >> 1;
+         const uint32_t y = (x & __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDEDFDFu, idx)) ^ __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx);
+         f[u] = ((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
+      }
+      sm = __builtin_amdgcn_udot4(f[0], 0x10204080u, __builtin_amdgcn_udot4(f[1], 0x01020408u, sm << 8, false), false);
+   }
+   return sm;
+}
+
+/* characters of the lane's 128 in front of lane-relative position b (0 .. 128) that are set in the masks m[] (first character of a group = bit 31);
+   c[] = the groups' exclusive prefix counts, c[4] = the total */
+__device__ __forceinline__ uint32_t pair_count_before(const uint32_t (&m)[4], const uint32_t (&c)[5], uint32_t b)
+{
+   const uint32_t r = b >> 5, lz = b & 31u;
+   const uint32_t mr = r == 0 ? m[0] : r == 1 ? m[1] : r == 2 ? m[2] : r == 3 ? m[3] : 0u;
+   const uint32_t cr = r == 0 ? c[0] : r == 1 ? c[1] : r == 2 ? c[2] : r == 3 ? c[3] : c[4];
+   return cr + (lz ? (uint32_t)__popc(mr >> (32u - lz)) : 0u);
+}
+
 /* The walk of one tile: warm-up of both chains, then their 64 owned bytes each; CHK: the fast alphabet check and the fast newline masks
  * ride along (nmask[], bad); else the caller makes the masks. */
 template <int WU, bool CHK>
@@ -145,9 +177,18 @@ __device__ __forceinline__ void pair_walk(const fused_v4u (&v)[8], uint32_t halo
 }
 
 /* WU: warm-up dwords (4 .. 8); FA: FASTA input (header lines: see k_stream) */
-template <int WU, bool FA>
+/* IG (round 5): SQ_IGNORE on read-length lines.  A skipped byte stretches the text a match spans, so the walk over aliased bytes says nothing about
+ * a line that holds one -- but every such line can be NAMED: an occurrence with <= tau errors takes at least m - tau characters that are not skipped,
+ * all inside its line, so a line with a skipped byte and that many other characters is a candidate from its first byte to its end whatever the walk
+ * said (a MARKER entry at the line's last character), a line with a skipped byte and fewer holds no occurrence, and a line without one is what it is
+ * under SQ_FAIL: the walk's candidates, windows and all.  The counts come from bit masks of the skipped bytes and a segmented prefix sum over the lanes
+ * (FusedArgs.ig_thr = m - tau); a line belongs to the tile it starts in, which reads the part of it that lies behind the tile (256 bytes) to count it
+ * whole: FASTQ quality lines hold ~10 such characters in 150 and stay silent, headers and '+' lines hold none.  k_bounds2 (seeq_order.h) adds a
+ * frequency bound on the pattern's most frequent base, and counts the rare line that was marked unseen (longer than a tile, or than the 256 bytes). */
+template <int WU, bool FA, bool IG = false>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
 {
+   static_assert(!(FA && IG), "SQ_IGNORE on FASTA input stays with k_stream");
    constexpr int NW = STREAM_NW;
    constexpr int CH = 128;
    constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
@@ -256,6 +297,103 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
             hm[x] &= np >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> np);
          }
       }
+      uint32_t mk[2] = {0u, 0u};                          /* IG: pairs of hm[] that are line markers */
+      const uint32_t walk_hm[2] = {hm[0], hm[1]};         /* IG: ... and what the walk itself flagged (a marker k_bounds2 drops may stand on a candidate: that one stays) */
+      if (IG) {
+         /* line ENDS of the tile: its newlines (the one in the buffer's very last byte included: it starts no line, but it ends one) and
+            -- e_tail, tile-relative 1 .. TB -- the end of the buffer when no newline closes it / the byte behind the tile when it is a newline */
+         uint32_t e_tail = 0;
+         if (t0 <= last && last < t0 + TB) { if (a.text[last] != '\n') e_tail = (uint32_t)(last - t0) + 1u; }
+         else if (!partial && a.text[t0 + TB] == '\n') e_tail = TB;
+         e_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_tail);
+         uint32_t vm[NM], sk[NM], dn[NM];
+#pragma unroll
+         for (int r = 0; r < NM; r++) {
+            const uint32_t lo = 32u * r;
+            vm[r] = valid <= lo ? 0u : (valid >= lo + 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (valid - lo)));
+            sk[r] = dmode ? pair_skip_mask32(v[2 * r], v[2 * r + 1]) & vm[r] : 0u;      /* (a tile that passed the fast check holds no skipped byte) */
+            dn[r] = ~(nmask[r] | sk[r]) & vm[r];
+         }
+         uint32_t cD[5], cS[5];
+         cD[0] = 0; cS[0] = 0;
+#pragma unroll
+         for (int r = 0; r < NM; r++) { cD[r + 1] = cD[r] + (uint32_t)__popc(dn[r]); cS[r + 1] = cS[r] + (uint32_t)__popc(sk[r]); }
+         /* a newline in my first byte ends the line of the lane before me: it is that lane's end at b = 128 */
+         const uint32_t end_after = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(nmask[0] >> 31), 0x130, 0xf, 0xf, true);      /* wave_shl:1 -- lane 63: 0 */
+         uint32_t b_tail = 0;                             /* a line end at lane-relative 1 .. 128 that no newline bit of mine stands for */
+         if (e_tail && (uint32_t)lane == (e_tail - 1u) / CH) b_tail = e_tail - (uint32_t)lane * CH;
+         if (end_after) b_tail = CH;
+         /* what the lanes behind me need: {a line ended in me, characters / skipped bytes behind my last line end} -- a segmented sum */
+         uint32_t lastb = 0, hasend = 0;                  /* lane-relative position behind my last end's line (its newline, or b_tail) */
+#pragma unroll
+         for (int r = 0; r < NM; r++)
+            if (nmask[r]) { lastb = 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])); hasend = 1u; }
+         if (b_tail) { lastb = b_tail; hasend = 1u; }
+         uint32_t P = (hasend << 31) | (cD[4] - pair_count_before(dn, cD, lastb)) | ((cS[4] - pair_count_before(sk, cS, lastb)) << 14);
+#define PAIR_SEG(ctrl, rmask) { const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, ctrl, rmask, 0xf, true); P = (P >> 31) ? P : y + P; }
+         PAIR_SEG(0x111, 0xf) PAIR_SEG(0x112, 0xf) PAIR_SEG(0x114, 0xf) PAIR_SEG(0x118, 0xf) PAIR_SEG(0x142, 0xa) PAIR_SEG(0x143, 0xc)
+#undef PAIR_SEG
+         /* A line belongs to the tile it STARTS in: the tile whose first byte follows a newline (or is the buffer's first) knows its first line
+            from its start; a line that began before the tile was the business of the tile before (below: the tail) */
+         const uint32_t starts_line = (uint32_t)__builtin_amdgcn_readfirstlane((t0 == 0 || (t0 >= 32 && ((uint32_t)__builtin_amdgcn_readlane((int)halo, 7) >> 24) == 0x0Au)) ? 1 : 0);
+         const uint32_t before = stream_from_prev_lane(P, starts_line << 31);
+         /* my line ends, in order: the line's counts = those since the end before it (the first: + what the lanes before me bring) */
+         uint32_t accD = before & 0x3FFFu, accS = (before >> 14) & 0x3FFFu, known = before >> 31, fromD = 0, fromS = 0;
+         auto mark = [&](uint32_t pq) { if (pq < 32u) mk[0] |= 0x80000000u >> pq; else mk[1] |= 0x80000000u >> (pq - 32u); };
+         auto line_end = [&](uint32_t b) {
+            const uint32_t Dc = pair_count_before(dn, cD, b), Sc = pair_count_before(sk, cS, b);
+            if (b >= 1u) {                                /* (b = 0: the lane before me has it as its b = 128) */
+               const uint32_t lineD = Dc - fromD + accD, lineS = Sc - fromS + accS;
+               if (known && lineS != 0u && lineD >= a.ig_thr) mark((b - 1u) >> 1);
+            }
+            fromD = Dc; fromS = Sc; accD = 0; accS = 0; known = 1u;
+         };
+#pragma unroll
+         for (int r = 0; r < NM; r++) {
+            uint32_t mm = nmask[r];
+            while (mm) {
+               const uint32_t lz = (uint32_t)__builtin_clz(mm);
+               mm &= ~(0x80000000u >> lz);
+               line_end(32u * r + lz);
+            }
+         }
+         if (b_tail) line_end(b_tail);
+         /* The TAIL: the line that runs past my last byte (not the buffer's last tile, no line end right at the tile's end).  Its remainder is
+            read from the text behind the tile -- 256 bytes, four per lane: a read-length line ends there -- and its marker, when it needs one,
+            stands on the tile's last pair: inside the line, in front of whatever the next tile finds in it (repeats of the line).  A line that
+            is longer, or that began before this tile as well, gets the marker unseen: k_bounds2 (seeq_order.h) reads it whole. */
+         {
+            const uint32_t tile_valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(partial ? (uint32_t)(lim - t0) : TB));
+            const uint32_t lv = (tile_valid - 1u) >> 7, bb = (tile_valid - 1u) & 127u;
+            const uint32_t ng = (bb >> 5) == 0 ? nmask[0] : (bb >> 5) == 1 ? nmask[1] : (bb >> 5) == 2 ? nmask[2] : nmask[3];
+            const uint32_t last_is_nl = (uint32_t)__builtin_amdgcn_readlane((int)((ng >> (31u - (bb & 31u))) & 1u), (int)lv);
+            const bool buffer_last = t0 <= last && last < t0 + TB;
+            if (!buffer_last && e_tail == 0u && !last_is_nl) {               /* (wave-uniform) */
+               const uint32_t P63 = (uint32_t)__builtin_amdgcn_readlane((int)P, 63);
+               const uint32_t started_here = (P63 >> 31) | starts_line;
+               const uint64_t pk = t0 + tile_valid + 4u * (uint32_t)lane;
+               uint32_t w = 0x0A0A0A0Au;                                       /* (behind the buffer: a line end) */
+               if (pk + 4 <= a.nbytes) w = *reinterpret_cast<const pair_u32_unaligned *>(a.text + pk);
+               else for (int i = 3; i >= 0; i--) w = (w << 8) | (pk + (uint64_t)i < a.nbytes ? (uint32_t)a.text[pk + i] : 0x0Au);
+               const uint32_t nlf = nl_flags(w);
+               const uint64_t nlb = __ballot(nlf != 0u);
+               uint32_t qualifies = 1u;                                        /* unseen: the marker goes out, k_bounds2 decides */
+               if (nlb != 0ull && started_here) {
+                  const uint32_t F = (uint32_t)__builtin_ctzll(nlb);
+                  const uint32_t nbytes_mine = (uint32_t)lane < F ? 4u : (uint32_t)lane == F ? ((uint32_t)__builtin_ctz(nlf) >> 3) : 0u;      /* my bytes in front of the newline */
+                  const uint32_t keepm = nbytes_mine >= 4u ? 0xFFFFFFFFu : (1u << (8u * nbytes_mine)) - 1u;
+                  const uint32_t idx = (w & 0x0E0E0E0Eu) >> 1;
+                  const uint32_t y = ((w & __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDEDFDFu, idx)) ^ __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx)) & keepm;
+                  const uint32_t cs = (uint32_t)__popc((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);
+                  const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32((nbytes_mine - cs) | (cs << 16)), 63);
+                  const uint32_t lineD = (P63 & 0x3FFFu) + (tot & 0xFFFFu), lineS = ((P63 >> 14) & 0x3FFFu) + (tot >> 16);
+                  qualifies = (lineS != 0u && lineD >= a.ig_thr) ? 1u : 0u;
+               }
+               if (qualifies && (uint32_t)lane == lv) mark(bb >> 1);
+            }
+         }
+         hm[0] |= mk[0]; hm[1] |= mk[1];
+      }
       if (t0 <= last && last < t0 + TB) {                 /* a newline in the very last byte starts no line */
          const uint32_t o = (uint32_t)(last - t0);
          if ((uint32_t)lane == o / CH) {
@@ -336,9 +474,13 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
                for (int r = 0; r < NM; r++) {
                   /* the pairs of this 32-byte group, first pair in bit 31 */
                   uint32_t mm = (r & 1) ? hm[r >> 1] << 16 : hm[r >> 1] & 0xFFFF0000u;
+                  const uint32_t mkm = (r & 1) ? mk[r >> 1] << 16 : mk[r >> 1] & 0xFFFF0000u;
+                  const uint32_t wkm = (r & 1) ? walk_hm[r >> 1] << 16 : walk_hm[r >> 1] & 0xFFFF0000u;
                   while (mm) {
                      const uint32_t lp = (uint32_t)__builtin_clz(mm);
                      mm &= ~(0x80000000u >> lp);
+                     /* bit 30 of the entry's first word: a line marker; bit 29: ... on a pair the walk flagged as well */
+                     const uint32_t isk = IG ? (((mkm << lp) >> 31) << 30) | ((((mkm & wkm) << lp) >> 31) << 29) : 0u;
                      uint32_t lz = 2u * lp + 1u;                            /* the pair's second byte, within the group */
                      if (partial && 32u * r + lz >= valid) lz = valid - 1u - 32u * r;      /* ... or its first, when the segment ends between them */
                      const uint32_t nlt = lz ? nmask[r] >> (32 - lz) : 0u;  /* newlines before it, same group */
@@ -347,7 +489,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
                      const uint32_t hp = (uint32_t)lane * CH + 32u * r + lz;           /* the candidate, tile-relative */
                      const uint32_t pos = st1 ? st1 - 1u : hp;
                      /* {tile | unresolved, rank | column of the candidate << 13, line start (or candidate) position, line rank} */
-                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u), ord | ((hp - pos) << 13),
+                     slice[slice_pos + ord] = make_uint4(tile | (st1 ? 0u : 0x80000000u) | isk, ord | ((hp - pos) << 13),
                                                          tile * TB + pos + a.pos_bias, nlb + nb);
                      ord++;
                   }

@@ -68,6 +68,7 @@ struct ScanPlan {
    bool lead_best;
    bool verify;            /* the exact pass is k_verify (+ k_nh_top, k_emit1): filters on text without skipped bytes, read-length lines */
    bool order2;            /* the hit list is made by seeq_order.h's three launches (read-length lines behind k_pair / k_stream) */
+   bool ig;                /* k_pair under SQ_IGNORE: line markers (seeq_pair.h IG), k_exact1 behind it */
    uint32_t skip_back, walk_ext, skip_thr;
 };
 
@@ -137,7 +138,10 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
       keep a superset a superset; a skipped byte, SQ_IGNORE, does not), while it makes few false candidates. */
    {
       const bool long_lines = (in.avg_line > 600.0 && kn.kernel != 3) || in.force_ll;      /* (a candidate inside a line of a whole tile sets force_ll) */
-      if (p.fusable && in.force_path != 1 && (options & PLAN_MASK_INPUT) == 0 && (nd == 0 || nd == PLAN_SQ_CONVERT) && !long_lines && !in.no_stream &&
+      /* (round 5: SQ_IGNORE too -- a line that holds a skipped byte is named whole by a marker, every other line is what it is under SQ_FAIL: IG in
+         seeq_pair.h; not FASTA input, not several patterns at once) */
+      const bool ig_ok = nd == PLAN_SQ_IGNORE && !fasta && !in.multi_active;
+      if (p.fusable && in.force_path != 1 && (options & PLAN_MASK_INPUT) == 0 && (nd == 0 || nd == PLAN_SQ_CONVERT || ig_ok) && !long_lines && !in.no_stream &&
           /* (round 5: text full of foreign bytes -- FASTQ records -- stays here: a tile that fails the fast alphabet check makes its newline
              masks again from its registers, and the exact pass looks at the bytes before a window, seeq_verify.h.  FASTA records with a
              header per read stay with k_stream: the header test of the FA variant reads a byte per newline) */
@@ -145,7 +149,7 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
          if (au.pair_state == 0) ensure(ctx, 1, 0, &au);
          p.use_pair = au.pair_state == 1 && (kn.kernel == 3 || in.multi_active || au.pair_pacc * in.avg_line <= 0.25);
       }
-      if (p.use_pair) { p.use_stream = true; p.can_sub = false; }
+      if (p.use_pair) { p.use_stream = true; p.can_sub = false; p.ig = nd == PLAN_SQ_IGNORE; }
       if (in.multi_active && !p.use_pair) { p.rc = -2; return p; }      /* this text / these options are not k_pair's: a scan per pattern */
    }
    /* k_stream's Myers mode: no automaton fits (or only a filter that is not selective enough), the lines are too long for

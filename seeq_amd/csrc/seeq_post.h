@@ -34,6 +34,6 @@ void seeq_launch_emit_all(int fw, unsigned grid, unsigned vgrid, hipStream_t st,
 #define SEEQ_ORDER_BLOCK      2048
 void seeq_launch_tiles_post(hipStream_t st, const FusedArgs &f, uint32_t nslices, uint32_t *bsum, uint32_t nb);
 void seeq_launch_order(unsigned grid, hipStream_t st, const FusedArgs &f, uint32_t nslices, const uint32_t *bsum, uint32_t nb, uint4 *ent);
-void seeq_launch_bounds2(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *ent, uint32_t *hit_col);
+void seeq_launch_bounds2(unsigned grid, hipStream_t st, const ScanArgs &a, uint4 *ent, uint32_t *hit_col);
 
 #endif

@@ -58,6 +58,7 @@ struct FusedArgs {
    uint32_t       ll_filter;        /* k_stream's long-line variant walks a partition filter: a chain that starts blind (accepting state) reports its first byte */
    uint32_t       skip_thr;         /* k_stream under SQ_IGNORE: m - tau when the automaton is the complete one -- a chain whose line holds fewer characters that
                                        are not skipped makes up no candidate (0: every chain with a skipped byte in its warm-up window does) */
+   uint32_t       ig_thr;           /* k_pair under SQ_IGNORE (IG): m - tau, the characters that are not skipped an occurrence needs at least */
    uint32_t       pair;             /* 1: k_pair (two bytes per step; everything it reports is a candidate); 2: k_stream's Myers mode (exact on clean text
                                        under SQ_CONVERT too).  Nonzero: text with non-DNA bytes needs no re-run on another kernel */
    Counters      *cnt;

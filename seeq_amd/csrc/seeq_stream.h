@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_stream_reorder(FusedArgs a, uint32_t ns
          for (int u = 0; u < 4; u++) e[u] = i0 + 64u * u < n ? slice[i0 + 64u * u] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
          for (int u = 0; u < 4; u++) {
-            const uint32_t tile = e[u].x & 0x7FFFFFFFu;
+            const uint32_t tile = e[u].x & 0x1FFFFFFFu;
             const bool ok = i0 + 64u * u < n;
             th[u] = ok ? a.tile_hits[tile] : 0u;
             tc[u] = ok ? a.tile_cl[tile] : 0u;

@@ -82,6 +82,9 @@ struct ScanArgs {
                                    (line - 1) * rec_pitch, the offset the same read has in the ASCII form of the batch (0: the line's real offset) */
    uint32_t       *nz_sum;      /* k_verify: per chunk the entries with >= 1 hit (NULL: not wanted) */
    uint32_t        fin;         /* != 0: k_nh_top ends the segment (seg_end_body with flags fin - 1); 0: k_seg_end does, behind the EMIT pass */
+   uint32_t        ig_thr;      /* k_pair under SQ_IGNORE: m - tau (line markers: seeq_pair.h IG); else 0 */
+   uint32_t        ig_need, ig_bval, ig_bmask;      /* ... the frequency bound of seeq_order.h: at least ig_need bytes c with (c & ig_bmask) == ig_bval in a marker's line (0: off) */
+   const uint4    *ig_ent;      /* ... the ordered entries (seeq_order.h): word 3, bit 1 = the entry is a line marker (bit 0: ... that stands on a candidate of the walk); else NULL */
    uint32_t        vrange;      /* k_verify: entries per workgroup range, 256 .. 1024 (0: 256): the repeats of a range are packed away before the walk */
    Counters      *cnt;
 };

@@ -54,7 +54,7 @@ void seeq_launch_order(unsigned grid, hipStream_t st, const FusedArgs &f, uint32
    hipLaunchKernelGGL(k_order, dim3(grid), dim3(256), 0, st, f, nslices, bsum, nb, ent);
 }
 
-void seeq_launch_bounds2(unsigned grid, hipStream_t st, const ScanArgs &a, const uint4 *ent, uint32_t *hit_col)
+void seeq_launch_bounds2(unsigned grid, hipStream_t st, const ScanArgs &a, uint4 *ent, uint32_t *hit_col)
 {
    hipLaunchKernelGGL(k_bounds2, dim3(grid), dim3(256), 0, st, a, ent, hit_col);
 }

@@ -1065,7 +1065,9 @@ def test_ignore_and_convert_with_foreign_bytes_inside_matches(gpu, capi, oracle)
 @pytest.mark.parametrize("seg", [None, "65536"])
 def test_fastq_records_on_the_pair_walk(gpu, capi, oracle, seg, monkeypatch):
     """Round 5: FASTQ-shaped text (four-line records, quality lines made of bytes that alias onto bases AND onto the newline
-    column: '+', ':', ';', '*', 'J') stays on k_pair under SQ_FAIL and SQ_CONVERT.  Every tile fails the fast alphabet check
+    column: '+', ':', ';', '*', 'J') stays on k_pair under SQ_FAIL, SQ_CONVERT and -- lines that hold a skipped byte named whole by
+    markers, seeq_pair.h IG -- SQ_IGNORE (there the copies planted in quality lines behind foreign bytes ARE hits, with the bytes
+    between their characters skipped).  Every tile fails the fast alphabet check
     there, remakes its newline masks from its registers, and k_verify looks at the bytes between a line's start and a
     candidate's window (reference libseeq.c:267-270: under SQ_FAIL such a byte ends the line).  Adversarial lines: a perfect
     copy of the pattern in a quality line BEHIND a foreign byte (no hit under SQ_FAIL, a hit under SQ_CONVERT), in front of the
@@ -1112,7 +1114,7 @@ def test_fastq_records_on_the_pair_walk(gpu, capi, oracle, seg, monkeypatch):
         buf = ("\n".join(lines) + ("\n" if rng.random() < 0.5 else "")).encode("latin-1")
         pat = dev.Pattern(pattern, tau)
         sc = dev.Scanner()
-        for nd in (SQ_FAIL, SQ_CONVERT):
+        for nd in (SQ_FAIL, SQ_CONVERT, SQ_IGNORE):
             for opt in (SQ_FIRST, SQ_BEST, SQ_ALL):
                 exp = oracle.buffer_scan(pattern, tau, buf, opt | nd)
                 got = sc.scan_host(pat, buf, opt | nd, dev.WANT_RECORDS)

@@ -574,8 +574,11 @@ def test_scan_plans_of_the_baseline_configurations(harness):
     # configs[4]: 40 positions, d = 5, 250 bp reads, --all: two-word column, a partition filter on k_pair
     p = plan("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5, SQ_ALL, RECORDS, 251.0)
     assert (p["path"], p["fw"], p["use_pair"], p["filter"], p["verify"], p["order2"]) == (6, 2, 1, 1, 1, 1), p
-    # SQ_IGNORE is not k_pair's (a skipped byte stretches a match): k_stream over the complete automaton with skip bytes, k_exact1 behind it
+    # SQ_IGNORE on read-length lines: k_pair too since round 5 (a line that holds a skipped byte is named whole by a marker: seeq_pair.h IG), with
+    # k_exact1 -- which knows how to skip -- behind it instead of k_verify; k_stream's skip variant where k_pair is told off or the input is FASTA
     p = plan(head, 3, SQ_BEST | SQ_IGNORE, RECORDS, 79.0)
+    assert (p["path"], p["use_pair"], p["stream_sub"], p["filter"], p["verify"], p["order2"], p["window_ok"]) == (6, 1, 0, 1, 0, 1, 1), p
+    p = plan(head, 3, SQ_BEST | SQ_IGNORE, RECORDS, 79.0, kernel=1)
     assert (p["path"], p["use_pair"], p["stream_sub"], p["filter"], p["verify"], p["order2"]) == (5, 0, 2, 0, 0, 1), p
     # FASTQ-shaped sample (foreign bytes), SQ_FAIL / SQ_CONVERT: k_pair since round 5 (dirty tiles remake their newline masks from registers,
     # k_verify looks at the bytes before a window); FASTA records with such a sample stay with k_stream
