@@ -133,7 +133,9 @@ int seeqdevScanCopyRecords(seeqdev_scan_t * scan, seeqdev_hit_t * host_out, size
  * holds the text go from hit to hit without walking the lines in between. */
 int seeqdevScanCopyOffsets(seeqdev_scan_t * scan, uint64_t * host_out, size_t first, size_t n);
 
-/* Page-locked host memory (hipHostMalloc / hipHostFree) for buffers handed to seeqdevScanHost. */
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for buffers handed to seeqdevScanHost.  May be called from any thread (seeqFileMatch's
+ * reader thread does): NULL + errno = ENOMEM on failure, and -- alone among these entries -- seeqerr is left untouched (it is the reference's plain
+ * global, libseeq.h:38, and belongs to the thread that calls the seeq API). */
 void * seeqdevHostAlloc(size_t bytes);
 void   seeqdevHostFree(void * p);
 

@@ -2322,10 +2322,11 @@ extern "C" long seeqdevPackReads(const char *text, size_t nbytes, uint32_t read_
 /* Page-locked host memory for staging buffers (H2D at link speed instead of through a bounce buffer). */
 extern "C" void *seeqdevHostAlloc(size_t bytes)
 {
+   /* Called from seeqFileMatch's READER THREAD (seeq_file.c slot_reserve): seeqerr is the reference's plain global (libseeq.h:38) and belongs to the
+      caller's thread -- this entry reports through errno (thread-local) alone; seeq_file.c clears seeqerr where it hands the failure to the caller. */
    void *p = NULL;
-   seeqerr = 0;
    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);      /* every device may copy from it */
-   if (e != hipSuccess) { hip_fail(e, "hipHostMalloc", ENOMEM); return NULL; }
+   if (e != hipSuccess) { snprintf(g_last_error, sizeof g_last_error, "hipHostMalloc: %s", hipGetErrorString(e)); errno = ENOMEM; return NULL; }
    return p;
 }
 

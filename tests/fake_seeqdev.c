@@ -67,7 +67,7 @@ static int fake_fail(int fp, int err_no)
          char *end;
          unsigned long lo = strtoul(e + ln + 1, &end, 10), hi = lo;
          if (*end == '-') { hi = end[1] >= '0' && end[1] <= '9' ? strtoul(end + 1, &end, 10) : ~0ul; }
-         if (n >= lo && n <= hi) { seeqerr = 0; errno = err_no; return 1; }
+         if (n >= lo && n <= hi) { if (fp != FP_HOSTALLOC) seeqerr = 0; errno = err_no; return 1; }   /* (HostAlloc runs on the reader thread: errno only, as the HIP library's) */
       }
       while (*e && *e != ',') e++;
       if (*e == ',') e++;
