@@ -119,26 +119,33 @@ __device__ __forceinline__ uint32_t pair_word8(const fused_v4u &p, const fused_v
 
 typedef uint32_t pair_u32_unaligned __attribute__((aligned(1)));
 
-/* SQ_IGNORE (IG, round 5): the bytes of 32 characters that the reference SKIPS (libseeq.c:265-266; seeqcore.h:89-111: everything but A C G T U N in
- * either case, the newline and -- flagged here too, which only makes the rule below more careful -- NUL), as a mask, first character = bit 31: per
- * word the canonical byte of its table column under the column's fold mask (column 2 folds bit 0 as well: T and U), a non-zero byte = skipped. */
-__device__ __forceinline__ uint32_t pair_skip_mask32(const fused_v4u &a, const fused_v4u &b)
+/* SQ_IGNORE (IG, round 5): which of 32 characters are NOT bases -- everything but A C G T U N in either case (seeqcore.h:89-111) --, as a mask,
+ * first character = bit 31.  The reference skips such a byte (libseeq.c:265-266) unless it ends the line: skipped = this mask without the newlines
+ * (a NUL counts as skipped here, which only makes the rule below more careful).  Per word: the low three bits of a byte pick its column's one base
+ * from an eight-entry table (v_perm; A 1, C 3, T 4, U 5, N 6, G 7; columns 0 and 2 -- the newline's -- hold none), the byte is a base when it equals
+ * it apart from bit 5; the four flags drop into the mask by v_dot4 (the flags stay at bit 7: the sums carry a factor 128, taken out per 16
+ * characters).  8.5 VALU per word. */
+__device__ __forceinline__ uint32_t pair_nonbase_mask32(const fused_v4u &a, const fused_v4u &b)
 {
    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-   uint32_t sm = 0;
+   uint32_t h[2];
 #pragma unroll
-   for (int k = 0; k < 8; k += 2) {
-      uint32_t f[2];
+   for (int g = 0; g < 2; g++) {
+      uint32_t acc = 0;
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-         const uint32_t x = w[k + u];
-         const uint32_t idx = (x & 0x0E0E0E0Eu) >> 1;
-         const uint32_t y = (x & __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDEDFDFu, idx)) ^ __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx);
-         f[u] = ((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) >> 7) & 0x01010101u;
+      for (int k = 4 * g; k < 4 * g + 4; k += 2) {
+         uint32_t f[2];
+#pragma unroll
+         for (int u = 0; u < 2; u++) {
+            const uint32_t x = w[k + u];
+            const uint32_t t = x ^ __builtin_amdgcn_perm(0x474E5554u, 0x43FF41FFu, x & 0x07070707u);
+            f[u] = (((t & 0x5F5F5F5Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+         }
+         acc = __builtin_amdgcn_udot4(f[0], 0x10204080u, __builtin_amdgcn_udot4(f[1], 0x01020408u, acc << 8, false), false);
       }
-      sm = __builtin_amdgcn_udot4(f[0], 0x10204080u, __builtin_amdgcn_udot4(f[1], 0x01020408u, sm << 8, false), false);
+      h[g] = acc;
    }
-   return sm;
+   return (h[0] << 9) | (h[1] >> 7);
 }
 
 /* characters of the lane's 128 in front of lane-relative position b (0 .. 128) that are set in the masks m[] (first character of a group = bit 31);
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          for (int r = 0; r < NM; r++) {
             const uint32_t lo = 32u * r;
             vm[r] = valid <= lo ? 0u : (valid >= lo + 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (valid - lo)));
-            sk[r] = dmode ? pair_skip_mask32(v[2 * r], v[2 * r + 1]) & vm[r] : 0u;      /* (a tile that passed the fast check holds no skipped byte) */
+            sk[r] = dmode ? pair_nonbase_mask32(v[2 * r], v[2 * r + 1]) & ~nmask[r] & vm[r] : 0u;      /* (a tile that passed the fast check holds no skipped byte) */
             dn[r] = ~(nmask[r] | sk[r]) & vm[r];
          }
          uint32_t cD[5], cS[5];
@@ -323,30 +330,18 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          uint32_t b_tail = 0;                             /* a line end at lane-relative 1 .. 128 that no newline bit of mine stands for */
          if (e_tail && (uint32_t)lane == (e_tail - 1u) / CH) b_tail = e_tail - (uint32_t)lane * CH;
          if (end_after) b_tail = CH;
-         /* what the lanes behind me need: {a line ended in me, characters / skipped bytes behind my last line end} -- a segmented sum */
-         uint32_t lastb = 0, hasend = 0;                  /* lane-relative position behind my last end's line (its newline, or b_tail) */
-#pragma unroll
-         for (int r = 0; r < NM; r++)
-            if (nmask[r]) { lastb = 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])); hasend = 1u; }
-         if (b_tail) { lastb = b_tail; hasend = 1u; }
-         uint32_t P = (hasend << 31) | (cD[4] - pair_count_before(dn, cD, lastb)) | ((cS[4] - pair_count_before(sk, cS, lastb)) << 14);
-#define PAIR_SEG(ctrl, rmask) { const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, ctrl, rmask, 0xf, true); P = (P >> 31) ? P : y + P; }
-         PAIR_SEG(0x111, 0xf) PAIR_SEG(0x112, 0xf) PAIR_SEG(0x114, 0xf) PAIR_SEG(0x118, 0xf) PAIR_SEG(0x142, 0xa) PAIR_SEG(0x143, 0xc)
-#undef PAIR_SEG
-         /* A line belongs to the tile it STARTS in: the tile whose first byte follows a newline (or is the buffer's first) knows its first line
-            from its start; a line that began before the tile was the business of the tile before (below: the tail) */
-         const uint32_t starts_line = (uint32_t)__builtin_amdgcn_readfirstlane((t0 == 0 || (t0 >= 32 && ((uint32_t)__builtin_amdgcn_readlane((int)halo, 7) >> 24) == 0x0Au)) ? 1 : 0);
-         const uint32_t before = stream_from_prev_lane(P, starts_line << 31);
-         /* my line ends, in order: the line's counts = those since the end before it (the first: + what the lanes before me bring) */
-         uint32_t accD = before & 0x3FFFu, accS = (before >> 14) & 0x3FFFu, known = before >> 31, fromD = 0, fromS = 0;
+         /* My line ends, in order.  A line's counts are those since the end before it; the FIRST end of a lane closes a line that began in an earlier
+            lane (or tile): its part in me is kept (first*) until the lanes before me have been summed up; every later line lies in me whole.
+            (baseD / baseS: minus the counts at the end before.) */
+         uint32_t baseD = 0, baseS = 0, seen_end = 0, firstP = 0, first_pq = 0;       /* firstP: bit 31 = there is one | skipped << 14 | characters */
          auto mark = [&](uint32_t pq) { if (pq < 32u) mk[0] |= 0x80000000u >> pq; else mk[1] |= 0x80000000u >> (pq - 32u); };
-         auto line_end = [&](uint32_t b) {
-            const uint32_t Dc = pair_count_before(dn, cD, b), Sc = pair_count_before(sk, cS, b);
+         auto line_end = [&](uint32_t b, uint32_t Dc, uint32_t Sc) {          /* Dc / Sc: characters / skipped bytes of mine in front of b */
             if (b >= 1u) {                                /* (b = 0: the lane before me has it as its b = 128) */
-               const uint32_t lineD = Dc - fromD + accD, lineS = Sc - fromS + accS;
-               if (known && lineS != 0u && lineD >= a.ig_thr) mark((b - 1u) >> 1);
+               const uint32_t lineD = Dc + baseD, lineS = Sc + baseS;
+               if (!seen_end) { firstP = 0x80000000u | (lineS << 14) | lineD; first_pq = (b - 1u) >> 1; }
+               else if (lineS != 0u && lineD >= a.ig_thr) mark((b - 1u) >> 1);
             }
-            fromD = Dc; fromS = Sc; accD = 0; accS = 0; known = 1u;
+            baseD = 0u - Dc; baseS = 0u - Sc; seen_end = 1u;
          };
 #pragma unroll
          for (int r = 0; r < NM; r++) {
@@ -354,10 +349,27 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
             while (mm) {
                const uint32_t lz = (uint32_t)__builtin_clz(mm);
                mm &= ~(0x80000000u >> lz);
-               line_end(32u * r + lz);
+               line_end(32u * r + lz, cD[r] + (uint32_t)__popc((dn[r] >> 1) >> (31u - lz)), cS[r] + (uint32_t)__popc((sk[r] >> 1) >> (31u - lz)));
             }
          }
-         if (b_tail) line_end(b_tail);
+         if (__ballot(b_tail != 0u)) {                    /* (wave-uniform; all but the buffer's own end stand behind the lane's last byte) */
+            if (b_tail == CH) line_end(CH, cD[4], cS[4]);
+            else if (b_tail) line_end(b_tail, pair_count_before(dn, cD, b_tail), pair_count_before(sk, cS, b_tail));
+         }
+         /* what the lanes behind me need: {a line ended in me, characters / skipped bytes behind my last line end} -- a segmented sum */
+         uint32_t P = (seen_end << 31) | (cD[4] + baseD) | ((cS[4] + baseS) << 14);
+#define PAIR_SEG(ctrl, rmask) { const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, ctrl, rmask, 0xf, true); P = (P >> 31) ? P : y + P; }
+         PAIR_SEG(0x111, 0xf) PAIR_SEG(0x112, 0xf) PAIR_SEG(0x114, 0xf) PAIR_SEG(0x118, 0xf) PAIR_SEG(0x142, 0xa) PAIR_SEG(0x143, 0xc)
+#undef PAIR_SEG
+         /* A line belongs to the tile it STARTS in: the tile whose first byte follows a newline (or is the buffer's first) knows its first line
+            from its start; a line that began before the tile was the business of the tile before (below: the tail) */
+         const uint32_t starts_line = (uint32_t)__builtin_amdgcn_readfirstlane((t0 == 0 || (t0 >= 32 && ((uint32_t)__builtin_amdgcn_readlane((int)halo, 7) >> 24) == 0x0Au)) ? 1 : 0);
+         const uint32_t before = stream_from_prev_lane(P, starts_line << 31);
+         /* the lane's first end: + what the lanes before me bring (known: the line's start was seen) */
+         if ((firstP & before) >> 31) {
+            const uint32_t sum = (firstP & 0x0FFFFFFFu) + (before & 0x0FFFFFFFu);
+            if ((sum >> 14) != 0u && (sum & 0x3FFFu) >= a.ig_thr) mark(first_pq);
+         }
          /* The TAIL: the line that runs past my last byte (not the buffer's last tile, no line end right at the tile's end).  Its remainder is
             read from the text behind the tile -- 256 bytes, four per lane: a read-length line ends there -- and its marker, when it needs one,
             stands on the tile's last pair: inside the line, in front of whatever the next tile finds in it (repeats of the line).  A line that
@@ -382,9 +394,8 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
                   const uint32_t F = (uint32_t)__builtin_ctzll(nlb);
                   const uint32_t nbytes_mine = (uint32_t)lane < F ? 4u : (uint32_t)lane == F ? ((uint32_t)__builtin_ctz(nlf) >> 3) : 0u;      /* my bytes in front of the newline */
                   const uint32_t keepm = nbytes_mine >= 4u ? 0xFFFFFFFFu : (1u << (8u * nbytes_mine)) - 1u;
-                  const uint32_t idx = (w & 0x0E0E0E0Eu) >> 1;
-                  const uint32_t y = ((w & __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDEDFDFu, idx)) ^ __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx)) & keepm;
-                  const uint32_t cs = (uint32_t)__popc((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);
+                  const uint32_t y = (w ^ __builtin_amdgcn_perm(0x474E5554u, 0x43FF41FFu, w & 0x07070707u)) & keepm;      /* (as pair_nonbase_mask32) */
+                  const uint32_t cs = (uint32_t)__popc((((y & 0x5F5F5F5Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);
                   const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32((nbytes_mine - cs) | (cs << 16)), 63);
                   const uint32_t lineD = (P63 & 0x3FFFu) + (tot & 0xFFFFu), lineS = ((P63 >> 14) & 0x3FFFu) + (tot >> 16);
                   qualifies = (lineS != 0u && lineD >= a.ig_thr) ? 1u : 0u;

@@ -67,7 +67,7 @@ typedef __attribute__((address_space(3))) const uint16_t stream_lds_cu16;
  * the first word of a pair) drops them into the mask, two words per shift.  `clean` (wave-uniform: the tile holds only
  * bytes of the alphabet, or has been corrected): every such byte but '\n' has bit 6 set, so ~bit 6 is the flag -- the
  * dot product then sums the NON-newline flags and the mask is its complement.  Otherwise the exact zero-byte test of
- * w ^ 0x0A0A0A0A.  3.5 (clean) / 6.5 VALU per word instead of 8. */
+ * w ^ 0x0A0A0A0A.  3.5 (clean) / 6.5 VALU per word. */
 __device__ __forceinline__ uint32_t stream_nl_mask32(const fused_v4u &a, const fused_v4u &b, bool clean)
 {
    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -80,13 +80,20 @@ __device__ __forceinline__ uint32_t stream_nl_mask32(const fused_v4u &a, const f
       }
       return ~nm;
    }
+   /* (the flags stay at bit 7 of their bytes: the dot products carry a factor 128, taken out per 16 characters) */
+   uint32_t h[2];
 #pragma unroll
-   for (int k = 0; k < 8; k += 2) {
-      const uint32_t x0 = w[k] ^ 0x0A0A0A0Au, x1 = w[k + 1] ^ 0x0A0A0A0Au;
-      const uint32_t f0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u, f1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u;
-      nm = __builtin_amdgcn_udot4(f0 >> 7, 0x10204080u, __builtin_amdgcn_udot4(f1 >> 7, 0x01020408u, nm << 8, false), false);
+   for (int g = 0; g < 2; g++) {
+      nm = 0;
+#pragma unroll
+      for (int k = 4 * g; k < 4 * g + 4; k += 2) {
+         const uint32_t x0 = w[k] ^ 0x0A0A0A0Au, x1 = w[k + 1] ^ 0x0A0A0A0Au;
+         const uint32_t f0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u, f1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u;
+         nm = __builtin_amdgcn_udot4(f0, 0x10204080u, __builtin_amdgcn_udot4(f1, 0x01020408u, nm << 8, false), false);
+      }
+      h[g] = nm;
    }
-   return nm;
+   return (h[0] << 9) | (h[1] >> 7);
 }
 
 /* Two independent walks interleaved (chains A and B of one lane): twice the gathers in flight per wave. */
