@@ -142,9 +142,8 @@ __device__ __forceinline__ uint64_t order_line_start(const uint8_t *text, uint64
 __device__ __forceinline__ void order_marker_word(uint32_t w, uint32_t nby, uint32_t bm, uint32_t bv, uint32_t &ns, uint32_t &nb)
 {
    const uint32_t keepm = nby >= 4u ? 0xFFFFFFFFu : (1u << (8u * nby)) - 1u;
-   const uint32_t idx = (w & 0x0E0E0E0Eu) >> 1;
-   const uint32_t y = ((w & __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDEDFDFu, idx)) ^ __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx)) & keepm;
-   ns += (uint32_t)__popc((((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);                        /* bytes outside the alphabet */
+   const uint32_t y = (w ^ __builtin_amdgcn_perm(0x474E5554u, 0x43FF41FFu, w & 0x07070707u)) & keepm;    /* (as pair_nonbase_mask32, seeq_pair.h: no newline among these bytes) */
+   ns += (uint32_t)__popc((((y & 0x5F5F5F5Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u);                        /* bytes outside the alphabet */
    const uint32_t z = ((w & bm) ^ bv) | ~keepm;
    nb += (uint32_t)__popc(~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u);                       /* copies of the base */
 }

@@ -66,7 +66,9 @@ __device__ __forceinline__ uint32_t pair_prep(uint32_t w)
 /* Per text word, in the shadow of a gather: the FAST alphabet check -- the canonical byte of the word's table columns
  * (A C T G . \n . N, upper case) against the word, differences summed by v_sad_u8: zero over a tile = nothing but upper
  * case A C G T N and newlines (anything else, lower case included, sends the tile through the exact check) -- and the
- * newline flags of the word (column 5), dropped into the mask by v_dot4_u32_u8 (two words per shift). */
+ * newline flags of the word (column 5), dropped into the mask by v_dot4_u32_u8 (two words per shift).
+ * (Round 5: indexing the two tables by the bytes' low three bits, which tell the six bytes apart as well, saves the shift -- and was 3 % SLOWER:
+ * the allocator, at its 64 registers, spilled one more value inside the tile loop.  profiles/r05/ab_fast_check_index.txt) */
 __device__ __forceinline__ void pair_chk(uint32_t w, uint32_t &bad, uint32_t &nm, bool first_of_two)
 {
    const uint32_t idx = (w >> 1) & 0x07070707u;

@@ -366,6 +366,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
             uint32_t w0 = stream_from_prev_lane(stream_word32(v, 32 - WU), (uint32_t)__builtin_amdgcn_readlane((int)hal, 32 - WU));
             stream_myers_lookup4<MW>(w0, eqb, ev[0]);
          }
+         /* Round 5: the column is exact m + tau - 1 bytes behind ANY start, so the warm-up begins that far back and no further: the words of the
+            instance's window (64 / 128 bytes) in front of it keep their look-ups (the pipeline below stays one piece of straight code) and skip
+            their column steps -- a scalar branch per warm-up word.  m = 20, tau = 4: 6 words of 16, 38 of the chain's 48 words stepped. */
+         const int wu_skip = __builtin_amdgcn_readfirstlane(WU - (int)(((uint32_t)a.m + (uint32_t)a.tau - 1u + 3u) >> 2));
 #pragma unroll
          for (int k = 0; k < WU + 32; k++) {
             if (k + 1 < WU + 32) {
@@ -378,6 +382,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
             if (k == WU) { seen = 0; hm = 0; }              /* every chain reports the first hit of a line inside its OWN bytes */
             /* a flagged byte (newline, terminator) in this word of ANY lane: the per-byte logic; else the lean steps (wave-uniform branch) */
             const fused_eq_t<MW> (&e4)[4] = ev[k & 1];
+            if (k < WU && k < wu_skip) continue;            /* (wave-uniform) in front of the warm-up this pattern needs */
             if (__any(((e4[0].w0 | e4[1].w0 | e4[2].w0 | e4[3].w0) & 3u) != 0u)) {
                if (k < WU) stream_myers_step4<MW, false>(e4, st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);
                else stream_myers_step4<MW, true>(e4, st, (uint32_t)a.m, (uint32_t)a.tau, dead, seen, hm);

@@ -432,7 +432,7 @@ def test_cli_pipelined_ingest_lanes_and_devices(gpu, capi):
     from concurrent.futures import ThreadPoolExecutor
     variants = (("700", "1", None), ("4096", "2", None), ("1500", "2", "0,0"), ("3000", "4", "0,0,0"), ("65536", "3", "all"))
 
-    def run(job):                                           # (three CLI processes at a time: each is mostly process and HIP start-up)
+    def run(job):                                           # (four CLI processes at a time: each is mostly process and HIP start-up)
         (name, args), v = job
         env = dict(os.environ)
         if v:
@@ -441,7 +441,7 @@ def test_cli_pipelined_ingest_lanes_and_devices(gpu, capi):
                 env["SEEQ_DEVICES"] = v[2]
         return subprocess.run([capi.CLI_PATH] + args + [os.path.join(GOLDEN, name)], capture_output=True, env=env)
     jobs = [(c, v) for c in cases for v in (None,) + variants]
-    with ThreadPoolExecutor(max_workers=3) as pool:
+    with ThreadPoolExecutor(max_workers=4) as pool:
         res = dict(zip([(c[0], tuple(c[1]), v) for c, v in jobs], pool.map(run, jobs)))
     for name, args in cases:
         ref = res[(name, tuple(args), None)]
@@ -475,17 +475,24 @@ def test_cli_pipeline_on_a_generated_file(gpu, capi, oracle, tmp_path):
     open(path, "wb").write(data)
     exp = oracle.buffer_scan(PAT20, 3, data, SQ_BEST)
     outs = {}
-    for chunk, lanes, devs in (("100000000", "2", None), ("4096", "1", None), ("65536", "3", "0,0"), ("1048576", "2", None), ("300001", "2", "0,0,0")):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(job):                                           # (four CLI processes at a time: each is mostly process and HIP start-up)
+        (chunk, lanes, devs), args = job
         env = dict(os.environ, SEEQ_CHUNK_BYTES=chunk, SEEQ_LANES=lanes)
         if devs:
             env["SEEQ_DEVICES"] = devs
-        for args in (["-c"], ["-b", "-f"], ["-a", "-l", "-p", "-k"], ["-i", "-c"], ["-x", "2", "-b", "-l", "-m"]):
-            r = subprocess.run([capi.CLI_PATH, "-d", "3"] + args + [PAT20, path], capture_output=True, env=env)
-            assert r.returncode == 0, (chunk, lanes, devs, args, r.stderr[-500:])
-            key = " ".join(args)
-            if key in outs:
-                assert r.stdout == outs[key], (chunk, lanes, devs, args)
-            outs[key] = r.stdout
+        return subprocess.run([capi.CLI_PATH, "-d", "3"] + args + [PAT20, path], capture_output=True, env=env)
+    jobs = [(cfg, args) for cfg in (("100000000", "2", None), ("4096", "1", None), ("65536", "3", "0,0"), ("1048576", "2", None), ("300001", "2", "0,0,0"))
+            for args in (["-c"], ["-b", "-f"], ["-a", "-l", "-p", "-k"], ["-i", "-c"], ["-x", "2", "-b", "-l", "-m"])]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(run, jobs))
+    for ((chunk, lanes, devs), args), r in zip(jobs, results):
+        assert r.returncode == 0, (chunk, lanes, devs, args, r.stderr[-500:])
+        key = " ".join(args)
+        if key in outs:
+            assert r.stdout == outs[key], (chunk, lanes, devs, args)
+        outs[key] = r.stdout
     assert int(outs["-c"]) == exp["nmatchlines"]
     rows = outs["-b -f"].decode().splitlines()
     assert len(rows) == len(exp["records"])

@@ -193,17 +193,49 @@ print("LEAD STRESS OK")
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"SEEQ_NO_LEADERS": "1"}, {"SEEQ_SEGMENT_BYTES": "262144"}], ids=["leaders", "one-lane-per-line", "256KiB-segments"])
-def test_long_lines_fresh_seed_stress(gpu, capi, oracle, env):
+STRESS_ENVS = {"leaders": {}, "one-lane-per-line": {"SEEQ_NO_LEADERS": "1"}, "256KiB-segments": {"SEEQ_SEGMENT_BYTES": "262144"}}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def stress_jobs(request, tmp_path_factory):
+    """The three variants of the long-line stress are processes of their own (20-26 s each, most of it the oracle on one host core, the GPU
+    idle): they START when this module does and run beside its other tests -- four processes on the card with pytest's own --; each test below
+    waits for its variant and judges it.  Same iterations, same checks as when they ran one after the other (66 s of the suite)."""
+    wanted = [it.callspec.id for it in request.session.items
+              if it.path == request.path and it.name.startswith("test_long_lines_fresh_seed_stress[") and hasattr(it, "callspec")]
+    jobs = {}
+    d = tmp_path_factory.mktemp("stress")
+    for vid in wanted:
+        seed = _fresh_seed()
+        code = LEAD_STRESS % dict(root=ROOT, seed=seed, iters=70)
+        out, err = open(os.path.join(d, vid + ".out"), "w+"), open(os.path.join(d, vid + ".err"), "w+")
+        jobs[vid] = (seed, subprocess.Popen([sys.executable, "-c", code], stdout=out, stderr=err, env=dict(os.environ, **STRESS_ENVS[vid])), out, err)
+    yield jobs
+    for _, p, out, err in jobs.values():
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+        out.close(); err.close()
+
+
+@pytest.mark.parametrize("vid", list(STRESS_ENVS), ids=list(STRESS_ENVS))
+def test_long_lines_fresh_seed_stress(gpu, capi, oracle, stress_jobs, vid):
     """The long-line machinery (k_stream's long-line variant and Myers mode, the window walk, leaders with their void-and-repeat
     rule) under a FRESH seed per run: 70 iterations per variant (210 a run) of 1-3 lines of 40-150 KB, patterns of 12-42 positions
     that are random, periodic or a single base, text with planted copies, tandem copies (windows that run into one another),
     poly-base runs and periodic stretches of up to 800 bytes -- --all records, both counts, --best and first-hit records against
     the oracle; with the leaders, with one lane per line, and with 256 KiB segments (lines that span segments)."""
-    seed = _fresh_seed()
-    code = LEAD_STRESS % dict(root=ROOT, seed=seed, iters=70)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=1200)
-    assert r.returncode == 0 and "LEAD STRESS OK" in r.stdout, (seed, env, r.stdout[-800:], r.stderr[-3000:])
+    seed, p, out, err = stress_jobs[vid]
+    print("SEEQ_FUZZ_SEED=%d" % seed)
+    try:
+        rc = p.wait(timeout=1200)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.wait()
+        rc = -9
+    out.seek(0); err.seek(0)
+    so, se = out.read(), err.read()
+    assert rc == 0 and "LEAD STRESS OK" in so, (seed, STRESS_ENVS[vid], so[-800:], se[-3000:])
 
 
 def _oracle_count_chunk(args):
