@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, evidence of the committed build: the default bench line (headline + FASTQ shape + configs[4] section) and the other workloads' lines,
 # rocprofv3 kernel stats + PMC passes of the headline workload and of cfg5, the PMC traffic file bench.py ties to the build, the published sweep
-# against the reference binary.  Usage: bash profiles/r05_final_evidence.sh [suite|bench|profile|pmc|sweep] (a gpurun call is at most 20 minutes).
+# against the reference binary.  Usage: bash profiles/r05_final_evidence.sh [suite|bench|profile|fastq|generic|pmc|sweep] (a gpurun call is at most 20 minutes).
 # Outputs land under gpurun_out/r05final/ and gpurun_out/prof_r05_final_*; the summaries are copied into profiles/ afterwards.
 set -u
 PART=${1:-bench}
@@ -42,4 +42,23 @@ timeout -k 10 500 bash profiles/pmc_traffic.sh r05final_pmc > $O/pmc_traffic.log
 fi
 if [ $PART = sweep ]; then
 timeout -k 10 1100 python3 profiles/chrom_sweep.py > $O/chrom_sweep.jsonl 2> $O/chrom_sweep.txt; echo "sweep exit $?"; tail -30 $O/chrom_sweep.txt
+fi
+if [ $PART = fastq ]; then
+# rocprofv3 kernel stats of the FASTQ shape (25 M records = 100 M lines, 7.9 GB) under the three non-DNA modes
+REPO=$PWD; cd /tmp
+for m in fail convert ignore; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/fastq_$m -- python3 $REPO/profiles/fastq_shape_bench.py 25000000 best fastq $m > $REPO/$O/fastq_$m.log 2>&1; echo "fastq $m exit $?"
+done
+cd $REPO
+python3 profiles/fastq_kernel_stats.py $O
+find $O -name "*.csv" -size +1M -delete
+fi
+if [ $PART = generic ]; then
+# the generic path (patterns of 63 .. 512 positions: newline index + k_forward<W> + k_exact<W>), whose speed no other evidence states
+rp() { python3 -c "import random; random.seed($1); print(''.join(random.choice('ACGT') for _ in range($2)))"; }
+{
+SEEQ_TS_PATTERN=$(rp 5 100) SEEQ_TS_TAU=5 SEEQ_TS_LEN=150 timeout -k 10 200 python3 profiles/time_scan.py "100-mer,d=5,150bp" 20000000 5 best
+SEEQ_TS_PATTERN=$(rp 6 300) SEEQ_TS_TAU=10 SEEQ_TS_LEN=500 timeout -k 10 200 python3 profiles/time_scan.py "300-mer,d=10,500bp" 5000000 5 best
+SEEQ_TS_PATTERN=$(rp 7 512) SEEQ_TS_TAU=20 SEEQ_TS_LEN=1000 timeout -k 10 200 python3 profiles/time_scan.py "512-mer,d=20,1000bp" 2000000 5 best
+} > $O/generic_path.txt 2>&1; echo "generic exit $?"; cat $O/generic_path.txt
 fi

@@ -19,7 +19,7 @@ PATTERN, TAU, L = os.environ.get("SEEQ_TS_PATTERN", "GATGTAGCGCGATTAGCCTG"), int
 torch.cuda.set_device(0)
 stream = torch.cuda.current_stream().cuda_stream
 text = torch.empty(n * (L + 1), dtype=torch.uint8, device="cuda:0")
-dev.synth_reads(text.data_ptr(), 0, n, L, dev.plain_pattern(PATTERN), TAU, stream=stream)
+dev.synth_reads(text.data_ptr(), 0, n, L, dev.plain_pattern(PATTERN)[:96], TAU, stream=stream)      # (the generator plants copies of at most 96 positions)
 torch.cuda.synchronize()
 pat = dev.Pattern(PATTERN, TAU)
 sc = dev.Scanner(stream)

@@ -1381,6 +1381,8 @@ static int run_setup(seeqdev_scan *s, SegRun &r)
          nw = 4;
          double want = s->avg_line * 63.5;                /* <= 64 lines per region: one per lane */
          if (want < 512) want = 512;
+         if (want > DIRECT_MAXRR * 1024) want = DIRECT_MAXRR * 1024;      /* (k_direct reads a region in at most DIRECT_MAXRR rounds of 1 KiB: lines that average more than 258 bytes
+                                                                              once made regions of 16 KiB + 48 bytes, whose last 48 bytes no round looked at -- profiles/ignore_fuzz.py) */
          tile_bytes = ((uint32_t)want) & ~15u;
          if (kn.tile_bytes >= 512 && kn.tile_bytes <= DIRECT_MAXRR * 1024) tile_bytes = (uint32_t)kn.tile_bytes & ~15u;
          int per_cu = occupancy_of(s, fw == 1 ? (const void *)k_direct<4, 1> : (const void *)k_direct<4, 2>, 256, 0);

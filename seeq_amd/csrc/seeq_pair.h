@@ -367,8 +367,10 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
             from its start; a line that began before the tile was the business of the tile before (below: the tail) */
          const uint32_t starts_line = (uint32_t)__builtin_amdgcn_readfirstlane((t0 == 0 || (t0 >= 32 && ((uint32_t)__builtin_amdgcn_readlane((int)halo, 7) >> 24) == 0x0Au)) ? 1 : 0);
          const uint32_t before = stream_from_prev_lane(P, starts_line << 31);
-         /* the lane's first end: + what the lanes before me bring (known: the line's start was seen) */
-         if ((firstP & before) >> 31) {
+         /* the lane's first end: + what the lanes before me bring.  Known when the line's start was seen: a line end in a lane before me, or the
+            tile's own first byte (starts_line: every lane's sums then run from there -- the buffer's first line, found unmarked by
+            profiles/ignore_fuzz.py, and every line that begins with its tile) */
+         if ((firstP >> 31) && ((before >> 31) | starts_line)) {
             const uint32_t sum = (firstP & 0x0FFFFFFFu) + (before & 0x0FFFFFFFu);
             if ((sum >> 14) != 0u && (sum & 0x3FFFu) >= a.ig_thr) mark(first_pq);
          }
