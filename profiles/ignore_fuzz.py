@@ -63,7 +63,7 @@ for b in range(nbuf):
     if ONLY is not None and b != int(ONLY):
         continue
     rng = random.Random(seed0 * 1000 + b)
-    m = rng.choice([8, 12, 16, 20, 20, 24, 30])
+    m = rng.choice([8, 12, 16, 20, 20, 24, 30, 30, 36, 44, 62])                    # (> 32: two column words)
     alphabet = rng.choice(["ACGT", "ACGT", "ACG", "AC", "ACGTT", "AAAC"])          # (a pattern poor in a base: the frequency bound bites or not)
     core = "".join(rng.choice(alphabet) for _ in range(m))
     pattern = core
@@ -73,7 +73,13 @@ for b in range(nbuf):
             i = rng.randrange(m)
             pl[i] = rng.choice(["N", "[AC]", "[GT]", "[ACG]"])
         pattern = "".join(pl)
-    tau = rng.randint(0, min(4, m // 5 + 1))
+    tau = rng.randint(0, min(6 if m > 32 else 4, m // 5 + 1))
+    lower = rng.choice([0.0, 0.0, 0.02, 0.5])                                       # share of reads written in lower case / with U for T
+    crlf = rng.random() < 0.15                                                      # "\r\n" line ends: the \r is one more skipped byte
+    high = rng.random() < 0.2                                                       # bytes >= 0x80 among the quality bytes
+    align = rng.choice([0, 0, 128, 8192])                                           # now and then a line is stretched so that the next begins a lane / a tile
+    qual = QUAL + ("\x80\xa7\xff" if high else "")
+    pos = 0                                                                         # offset of the line being made
     dna_share = rng.choice([0.0, 0.05, 0.1, 0.15, 0.3, 0.6])                        # share of bases among a quality line's bytes
     lines = []
     nlines = rng.choice([400, 1500, 4000])
@@ -84,7 +90,7 @@ for b in range(nbuf):
             t = [rng.choice("ACGT") for _ in range(n)]
         elif kind < 0.60:                                                           # a quality-like line
             n = rng.choice([50, 100, 150, 150, 151, 250])
-            t = [rng.choice("ACGTN") if rng.random() < dna_share else rng.choice(QUAL) for _ in range(n)]
+            t = [rng.choice("ACGTN") if rng.random() < dna_share else rng.choice(qual) for _ in range(n)]
         elif kind < 0.70:                                                           # header
             t = list("@r%09d %s" % (i, "".join(rng.choice("acgtnACGTlength=xyz0123") for _ in range(rng.randint(0, 40)))))
         elif kind < 0.78:
@@ -116,7 +122,16 @@ for b in range(nbuf):
             t = t[:n]
         if rng.random() < 0.004 and n:
             t[rng.randrange(n)] = "\0"
+        if kind < 0.30 and rng.random() < lower:
+            t = [c.lower() if rng.random() < 0.7 else ("U" if c == "T" else c) for c in t]
+        if align and rng.random() < 0.08:                                           # stretch: the NEXT line starts on a multiple of `align`
+            room = (-(pos + len(t) + 1 + (1 if crlf else 0))) % align
+            if room < 700:
+                t += [rng.choice("ACGT" + (SKIP if rng.random() < 0.5 else "")) for _ in range(room)]
+        if crlf:
+            t.append("\r")
         lines.append("".join(t))
+        pos += len(t) + 1
     buf = ("\n".join(lines) + ("\n" if b % 2 else "")).encode("latin-1")
     for forced in (None, "pair"):
         if forced:

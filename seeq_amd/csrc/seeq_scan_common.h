@@ -83,15 +83,18 @@ __device__ __forceinline__ void fused_step(uint32_t eq, uint32_t &pv, uint32_t &
    mv = ph2 & d0;
 }
 
-/* alphabet check of four characters: nonzero when a byte is outside {ACGTN, acgtn, '\n'} (k_stream's table columns
- * are exact for those; any other byte aliases onto one of them) */
+/* alphabet check of four characters: nonzero when a byte is outside {ACGTUN, acgtun, '\n'} (k_stream's table columns
+ * are exact for those -- U and u share T's column, as they share its class in the reference, seeqcore.h:89-111 --; any other
+ * byte aliases onto one of them).  (Until round 5 U and u counted as outside: harmless where the flag only makes the exact pass
+ * look, wrong under SQ_CONVERT / SQ_IGNORE on k_stream, whose corrected copy turned them into N / a skipped byte -- found by
+ * profiles/ignore_fuzz.py.) */
 __device__ __forceinline__ uint32_t fused_bad4(uint32_t w)
 {
    /* canonical byte of each table column (A C T G . \n . N); the text must equal it -- letters in either case,
       the newline exactly ('*' = 0x2A is '\n' with the case bit set: it must NOT pass) */
    const uint32_t idx = (w & 0x0E0E0E0Eu) >> 1;
    const uint32_t canon = __builtin_amdgcn_perm(0x4EFF0AFFu, 0x47544341u, idx);
-   const uint32_t fold = __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDFDFDFu, idx);      /* per column: case-fold mask */
+   const uint32_t fold = __builtin_amdgcn_perm(0xDFFFFFFFu, 0xDFDEDFDFu, idx);      /* per column: case-fold mask (column 2 folds bit 0 as well: T and U) */
    return (w & fold) ^ canon;
 }
 

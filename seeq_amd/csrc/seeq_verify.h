@@ -211,8 +211,8 @@ struct verify_rules {
 /* Text with bytes outside the alphabet somewhere (Counters.dirty: FASTQ quality lines, lower case, binary junk): may the window of
  * this lane's candidate be trusted?  The walk itself meets every byte of the window and ends the line at one that ends it; what
  * it cannot see is such a byte BEFORE the window, in text[off, off + pos) -- the reference stopped there (libseeq.c:267-270) and
- * the line has no occurrence behind it.  Under SQ_FAIL any byte outside { A C G T N a c g t n } counts (fused_bad4: U and u too,
- * which is conservative), under SQ_CONVERT a NUL only (every other byte is an N there, libseeq.c:223-228).  Returns true when the
+ * the line has no occurrence behind it.  Under SQ_FAIL any byte outside { A C G T U N a c g t u n } counts (fused_bad4),
+ * under SQ_CONVERT a NUL only (every other byte is an N there, libseeq.c:223-228).  Returns true when the
  * stretch holds one: the lane then scans its line from the first byte, which is exact whatever the bytes are.  Wave-wide (every
  * lane calls it; lanes with pos = 0 look at nothing): 64 bytes per round, the four loads in flight together. */
 __device__ __forceinline__ bool verify_prefix_dirty(const ScanArgs &a, uint64_t off, uint32_t pos)

@@ -1137,6 +1137,132 @@ def test_fastq_records_on_the_pair_walk(gpu, capi, oracle, seg, monkeypatch):
         pat.close()
 
 
+def test_ignore_lines_that_begin_with_their_tile(gpu, capi, oracle):
+    """Found by profiles/ignore_fuzz.py (round 5): under SQ_IGNORE on k_pair a line that begins with its 8 KiB tile -- the buffer's
+    first line, or one whose first byte stands on a multiple of 8192 -- and runs past the tile's first lane (128 bytes) was left
+    without its marker: the lanes behind the first did not know the line's start had been seen.  Here: such lines hold a copy of
+    the pattern with skipped bytes INSIDE it (a hit only when they are skipped), at the buffer's start and at tiles 1, 2 and 5,
+    lengths from one lane to three, with and without a skipped byte in the first lane."""
+    from seeq_amd import device as dev
+    rng = random.Random(50501)
+    pattern, tau = PAT20, 3
+    core = dev.plain_pattern(pattern)
+
+    def special(n, where, skip_early):
+        t = [rng.choice("ACGT") for _ in range(n)]
+        c = list(core)
+        for _ in range(7):                                  # (more than tau: the walk over aliased bytes cannot see the copy, only the marker names the line)
+            c.insert(rng.randrange(1, len(c)), rng.choice("!+:J*;@5"))
+        t[where:where + len(c)] = c
+        if skip_early:
+            t[rng.randrange(0, 100)] = "#"
+        return "".join(t[:n])
+    for n, where in ((150, 20), (150, 120), (300, 150), (300, 260), (129, 100), (400, 300)):
+        for skip_early in (False, True):
+            lines, pos = [], 0
+            lines.append(special(n, where, skip_early)); pos += n + 1
+            for tile in (1, 2, 5):
+                while pos + 152 < tile * 8192:
+                    lines.append("".join(rng.choice("ACGT") for _ in range(150))); pos += 151
+                pad = tile * 8192 - pos - 1                # the filler line ends right in front of the tile
+                lines.append("".join(rng.choice("ACGT") for _ in range(pad))); pos += pad + 1
+                assert pos == tile * 8192
+                lines.append(special(n, where, skip_early)); pos += n + 1
+            for _ in range(40):
+                lines.append("".join(rng.choice("ACGT") for _ in range(150)))
+            buf = ("\n".join(lines) + "\n").encode("latin-1")
+            pat = dev.Pattern(pattern, tau)
+            sc = dev.Scanner()
+            for opt in (SQ_BEST, SQ_ALL, SQ_FIRST):
+                exp = oracle.buffer_scan(pattern, tau, buf, opt | SQ_IGNORE)
+                got = sc.scan_host(pat, buf, opt | SQ_IGNORE, dev.WANT_RECORDS)
+                assert sc.last_kernel() == "k_pair"
+                assert exp["nmatchlines"] >= 4                                  # (the four special lines are hits under SQ_IGNORE)
+                assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (n, where, skip_early, opt, got["nmatchlines"], exp["nmatchlines"])
+                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (n, where, skip_early, opt)
+            sc.close()
+            pat.close()
+
+
+@pytest.mark.parametrize("kernel", [None, "stream", "direct", "generic"])
+def test_u_and_lower_case_are_bases_on_every_walk(gpu, capi, oracle, monkeypatch, kernel):
+    """Found by profiles/ignore_fuzz.py (round 5): U and u are T (reference seeqcore.h:89-111), but k_stream's alphabet check counted
+    them as foreign -- harmless under SQ_FAIL (the exact pass looked), wrong under SQ_CONVERT and SQ_IGNORE, where the corrected copy it
+    walks had turned them into N / a skipped byte: occurrences written with U were lost.  Reads in mixed case with U for T, planted
+    copies written the same way, on read-length and on long lines, every walk, the three non-DNA modes."""
+    from seeq_amd import device as dev
+    if kernel == "generic":
+        monkeypatch.setenv("SEEQ_PATH", "generic")
+    elif kernel:
+        monkeypatch.setenv("SEEQ_FUSED_KERNEL", kernel)
+    rng = random.Random(50503)
+
+    def rna(t):
+        return "".join((c.lower() if rng.random() < 0.5 else c) if c != "T" or rng.random() < 0.3 else rng.choice("Uu") for c in t)
+    for pattern, tau, lens in ((PAT20, 3, (150,)), ("TTCTTGTTAT", 1, (100, 151)), (PAT20, 2, (3000, 9000))):
+        core = dev.plain_pattern(pattern)
+        lines = []
+        for i in range(1200 if lens[0] < 1000 else 60):
+            n = rng.choice(lens)
+            t = [rng.choice("ACGT") for _ in range(n)]
+            for _ in range(1 + n // 1000):
+                if rng.random() < 0.5:
+                    c = _mutate(rng, core, rng.randint(0, tau + 1))
+                    p = rng.randrange(0, n - len(c))
+                    t[p:p + len(c)] = list(c)
+            t = rna("".join(t))
+            if rng.random() < 0.1:
+                t = t[:5] + rng.choice("!;*") + t[6:]            # and now and then a byte that IS foreign
+            lines.append(t)
+        buf = ("\n".join(lines) + "\n").encode("latin-1")
+        pat = dev.Pattern(pattern, tau)
+        sc = dev.Scanner()
+        for nd in (SQ_CONVERT, SQ_IGNORE, SQ_FAIL):
+            for opt in (SQ_BEST, SQ_ALL):
+                exp = oracle.buffer_scan(pattern, tau, buf, opt | nd)
+                got = sc.scan_host(pat, buf, opt | nd, dev.WANT_RECORDS)
+                assert exp["nmatchlines"] > 10
+                assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (kernel, pattern, lens, nd, opt, sc.last_kernel(), got["nmatchlines"], exp["nmatchlines"])
+                assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (kernel, pattern, lens, nd, opt, sc.last_kernel())
+        sc.close()
+        pat.close()
+
+
+def test_direct_regions_on_lines_of_259_bytes(gpu, capi, oracle, monkeypatch):
+    """Found by profiles/ignore_fuzz.py (round 5): k_direct sizes its regions to 63.5 lines of the sampled average and reads a region
+    in at most 16 rounds of 1 KiB -- lines averaging more than 258 bytes made regions of 16 KiB + 48 bytes, the last 48 bytes of
+    which no round looked at: a newline there was not counted and every later record carried a line number one too small.  (The
+    planner sends such text to k_direct by itself under SQ_IGNORE when it also holds long lines.)"""
+    from seeq_amd import device as dev
+    monkeypatch.setenv("SEEQ_FUSED_KERNEL", "direct")
+    rng = random.Random(50502)
+    pattern, tau = PAT20, 3
+    core = dev.plain_pattern(pattern)
+    ran_direct = 0
+    for lens in ((258,), (257, 259), (240, 277), (200, 317)):      # (with the newline: 259 .. 259.5 bytes a line -- above 260 the planner leaves k_direct)
+        lines = []
+        for i in range(1500):
+            n = rng.choice(lens)
+            t = [rng.choice("ACGT") for _ in range(n)]
+            if rng.random() < 0.3:
+                c = _mutate(rng, core, rng.randint(0, tau + 1))
+                p = rng.randrange(0, n - len(c))
+                t[p:p + len(c)] = list(c)
+            lines.append("".join(t))
+        buf = ("\n".join(lines) + "\n").encode("latin-1")
+        pat = dev.Pattern(pattern, tau)
+        sc = dev.Scanner()
+        for nd in (SQ_FAIL, SQ_IGNORE):
+            exp = oracle.buffer_scan(pattern, tau, buf, SQ_BEST | nd)
+            got = sc.scan_host(pat, buf, SQ_BEST | nd, dev.WANT_RECORDS)
+            ran_direct += sc.last_kernel() == "k_direct"
+            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (lens, nd, got["nlines"], exp["nlines"])
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (lens, nd)
+        sc.close()
+        pat.close()
+    assert ran_direct >= 6
+
+
 @pytest.mark.parametrize("seg", [None, "65536"])
 def test_stream_fuzz_long_lines(gpu, capi, oracle, seg, monkeypatch):
     """Random patterns over long lines (up to 70 000 bytes, many planted hits per line, some with a non-DNA byte or as
