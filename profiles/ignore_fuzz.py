@@ -138,8 +138,8 @@ for b in range(nbuf):
             os.environ["SEEQ_FUSED_KERNEL"] = forced
         else:
             os.environ.pop("SEEQ_FUSED_KERNEL", None)
-        if b % 4 == 3:
-            os.environ["SEEQ_SEGMENT_BYTES"] = "65536"                              # lines and markers across segment seams
+        if b % 4 == 3 or os.environ.get("IGNORE_FUZZ_SEGMENTS") == "1":             # (IGNORE_FUZZ_SEGMENTS=1: every buffer)
+            os.environ["SEEQ_SEGMENT_BYTES"] = rng.choice(["65536", "65536", "16384", "131072"])   # lines and markers across segment seams
         else:
             os.environ.pop("SEEQ_SEGMENT_BYTES", None)
         p = dev.Pattern(pattern, tau)

@@ -1184,6 +1184,50 @@ def test_ignore_lines_that_begin_with_their_tile(gpu, capi, oracle):
             pat.close()
 
 
+def test_ignore_line_across_a_segment_seam(gpu, capi, oracle, monkeypatch):
+    """Found by profiles/ignore_fuzz.py (round 5): under SQ_IGNORE on k_pair a segment's last tile names the line that runs out of it
+    by a marker made unseen; k_bounds2 drops the marker when the line holds no skipped byte -- but the next segment still took
+    the line for covered by the segment before and dropped what it found in it as repeats: the hits of a line that starts in
+    front of a seam and has them behind it were lost.  Lines of 300 to 1 200 bytes across a 64 KiB seam, copies of the pattern
+    in front of the seam, behind it, on both sides; without a skipped byte, with one in front of the seam, with one behind it."""
+    from seeq_amd import device as dev
+    monkeypatch.setenv("SEEQ_SEGMENT_BYTES", "65536")
+    rng = random.Random(50504)
+    pattern, tau = PAT20, 2
+    core = dev.plain_pattern(pattern)
+    for n, before in ((1200, 460), (600, 300), (300, 150), (1200, 1100)):
+        for copies in ("behind", "front", "both"):
+            for skip in (None, "front", "behind"):
+                lines, pos = [], 0
+                while pos + 152 < 65536 - before - 200:
+                    lines.append("".join(rng.choice("ACGT") for _ in range(150))); pos += 151
+                pad = 65536 - before - pos - 1
+                lines.append("".join(rng.choice("ACGT") for _ in range(pad))); pos += pad + 1
+                t = [rng.choice("ACGT") for _ in range(n)]
+                if copies in ("behind", "both"):
+                    p = rng.randrange(before + 30, n - 25); t[p:p + 20] = list(core)
+                if copies in ("front", "both"):
+                    p = rng.randrange(0, before - 25); t[p:p + 20] = list(core)
+                if skip == "front":
+                    t[rng.randrange(0, before)] = "#"
+                elif skip == "behind":
+                    t[rng.randrange(before, n)] = "#"
+                lines.append("".join(t))
+                for _ in range(60):
+                    lines.append("".join(rng.choice("ACGT") for _ in range(150)))
+                buf = ("\n".join(lines) + "\n").encode("latin-1")
+                pat = dev.Pattern(pattern, tau)
+                sc = dev.Scanner()
+                for opt in (SQ_BEST, SQ_ALL):
+                    exp = oracle.buffer_scan(pattern, tau, buf, opt | SQ_IGNORE)
+                    got = sc.scan_host(pat, buf, opt | SQ_IGNORE, dev.WANT_RECORDS)
+                    assert exp["nmatchlines"] >= 1
+                    assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (n, before, copies, skip, opt, sc.last_kernel(), got["nmatchlines"], exp["nmatchlines"])
+                    assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (n, before, copies, skip, opt, sc.last_kernel())
+                sc.close()
+                pat.close()
+
+
 @pytest.mark.parametrize("kernel", [None, "stream", "direct", "generic"])
 def test_u_and_lower_case_are_bases_on_every_walk(gpu, capi, oracle, monkeypatch, kernel):
     """Found by profiles/ignore_fuzz.py (round 5): U and u are T (reference seeqcore.h:89-111), but k_stream's alphabet check counted
