@@ -171,6 +171,21 @@ for b in range(nbuf):
             c2 = sc.scan_host(p, buf, nd, dev.WANT_COUNTMATCH)
             assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], ("countlines", seed0, b, pattern, tau, nd, forced)
             assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], ("countmatch", seed0, b, pattern, tau, nd, forced)
+        # several patterns in one walk over the same buffer (seeqdevScanHostMulti): the pattern, a neighbour of it, a random one
+        if forced is None and ONLY is None:
+            others = [mutate(rng, core, 2)[:m] or core, "".join(rng.choice("ACGT") for _ in range(max(8, m - 4)))]
+            pats = [p] + [dev.Pattern(q, min(tau, max(0, len(q) // 5))) for q in others]
+            specs = [(pattern, tau)] + [(q, min(tau, max(0, len(q) // 5))) for q in others]
+            for nd in (dev.SQ_IGNORE, 0, dev.SQ_CONVERT):
+                res = sc.scan_host_multi(pats, buf, SQ_BEST | nd, dev.WANT_RECORDS)
+                for (q, tq), r in zip(specs, res):
+                    exp = o.buffer_scan(q, tq, buf, SQ_BEST | nd)
+                    assert r["nlines"] == exp["nlines"] and r["nmatchlines"] == exp["nmatchlines"], ("multi counts", seed0, b, q, tq, nd, sc.last_multi_one_pass(), r["nmatchlines"], exp["nmatchlines"])
+                    assert np.array_equal(r["records"].astype(np.uint64), exp["records"]), ("multi records", seed0, b, q, tq, nd, sc.last_multi_one_pass())
+                    tot += 1
+                kernels["multi one pass" if sc.last_multi_one_pass() else "multi per pattern"] = kernels.get("multi one pass" if sc.last_multi_one_pass() else "multi per pattern", 0) + 1
+            for q in pats[1:]:
+                q.close()
         sc.close(); p.close()
 if bad:
     print("ignore fuzz FAILED:", bad, "scans differ")
