@@ -133,6 +133,19 @@ def test_fuzz_kinds_of_lines_fresh_seed(gpu, capi, oracle):
     assert "k_pair" in r.stdout, r.stdout[-500:]
 
 
+def test_cli_fuzz_against_the_reference_binary(gpu, capi):
+    """Round 5, profiles/cli_diff_fuzz.py: seeq_amd/bin/seeq against oracle/_ref/seeq_ref (the reference's own sources, compiled by
+    oracle/Makefile) on files of line kinds -- reads, quality-like lines, headers, empty lines, lines of a few KB, CR LF ends, NULs,
+    copies with foreign bytes inside -- with random patterns, distances, -b / -a / -i, -x 0 / 1 / 2 and format options in any
+    combination (the ones the reference rejects included): stdout and exit status byte for byte.  Fresh seed, 3 files x 16 runs."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "seeq_ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/seeq_ref is not built (it is built where /root/reference is present and travels with the snapshot)")
+    seed = _fresh_seed()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "cli_diff_fuzz.py"), str(seed), "3", "16"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "cli diff fuzz OK: 48" in r.stdout, (seed, r.stdout[-3000:], r.stderr[-2000:])
+
+
 # (round 5: the knobs that kept superseded kernels compiled in are gone -- SEEQ_VERIFY / SEEQ_ORDER / SEEQ_EMIT_ALL = old, SEEQ_NO_SKIPCOUNT,
 #  SEEQ_NO_LL_FILTER, SEEQ_PAIR_PF, SEEQ_EXACT, SEEQ_PACKED_STAGE: tag r05-before-prune -- so are their variants; what is left selects a
 #  SHIPPED path that some input reaches on its own)
