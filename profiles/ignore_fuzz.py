@@ -46,6 +46,7 @@ ONLY = os.environ.get("IGNORE_FUZZ_ONLY")                 # replay one buffer of
 
 
 def report(buf, got, exp, m):
+    print("nheaders", got.get("nheaders"), exp.get("nheaders"))
     g = {tuple(r) for r in got["records"].astype(np.uint64).tolist()}
     e = {tuple(r) for r in exp["records"].tolist()}
     starts = [0] + [i + 1 for i, c in enumerate(buf) if c == 10]
@@ -79,6 +80,7 @@ for b in range(nbuf):
     high = rng.random() < 0.2                                                       # bytes >= 0x80 among the quality bytes
     align = rng.choice([0, 0, 128, 8192])                                           # now and then a line is stretched so that the next begins a lane / a tile
     qual = QUAL + ("\x80\xa7\xff" if high else "")
+    fasta = rng.random() < 0.2                                                      # SEEQDEV_FASTA: lines that start with '>' are headers (seeq.c:367-374)
     pos = 0                                                                         # offset of the line being made
     dna_share = rng.choice([0.0, 0.05, 0.1, 0.15, 0.3, 0.6])                        # share of bases among a quality line's bytes
     lines = []
@@ -92,7 +94,9 @@ for b in range(nbuf):
             n = rng.choice([50, 100, 150, 150, 151, 250])
             t = [rng.choice("ACGTN") if rng.random() < dna_share else rng.choice(qual) for _ in range(n)]
         elif kind < 0.70:                                                           # header
-            t = list("@r%09d %s" % (i, "".join(rng.choice("acgtnACGTlength=xyz0123") for _ in range(rng.randint(0, 40)))))
+            t = list("%sr%09d %s" % (">" if fasta else "@", i, "".join(rng.choice("acgtnACGTlength=xyz0123") for _ in range(rng.randint(0, 40)))))
+            if fasta and rng.random() < 0.3:
+                t = list(">") + list(mutate(rng, core, 0)) + t[1:]                  # a header that holds the pattern: never a hit line
         elif kind < 0.78:
             t = list("+")
         elif kind < 0.80:
@@ -144,10 +148,11 @@ for b in range(nbuf):
             os.environ.pop("SEEQ_SEGMENT_BYTES", None)
         p = dev.Pattern(pattern, tau)
         sc = dev.Scanner()
+        FA = dev.SEEQDEV_FASTA if fasta else 0
         for nd in (dev.SQ_IGNORE, 0, dev.SQ_CONVERT):
             for mo in (SQ_BEST, SQ_ALL, SQ_FIRST):
-                exp = o.buffer_scan(pattern, tau, buf, mo | nd)
-                got = sc.scan_host(p, buf, mo | nd, dev.WANT_RECORDS)
+                exp = o.buffer_scan(pattern, tau, buf, mo | nd, fasta=fasta)
+                got = sc.scan_host(p, buf, mo | nd | FA, dev.WANT_RECORDS)
                 kernels[sc.last_kernel()] = kernels.get(sc.last_kernel(), 0) + 1
                 ctx = (seed0, b, pattern, tau, mo, nd, forced, os.environ.get("SEEQ_SEGMENT_BYTES"))
                 if ONLY is not None and got["nlines"] != exp["nlines"]:
@@ -166,9 +171,9 @@ for b in range(nbuf):
                         k += 1
                     raise AssertionError(("records", ctx, len(g), len(e), k, g[k:k + 3].tolist(), e[k:k + 3].tolist()))
                 tot += 1
-            expa = o.buffer_scan(pattern, tau, buf, SQ_ALL | nd)
-            c1 = sc.scan_host(p, buf, nd, dev.WANT_COUNTLINES)
-            c2 = sc.scan_host(p, buf, nd, dev.WANT_COUNTMATCH)
+            expa = o.buffer_scan(pattern, tau, buf, SQ_ALL | nd, fasta=fasta)
+            c1 = sc.scan_host(p, buf, nd | FA, dev.WANT_COUNTLINES)
+            c2 = sc.scan_host(p, buf, nd | FA, dev.WANT_COUNTMATCH)
             assert c1["nmatchlines"] == expa["nmatchlines"] and c1["nlines"] == expa["nlines"], ("countlines", seed0, b, pattern, tau, nd, forced)
             assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], ("countmatch", seed0, b, pattern, tau, nd, forced)
         # several patterns in one walk over the same buffer (seeqdevScanHostMulti): the pattern, a neighbour of it, a random one
@@ -177,9 +182,9 @@ for b in range(nbuf):
             pats = [p] + [dev.Pattern(q, min(tau, max(0, len(q) // 5))) for q in others]
             specs = [(pattern, tau)] + [(q, min(tau, max(0, len(q) // 5))) for q in others]
             for nd in (dev.SQ_IGNORE, 0, dev.SQ_CONVERT):
-                res = sc.scan_host_multi(pats, buf, SQ_BEST | nd, dev.WANT_RECORDS)
+                res = sc.scan_host_multi(pats, buf, SQ_BEST | nd | FA, dev.WANT_RECORDS)
                 for (q, tq), r in zip(specs, res):
-                    exp = o.buffer_scan(q, tq, buf, SQ_BEST | nd)
+                    exp = o.buffer_scan(q, tq, buf, SQ_BEST | nd, fasta=fasta)
                     assert r["nlines"] == exp["nlines"] and r["nmatchlines"] == exp["nmatchlines"], ("multi counts", seed0, b, q, tq, nd, sc.last_multi_one_pass(), r["nmatchlines"], exp["nmatchlines"])
                     assert np.array_equal(r["records"].astype(np.uint64), exp["records"]), ("multi records", seed0, b, q, tq, nd, sc.last_multi_one_pass())
                     tot += 1

@@ -418,7 +418,12 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
                   }
                   const uint32_t cpos = hit_col[knext++];                 /* position of the repeat's first hit */
                   const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs + a.walk_ext;
-                  if (ccol > pos + wback && exact1_clean(a, off + pos, off + ccol - wback)) {   /* jump: fresh column `wback` columns before it */
+                  /* FASTA input: a header line carries the rank of the line before it (its newline is not counted), so a "repeat" may lie in the
+                     header BEHIND this line's end.  The stretch jumped over must then hold no newline: a header's first byte, '>', is outside
+                     the alphabet and fails the test -- unless the jump lands exactly on it, the newline being the stretch's last byte: the
+                     landing byte is looked at too (found by profiles/ignore_fuzz.py: a hit inside a header reported for the line before). */
+                  const uint64_t land = (a.options & SEEQDEV_FASTA) ? 1u : 0u;
+                  if (ccol > pos + wback && exact1_clean(a, off + pos, off + ccol - wback + land)) {   /* jump: fresh column `wback` columns before it */
                      pos = ccol - wback; wend = cend;
                      st.init(m); streak = tau1; latch = false; lastsub = -0x40000000;
                      break;

@@ -1184,6 +1184,43 @@ def test_ignore_lines_that_begin_with_their_tile(gpu, capi, oracle):
             pat.close()
 
 
+def test_fasta_header_hit_behind_a_hit_line_on_long_line_plans(gpu, capi, oracle):
+    """Found by profiles/ignore_fuzz.py (round 5): FASTA input under SQ_CONVERT on the long-line plans (a buffer that also holds a long
+    line with candidates).  A header line carries the line number of the line before it, so a candidate inside a header is a
+    "repeat" of that line, and the window walk of the exact pass jumped to it over the line's END when the stretch it skipped held
+    nothing outside the alphabet -- the newline as its last byte, the header's '>' right behind it: a hit inside the header came out
+    as a hit of the line before.  Here: hit lines of 150 bytes followed by headers that hold the pattern at offsets 1 .. 40, at
+    eight random alignments each, so that every landing position of the jump occurs, '>' itself included."""
+    from seeq_amd import device as dev
+    rng = random.Random(50505)
+    pattern, tau = "CAACCCCAACACCACAACCAAAAA", 4
+
+    def dna(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    long_line = "".join((pattern if i % 7 == 0 else dna(40)) for i in range(700))      # ~27 KB with copies all over: the long-line plan
+    lines = [long_line]
+    for off in range(1, 41):
+        for rep in range(8):                                # (the walk looks for its next candidate at block ends: filler lines of random length shift the line through every alignment)
+            where = rng.choice((19, 19, 60, 100, 126))
+            lines.append(dna(rng.randint(90, 220)))
+            lines.append(dna(where) + pattern + dna(150 - where - len(pattern)))
+            lines.append(">" + "r" * (off - 1) + pattern + " tail")
+    buf = ("\n".join(lines) + "\n").encode("latin-1")
+    pat = dev.Pattern(pattern, tau)
+    sc = dev.Scanner()
+    kernels = set()
+    for nd in (SQ_CONVERT, SQ_FAIL):
+        for opt in (SQ_ALL, SQ_BEST, SQ_FIRST):
+            exp = oracle.buffer_scan(pattern, tau, buf, opt | nd, fasta=True)
+            got = sc.scan_host(pat, buf, opt | nd | dev.SEEQDEV_FASTA, dev.WANT_RECORDS)
+            kernels.add((nd, sc.last_kernel()))
+            assert got["nlines"] == exp["nlines"] and got["nmatchlines"] == exp["nmatchlines"], (nd, opt, sc.last_kernel(), got["nmatchlines"], exp["nmatchlines"])
+            assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (nd, opt, sc.last_kernel())
+    assert (SQ_CONVERT, "k_myers") in kernels, kernels              # (the long-line plan of this text under SQ_CONVERT)
+    sc.close()
+    pat.close()
+
+
 def test_ignore_line_across_a_segment_seam(gpu, capi, oracle, monkeypatch):
     """Found by profiles/ignore_fuzz.py (round 5): under SQ_IGNORE on k_pair a segment's last tile names the line that runs out of it
     by a marker made unseen; k_bounds2 drops the marker when the line holds no skipped byte -- but the next segment still took
