@@ -108,7 +108,7 @@ for fno in range(nfiles):
         a = subprocess.run([OURS] + args + [pattern, path], capture_output=True, timeout=120)
         b = subprocess.run([REF] + args + [pattern, path], capture_output=True, timeout=120)
         return args, a, b
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("CLI_FUZZ_PAR", "4"))) as pool:      # (CLI processes on the card at a time)
         for args, a, b in pool.map(run, jobs):
             if a.returncode != b.returncode or a.stdout != b.stdout:
                 k = 0

@@ -105,47 +105,94 @@ def _run_fuzz(seeds, long_lines, env=None, nshort=3000, nlong=120, timeout=900):
     return r.stdout
 
 
-def test_fuzz_fresh_seed(gpu, capi, oracle):
-    seed = _fresh_seed()
-    out = _run_fuzz([(seed, 40)] + [(s, 6) for s in REGRESSION_SEEDS], False)
-    assert "k_pair" in out or "k_stream" in out, out
+class _Jobs:
+    """The fresh-seed campaigns of this module are processes of their own (8-25 s each, most of it the oracle on one host core, the GPU
+    idle): they are queued when the module starts and run THREE at a time beside its other tests -- with pytest's own process and the one a
+    foreground test may start that is five on the card --; each test waits for its job and judges it.  Same iterations, same checks as
+    when they ran one after the other (125 s of the suite)."""
+    MAXPAR = 3
+
+    def __init__(self, tmpdir):
+        import threading
+        self.tmp, self.specs, self.done, self.running = tmpdir, [], {}, {}
+        self.lock, self.cv = threading.Lock(), threading.Condition()
+        self.thread = None
+
+    def add(self, name, seed, argv, env):
+        self.specs.append((name, seed, argv, env))
+
+    def start(self):
+        import threading
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        queue = list(self.specs)
+        while queue or self.running:
+            while queue and len(self.running) < self.MAXPAR:
+                name, seed, argv, env = queue.pop(0)
+                out, err = open(os.path.join(self.tmp, name.replace(":", "_") + ".out"), "w+"), open(os.path.join(self.tmp, name.replace(":", "_") + ".err"), "w+")
+                self.running[name] = (seed, subprocess.Popen(argv, stdout=out, stderr=err, env=dict(os.environ, **env)), out, err, time.time())
+            for name, (seed, p, out, err, t0) in list(self.running.items()):
+                rc = p.poll()
+                if rc is None and time.time() - t0 > 1200:
+                    p.kill(); p.wait(); rc = -9
+                if rc is not None:
+                    out.seek(0); err.seek(0)
+                    with self.cv:
+                        self.done[name] = (seed, rc, out.read(), err.read())
+                        self.cv.notify_all()
+                    out.close(); err.close()
+                    del self.running[name]
+            time.sleep(0.05)
+
+    def result(self, name):
+        assert any(sp[0] == name for sp in self.specs), name
+        with self.cv:
+            while name not in self.done:
+                self.cv.wait(timeout=1.0)
+            seed = self.done[name][0]
+        print("SEEQ_FUZZ_SEED=%d" % seed)          # (pytest shows it with the failure; rerun with it set to replay)
+        return self.done[name]
+
+    def stop(self):
+        for _, p, out, err, _t in list(self.running.values()):
+            if p.poll() is None:
+                p.kill()
+                p.wait()
 
 
-def test_fuzz_long_lines_fresh_seed(gpu, capi, oracle):
-    seed = _fresh_seed()
-    # (119900423: found by this test in round 3 -- a 6-mer at distance 4 hits nearly everywhere, a candidate-free chunk is not
-    #  a hit-free one there, and a walk that ran on to the end of its line had not vouched for the lanes started behind it)
-    _run_fuzz([(seed, 10), (REGRESSION_SEEDS[0], 3), (REGRESSION_SEEDS[3], 3), (119900423, 8)], True)
+@pytest.fixture(scope="module", autouse=True)
+def background_jobs(request, tmp_path_factory):
+    selected = {it.name for it in request.session.items if it.path == request.path}
+    jobs = _Jobs(str(tmp_path_factory.mktemp("jobs")))
+    py = sys.executable
+    # (queued in the order the tests below ask for them)
+    if "test_fuzz_fresh_seed" in selected:
+        seed = _fresh_seed()
+        jobs.add("fuzz", seed, [py, "-c", FUZZ % dict(root=ROOT, long=False, seeds=[(seed, 40)] + [(sd, 6) for sd in REGRESSION_SEEDS], nshort=3000, nlong=120)], {})
+    if "test_fuzz_long_lines_fresh_seed" in selected:
+        seed = _fresh_seed()
+        # (119900423: found by this test in round 3 -- a 6-mer at distance 4 hits nearly everywhere, a candidate-free chunk is not
+        #  a hit-free one there, and a walk that ran on to the end of its line had not vouched for the lanes started behind it)
+        jobs.add("fuzz_long", seed, [py, "-c", FUZZ % dict(root=ROOT, long=True, seeds=[(seed, 10), (REGRESSION_SEEDS[0], 3), (REGRESSION_SEEDS[3], 3), (119900423, 8)],
+                                                             nshort=3000, nlong=120)], {})
+    if "test_fuzz_kinds_of_lines_fresh_seed" in selected:
+        seed = _fresh_seed()
+        jobs.add("kinds", seed, [py, os.path.join(ROOT, "profiles", "ignore_fuzz.py"), str(seed), "16"], {})
+    for vid, env in STRESS_ENVS.items():
+        if "test_long_lines_fresh_seed_stress[%s]" % vid in selected:
+            seed = _fresh_seed()
+            jobs.add("stress:" + vid, seed, [py, "-c", LEAD_STRESS % dict(root=ROOT, seed=seed, iters=70)], env)
+    if "test_cli_fuzz_against_the_reference_binary" in selected and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "seeq_ref")):
+        seed = _fresh_seed()
+        jobs.add("cli", seed, [py, os.path.join(ROOT, "profiles", "cli_diff_fuzz.py"), str(seed), "3", "16"], {"CLI_FUZZ_PAR": "1"})      # (one CLI on the card at a time)
+    jobs.start()
+    yield jobs
+    jobs.stop()
 
 
-def test_fuzz_kinds_of_lines_fresh_seed(gpu, capi, oracle):
-    """Round 5, profiles/ignore_fuzz.py: FASTQ-like text made of line KINDS -- reads (some in lower case, with U), quality-like lines
-    with a tunable share of bases (the count that decides an SQ_IGNORE marker falls on either side of m - tau), headers, '+' and
-    empty lines, lines longer than a tile's look-ahead and than a tile, CR LF line ends, bytes >= 0x80, lines stretched so that the next
-    begins a lane or a tile, copies of the pattern with skipped bytes INSIDE them, patterns poor in one base, one or two column words --
-    under the three non-DNA modes, first / best / all records and both counts against the oracle, default plan and forced onto
-    k_pair, every fourth buffer in 64 KiB segments.  A fresh seed per run, 16 buffers.  (Its first campaigns found the two defects
-    test_ignore_lines_that_begin_with_their_tile and test_direct_regions_on_lines_of_259_bytes pin.)"""
-    script = os.path.join(ROOT, "profiles", "ignore_fuzz.py")
-    seed = _fresh_seed()
-    r = subprocess.run([sys.executable, script, str(seed), "16"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ignore fuzz OK" in r.stdout, (seed, r.stdout[-3000:], r.stderr[-2000:])
-    assert "k_pair" in r.stdout, r.stdout[-500:]
-
-
-def test_cli_fuzz_against_the_reference_binary(gpu, capi):
-    """Round 5, profiles/cli_diff_fuzz.py: seeq_amd/bin/seeq against oracle/_ref/seeq_ref (the reference's own sources, compiled by
-    oracle/Makefile) on files of line kinds -- reads, quality-like lines, headers, empty lines, lines of a few KB, CR LF ends, NULs,
-    copies with foreign bytes inside -- with random patterns, distances, -b / -a / -i, -x 0 / 1 / 2 and format options in any
-    combination (the ones the reference rejects included): stdout and exit status byte for byte.  Fresh seed, 3 files x 16 runs."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "seeq_ref")
-    if not os.path.exists(ref):
-        pytest.skip("oracle/_ref/seeq_ref is not built (it is built where /root/reference is present and travels with the snapshot)")
-    seed = _fresh_seed()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "cli_diff_fuzz.py"), str(seed), "3", "16"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "cli diff fuzz OK: 48" in r.stdout, (seed, r.stdout[-3000:], r.stderr[-2000:])
-
-
+# (the tests that run in THIS process come first: the campaigns queued above go on beside them, and the tests that wait for them follow)
 # (round 5: the knobs that kept superseded kernels compiled in are gone -- SEEQ_VERIFY / SEEQ_ORDER / SEEQ_EMIT_ALL = old, SEEQ_NO_SKIPCOUNT,
 #  SEEQ_NO_LL_FILTER, SEEQ_PAIR_PF, SEEQ_EXACT, SEEQ_PACKED_STAGE: tag r05-before-prune -- so are their variants; what is left selects a
 #  SHIPPED path that some input reaches on its own)
@@ -160,6 +207,41 @@ def test_forced_variants(gpu, capi, oracle, variant):
     length and long lines): the results must be the oracle's whatever ran."""
     _run_fuzz([(REGRESSION_SEEDS[1], 3), (REGRESSION_SEEDS[2], 3)], False, variant, nshort=1500)
     _run_fuzz([(REGRESSION_SEEDS[2], 1)], True, variant, nlong=60)
+
+
+def test_fuzz_fresh_seed(gpu, capi, oracle, background_jobs):
+    seed, rc, so, se = background_jobs.result("fuzz")
+    assert rc == 0 and "FUZZ OK" in so, (seed, so[-800:], se[-3000:])
+    assert "k_pair" in so or "k_stream" in so, so
+
+
+def test_fuzz_long_lines_fresh_seed(gpu, capi, oracle, background_jobs):
+    seed, rc, so, se = background_jobs.result("fuzz_long")
+    assert rc == 0 and "FUZZ OK" in so, (seed, so[-800:], se[-3000:])
+
+
+def test_fuzz_kinds_of_lines_fresh_seed(gpu, capi, oracle, background_jobs):
+    """Round 5, profiles/ignore_fuzz.py: FASTQ-like text made of line KINDS -- reads (some in lower case, with U), quality-like lines
+    with a tunable share of bases (the count that decides an SQ_IGNORE marker falls on either side of m - tau), headers, '+' and
+    empty lines, lines longer than a tile's look-ahead and than a tile, CR LF line ends, bytes >= 0x80, lines stretched so that the next
+    begins a lane or a tile, copies of the pattern with skipped bytes INSIDE them, patterns poor in one base, one or two column words --
+    under the three non-DNA modes, first / best / all records and both counts against the oracle, default plan and forced onto
+    k_pair, every fourth buffer in 64 KiB segments.  A fresh seed per run, 16 buffers.  (Its first campaigns found the two defects
+    test_ignore_lines_that_begin_with_their_tile and test_direct_regions_on_lines_of_259_bytes pin.)"""
+    seed, rc, so, se = background_jobs.result("kinds")
+    assert rc == 0 and "ignore fuzz OK" in so, (seed, so[-3000:], se[-2000:])
+    assert "k_pair" in so, so[-500:]
+
+
+def test_cli_fuzz_against_the_reference_binary(gpu, capi, background_jobs):
+    """Round 5, profiles/cli_diff_fuzz.py: seeq_amd/bin/seeq against oracle/_ref/seeq_ref (the reference's own sources, compiled by
+    oracle/Makefile) on files of line kinds -- reads, quality-like lines, headers, empty lines, lines of a few KB, CR LF ends, NULs,
+    copies with foreign bytes inside -- with random patterns, distances, -b / -a / -i, -x 0 / 1 / 2 and format options in any
+    combination (the ones the reference rejects included): stdout and exit status byte for byte.  Fresh seed, 3 files x 16 runs."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "seeq_ref")):
+        pytest.skip("oracle/_ref/seeq_ref is not built (it is built where /root/reference is present and travels with the snapshot)")
+    seed, rc, so, se = background_jobs.result("cli")
+    assert rc == 0 and "cli diff fuzz OK: 48" in so, (seed, so[-3000:], se[-2000:])
 
 
 LEAD_STRESS = r"""
@@ -224,45 +306,14 @@ print("LEAD STRESS OK")
 STRESS_ENVS = {"leaders": {}, "one-lane-per-line": {"SEEQ_NO_LEADERS": "1"}, "256KiB-segments": {"SEEQ_SEGMENT_BYTES": "262144"}}
 
 
-@pytest.fixture(scope="module", autouse=True)
-def stress_jobs(request, tmp_path_factory):
-    """The three variants of the long-line stress are processes of their own (20-26 s each, most of it the oracle on one host core, the GPU
-    idle): they START when this module does and run beside its other tests -- four processes on the card with pytest's own --; each test below
-    waits for its variant and judges it.  Same iterations, same checks as when they ran one after the other (66 s of the suite)."""
-    wanted = [it.callspec.id for it in request.session.items
-              if it.path == request.path and it.name.startswith("test_long_lines_fresh_seed_stress[") and hasattr(it, "callspec")]
-    jobs = {}
-    d = tmp_path_factory.mktemp("stress")
-    for vid in wanted:
-        seed = _fresh_seed()
-        code = LEAD_STRESS % dict(root=ROOT, seed=seed, iters=70)
-        out, err = open(os.path.join(d, vid + ".out"), "w+"), open(os.path.join(d, vid + ".err"), "w+")
-        jobs[vid] = (seed, subprocess.Popen([sys.executable, "-c", code], stdout=out, stderr=err, env=dict(os.environ, **STRESS_ENVS[vid])), out, err)
-    yield jobs
-    for _, p, out, err in jobs.values():
-        if p.poll() is None:
-            p.kill()
-            p.wait()
-        out.close(); err.close()
-
-
 @pytest.mark.parametrize("vid", list(STRESS_ENVS), ids=list(STRESS_ENVS))
-def test_long_lines_fresh_seed_stress(gpu, capi, oracle, stress_jobs, vid):
+def test_long_lines_fresh_seed_stress(gpu, capi, oracle, background_jobs, vid):
     """The long-line machinery (k_stream's long-line variant and Myers mode, the window walk, leaders with their void-and-repeat
     rule) under a FRESH seed per run: 70 iterations per variant (210 a run) of 1-3 lines of 40-150 KB, patterns of 12-42 positions
     that are random, periodic or a single base, text with planted copies, tandem copies (windows that run into one another),
     poly-base runs and periodic stretches of up to 800 bytes -- --all records, both counts, --best and first-hit records against
     the oracle; with the leaders, with one lane per line, and with 256 KiB segments (lines that span segments)."""
-    seed, p, out, err = stress_jobs[vid]
-    print("SEEQ_FUZZ_SEED=%d" % seed)
-    try:
-        rc = p.wait(timeout=1200)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        p.wait()
-        rc = -9
-    out.seek(0); err.seek(0)
-    so, se = out.read(), err.read()
+    seed, rc, so, se = background_jobs.result("stress:" + vid)
     assert rc == 0 and "LEAD STRESS OK" in so, (seed, STRESS_ENVS[vid], so[-800:], se[-3000:])
 
 
