@@ -3,7 +3,8 @@
 oracle/Makefile): files made of line kinds (reads, quality-like lines, headers, '+', empty lines, short lines, lines of a few KB, CR LF ends,
 a NUL now and then, copies of the pattern with foreign bytes inside), random patterns (classes, N), distances, match modes (-b -a -i), non-DNA
 modes (-x 0 1 2) and format options (-c -m -n -l -p -k -f -e -r in any combination, the ones the reference rejects included): stdout and the exit
-status of seeq_amd/bin/seeq must be the reference's, byte for byte.  Bytes >= 0x80 are left out (the reference indexes a table with a negative char
+status of seeq_amd/bin/seeq must be the reference's, byte for byte -- half of the runs with the ingest pipeline cut into small chunks (700 bytes
+to 300 KB, 1-3 lanes, a device listed twice).  Bytes >= 0x80 are left out (the reference indexes a table with a negative char
 there: a stated difference).  Usage: python profiles/cli_diff_fuzz.py [seed] [files] [invocations per file]"""
 import os
 import random
@@ -102,12 +103,20 @@ for fno in range(nfiles):
             args += ["-x", str(rng.randint(0, 2))]
         fmt = [f for f in ("-c", "-m", "-n", "-l", "-p", "-k", "-f", "-e", "-r") if rng.random() < 0.22]
         rng.shuffle(fmt)
-        jobs.append(args + fmt)
+        # the ingest pipeline of OUR binary (seeq_file.c): now and then small chunks (lines longer than a chunk: it has to grow), 1-3 lanes, one device listed twice
+        env = {}
+        if rng.random() < 0.5:
+            env["SEEQ_CHUNK_BYTES"] = str(rng.choice([700, 3000, 20000, 65536, 300001]))
+            env["SEEQ_LANES"] = str(rng.randint(1, 3))
+            if rng.random() < 0.3:
+                env["SEEQ_DEVICES"] = "0,0"
+        jobs.append((args + fmt, env))
 
-    def run(args):
-        a = subprocess.run([OURS] + args + [pattern, path], capture_output=True, timeout=120)
+    def run(job):
+        args, env = job
+        a = subprocess.run([OURS] + args + [pattern, path], capture_output=True, timeout=120, env=dict(os.environ, **env))
         b = subprocess.run([REF] + args + [pattern, path], capture_output=True, timeout=120)
-        return args, a, b
+        return args + ["   env:"] + ["%s=%s" % kv for kv in sorted(env.items())], a, b
     with ThreadPoolExecutor(max_workers=int(os.environ.get("CLI_FUZZ_PAR", "4"))) as pool:      # (CLI processes on the card at a time)
         for args, a, b in pool.map(run, jobs):
             if a.returncode != b.returncode or a.stdout != b.stdout:
