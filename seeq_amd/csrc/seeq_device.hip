@@ -539,6 +539,7 @@ struct seeqdev_pattern {
    int       sdfa_state;     /* the streaming automaton of k_stream (seeq_dfa.h): 0 not tried, 1 built, -1 none fits */
    uint16_t *d_sdfa;         /* transition table in HBM, staged into LDS by k_stream */
    uint16_t *d_sdfa_skip;    /* its skip variant (SQ_IGNORE: column 4 maps every state onto itself) */
+   uint16_t *d_sdfa_restart; /* a filter's restart variant (long lines: acceptance goes on from the root, every part occurrence is flagged) */
    uint32_t  sdfa_rows, sdfa_final_base;
    int       sdfa_parts;     /* 1: the complete automaton (exact verdicts); > 1: partition filter (candidates) */
    int       sdfa_warm;      /* bytes of warm-up a chunk walk needs */
@@ -611,6 +612,7 @@ extern "C" void seeqdevPatternFree(seeqdev_pattern_t *p)
    if (p->d_peq) (void)hipFree(p->d_peq);
    if (p->d_sdfa) (void)hipFree(p->d_sdfa);
    if (p->d_sdfa_skip) (void)hipFree(p->d_sdfa_skip);
+   if (p->d_sdfa_restart) (void)hipFree(p->d_sdfa_restart);
    if (p->d_pair) (void)hipFree(p->d_pair);
    if (p->d_quad) (void)hipFree(p->d_quad);
    pthread_mutex_destroy(&p->plan_lock);
@@ -631,10 +633,12 @@ static void pattern_plan_stream(seeqdev_pattern *mp, bool complete_only)
       if (d) {
          const size_t bytes = (size_t)d->nrows * 16;
          uint16_t *skip = seeq_dfa_skip_variant(d);
-         uint16_t *t0 = nullptr, *t1 = nullptr;
-         if (skip && hipMalloc((void **)&t0, bytes) == hipSuccess && hipMemcpy(t0, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMalloc((void **)&t1, bytes) == hipSuccess && hipMemcpy(t1, skip, bytes, hipMemcpyHostToDevice) == hipSuccess) {
-            mp->d_sdfa = t0; mp->d_sdfa_skip = t1;
+         uint16_t *rst = d->nparts > 1 ? seeq_dfa_restart_variant(d) : nullptr;
+         uint16_t *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;
+         if (skip && (rst || d->nparts <= 1) && hipMalloc((void **)&t0, bytes) == hipSuccess && hipMemcpy(t0, d->table, bytes, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMalloc((void **)&t1, bytes) == hipSuccess && hipMemcpy(t1, skip, bytes, hipMemcpyHostToDevice) == hipSuccess &&
+             (!rst || (hipMalloc((void **)&t2, bytes) == hipSuccess && hipMemcpy(t2, rst, bytes, hipMemcpyHostToDevice) == hipSuccess))) {
+            mp->d_sdfa = t0; mp->d_sdfa_skip = t1; mp->d_sdfa_restart = t2;
             mp->sdfa_rows = d->nrows;
             mp->sdfa_final_base = d->acc_final;            /* state value of ACC_NEW */
             mp->sdfa_parts = d->nparts;
@@ -644,8 +648,10 @@ static void pattern_plan_stream(seeqdev_pattern *mp, bool complete_only)
          } else {
             if (t0) (void)hipFree(t0);
             if (t1) (void)hipFree(t1);
+            if (t2) (void)hipFree(t2);
          }
          free(skip);
+         free(rst);
          seeq_dfa_free(d);
       }
       __atomic_store_n(&mp->sdfa_state, state, __ATOMIC_RELEASE);
@@ -1467,8 +1473,8 @@ static int seg_onepass(seeqdev_scan *s, const SegRun &r, ScanArgs &a, size_t sg,
    f.clk_probe = (s->prof && s->clk_probe && use_pair) ? s->clk_probe + 4 * sg : nullptr;
    uint32_t pos_bias = 0;
    if (use_stream) {
-      f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
-      f.ll_filter = plan.ll_filter ? 1u : 0u;
+      f.dfa = stream_sub == 2 ? pat->d_sdfa_skip : plan.ll_restart ? pat->d_sdfa_restart : pat->d_sdfa; f.dfa_rows = pat->sdfa_rows; f.dfa_final_base = pat->sdfa_final_base;
+      f.ll_filter = plan.ll_restart ? 2u : plan.ll_filter ? 1u : 0u;      /* (2: the restart table -- a chain that accepted inside its warm-up window names its first byte) */
       f.skip_thr = plan.skip_thr;
       if (use_pair) { f.dfa = pat->d_pair; f.dfa_rows = pat->pair_units; f.dfa_final_base = 0; f.pair = 1; f.ig_thr = plan.ig ? (uint32_t)(pat->wlen - pat->tau) : 0u; }
       if (use_myers) { f.dfa = (const uint16_t *)(s->d_eqtab + (size_t)512 * fw); f.dfa_rows = (uint32_t)(64 * fw); f.dfa_final_base = 0; f.pair = 2; }
@@ -1525,7 +1531,7 @@ static int seg_onepass(seeqdev_scan *s, const SegRun &r, ScanArgs &a, size_t sg,
    /* the exact pass walks candidate windows instead of whole lines where lines are long (sampled average);
       read-length lines are scanned whole -- the bookkeeping of the walk costs more than it saves there */
    a.stream_ch = stream_ll ? (uint32_t)stream_ch : 0u;
-   a.walk_ext = plan.walk_ext;
+   a.walk_ext = plan.walk_ext; a.ll_restart = plan.ll_restart ? 1u : 0u;
    return 0;
 }
 

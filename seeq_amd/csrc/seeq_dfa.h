@@ -270,6 +270,21 @@ static inline uint16_t *seeq_dfa_skip_variant(const seeq_dfa_t *d)
    return t;
 }
 
+/* The RESTART variant of a laid-out FILTER table (k_stream's long-line variant, round 5): acceptance does not absorb -- the row of ACC_NEW
+ * (row nstates: entered by the transition that completes a part occurrence, which is what the kernel flags) is a copy of the ROOT's row, so
+ * the walk goes on from the root and flags EVERY part occurrence, as k_pair's automata do (seeq_pair.h): the exact pass then scans
+ * m + tau columns either side of a candidate instead of the rest of its chunk.  Same rows, same state values.  malloc'ed copy, or NULL. */
+static inline uint16_t *seeq_dfa_restart_variant(const seeq_dfa_t *d)
+{
+   uint16_t *t = (uint16_t *)malloc((size_t)d->nrows * 8 * sizeof(uint16_t));
+   if (!t) return NULL;
+   memcpy(t, d->table, (size_t)d->nrows * 8 * sizeof(uint16_t));
+   const uint32_t r = d->nstates;                                     /* ACC_NEW */
+   const int rot_r = (int)((r >> 3) & 1);                             /* (the root, row 0, is not rotated) */
+   for (int k = 0; k < 8; k++) t[(size_t)r * 8 + (size_t)(k ^ (rot_r ? 4 : 0))] = d->table[k];
+   return t;
+}
+
 /* The complete automaton of the pattern, or NULL when it has more than SEEQ_DFA_MAX_STATES states. */
 static inline seeq_dfa_t *seeq_dfa_build_stream(const char *keys, int m, int tau)
 {

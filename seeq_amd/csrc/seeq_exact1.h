@@ -239,7 +239,9 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
          const uint32_t lastnl = c->seg_last_nl;
          const bool last_seg = a.seg_base + a.pos_bias + a.seg_len >= a.nbytes;
          win = walk && (last_seg || (lastnl != 0 && (int64_t)hs - (int64_t)a.pos_bias < (int64_t)lastnl));
-         wend = (((hs + col) | (a.stream_ch - 1u)) + 1u) - hs + a.walk_ext;
+         /* (ll_restart, round 5: the filter's restart table flags every part occurrence, so every occurrence of the pattern holds a candidate
+            and ends within m + tau behind it -- the window ends there, not at the end of the candidate's chunk) */
+         wend = a.ll_restart ? col + m + tau1 + 1u : (((hs + col) | (a.stream_ch - 1u)) + 1u) - hs + a.walk_ext;
       }
       bool latch = false;
       seeqdev_hit_t *out = nullptr;
@@ -267,9 +269,14 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
             for (int q = 0; q < 4; q++)
                *reinterpret_cast<fused_v4u *>(row + 16 * q) = direct_load16(a.text, off + pos + 16 * q, a.nbytes);
          }
+         uint32_t adv = 64;                                /* columns of this block the wave steps */
 #pragma unroll 1
          for (uint32_t t4 = 0; t4 < 64; t4 += 4) {
             if (!__any(!done)) break;
+            /* window walk: once EVERY lane still at work stands behind the end of its window the block ends here (round 5: the restart
+               table's windows are all 2 (m + tau) + 2 columns from a start 64 apart -- they end together, mid-block: 128 columns stepped for 86
+               before this); what a lane does next -- the next candidate, a longer window, the end -- is decided below as at a block's end */
+            if (walk && t4 != 0u && !__any(!done && !(win && pos + t4 >= wend))) { adv = t4; break; }
             /* four characters: the EQ lookups go out together, the column steps are predicated (no branches) */
             const uint32_t w4 = *reinterpret_cast<const uint32_t *>(row + t4);
             fused_eq_t<W> ev[4];
@@ -400,12 +407,14 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
             } else { EXACT1_CHARS4(false) }
 #undef EXACT1_CHARS4
          }
-         pos += 64;
+         pos += adv;
          if (walk && win && !done) {
             /* A score <= tau in the last 32 columns of a chunk (or inside the chunk the walk stands in) may have put
                that chunk's lane into the accepting state before it could report: the chunk has to be scanned whole. */
             const int32_t b = (int32_t)(((hs + pos) & ~(a.stream_ch - 1u)) - hs);      /* start of the chunk holding `pos` */
-            if (lastsub >= b - (int32_t)wback && b + (int32_t)a.stream_ch > (int32_t)wend) wend = (uint32_t)(b + (int32_t)a.stream_ch);
+            /* (not behind the restart table: no chain is ever absorbed there -- every part occurrence is a candidate of its own, or the first byte
+               of the chain that met it inside its warm-up window is -- and the leaders' spacing counts on windows that end where they say) */
+            if (!a.ll_restart && lastsub >= b - (int32_t)wback && b + (int32_t)a.stream_ch > (int32_t)wend) wend = (uint32_t)(b + (int32_t)a.stream_ch);
             if (pos >= wend) {
                /* the window is done and the columns behind are clean: nothing can hide before the next candidate */
                for (;;) {
@@ -417,7 +426,7 @@ __device__ __forceinline__ void exact1_body(const ScanArgs &a, const uint32_t *e
                      break;
                   }
                   const uint32_t cpos = hit_col[knext++];                 /* position of the repeat's first hit */
-                  const uint32_t ccol = cpos - hs, cend = ((cpos | (a.stream_ch - 1u)) + 1u) - hs + a.walk_ext;
+                  const uint32_t ccol = cpos - hs, cend = a.ll_restart ? ccol + m + tau1 + 1u : ((cpos | (a.stream_ch - 1u)) + 1u) - hs + a.walk_ext;
                   /* FASTA input: a header line carries the rank of the line before it (its newline is not counted), so a "repeat" may lie in the
                      header BEHIND this line's end.  The stretch jumped over must then hold no newline: a header's first byte, '>', is outside
                      the alphabet and fails the test -- unless the jump lands exactly on it, the newline being the stretch's last byte: the

@@ -64,6 +64,7 @@ struct ScanPlan {
    bool superset, need_nh, nh_is_count;
    bool window_ok;         /* k_pair: the exact pass scans candidate windows */
    bool ll_filter;         /* k_stream's long-line variant over a partition filter */
+   bool ll_restart;        /* ... walking the filter's RESTART table: every part occurrence is a candidate, windows of m + tau either side (round 5) */
    bool leaders;           /* long lines: candidates far behind the one before them get lanes of their own */
    bool lead_best;
    bool verify;            /* the exact pass is k_verify (+ k_nh_top, k_emit1): filters on text without skipped bytes, read-length lines */
@@ -178,6 +179,11 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
    p.skip_back = (uint32_t)(in.wlen + in.tau - 1) + (p.use_pair ? 1u : 0u);      /* (k_pair reports the second byte of a pair) */
    p.window_ok = p.use_pair && !in.no_window && !kn.no_window;
    p.ll_filter = p.use_fused && p.use_stream && p.stream_ll && p.filter && !p.use_pair && !p.use_myers;
+   /* Which table the long-line filter walks.  Absorbing (round 4): one candidate per chain and line, the exact pass scans the rest of the candidate's
+      chunk (~145 columns, lanes of very different lengths).  Restart (round 5): every part occurrence is a candidate (about twice as many), the exact
+      pass scans m + tau either side of each (~2 (m + tau) columns, all lanes alike); its warm-up remembers acceptances (2 VALU per warm-up byte and
+      chain).  The restart table pays where the exact pass is the larger part of the scan: filters that flag more than ~1 position in 20 KB. */
+   p.ll_restart = p.ll_filter && !kn.no_window && au.sdfa_pacc > 0.00005;      /* (SEEQ_NO_WINDOW=1: the absorbing table, A/B and tests) */
    p.walk_ext = p.ll_filter ? (uint32_t)(in.wlen + in.tau + 2) : 0u;
    p.skip_thr = (p.use_fused && p.use_stream && !p.use_pair && !p.use_myers && p.stream_sub == 2 && au.sdfa_parts == 1) ? (uint32_t)(in.wlen - in.tau) : 0u;
    p.lead_best = want == PLAN_WANT_RECORDS && match_opt == PLAN_SQ_BEST;      /* (one record per line: the groups' best hits are reduced per line) */
@@ -195,7 +201,7 @@ static inline void seeq_plan_print(FILE *f, const PlanIn &in, const PlanAutomata
               "automata: stream %s (parts %d, warm %d, p_acc %.2g), pair %s (warm %d, p_acc %.2g) | "
               "post-pass: %s, %s%s%s, skip_back %u%s\n",
            in.wlen, in.tau, (unsigned)in.options, in.want, in.avg_line, in.line_hint > 0 ? " (hint)" : "",
-           kname[p.path & 7], p.filter ? " [candidates: filter / prefix]" : "", p.stream_ll ? " [long lines]" : "", p.ll_filter ? " [filter on long lines]" : "",
+           kname[p.path & 7], p.filter ? " [candidates: filter / prefix]" : "", p.stream_ll ? " [long lines]" : "", p.ll_restart ? " [filter on long lines, restart table]" : p.ll_filter ? " [filter on long lines]" : "",
            p.rc == -2 ? " [multi: not k_pair's -- a scan per pattern]" : "",
            p.fw, 4 * p.stream_wu, p.stream_sub,
            au.sdfa_state == 1 ? "yes" : au.sdfa_state == 0 ? "not asked" : "none", au.sdfa_parts, au.sdfa_warm, au.sdfa_pacc,

@@ -112,6 +112,18 @@ __device__ __forceinline__ void stream_warm4x2(uint32_t &sa, uint32_t wa, uint32
    STREAM_X2(0) STREAM_X2(1) STREAM_X2(2) STREAM_X2(3)
 }
 
+/* the same, remembering whether a chain accepted (restart tables: a chain that restarted inside its warm-up window is out of step with the
+   walk the line's start would have made -- it names its own first byte a candidate, as k_pair's chains do) */
+__device__ __forceinline__ void stream_warm4x2_seen(uint32_t &sa, uint32_t wa, uint32_t &sb, uint32_t wb, uint32_t acc_new, uint32_t &seena, uint32_t &seenb)
+{
+   const uint32_t wma = wa & 0x0E0E0E0Eu, wmb = wb & 0x0E0E0E0Eu;
+   uint32_t ada, adb;
+   STREAM_X2(0) seena |= sa == acc_new ? 1u : 0u; seenb |= sb == acc_new ? 1u : 0u;
+   STREAM_X2(1) seena |= sa == acc_new ? 1u : 0u; seenb |= sb == acc_new ? 1u : 0u;
+   STREAM_X2(2) seena |= sa == acc_new ? 1u : 0u; seenb |= sb == acc_new ? 1u : 0u;
+   STREAM_X2(3) seena |= sa == acc_new ? 1u : 0u; seenb |= sb == acc_new ? 1u : 0u;
+}
+
 __device__ __forceinline__ void stream_own4x2(uint32_t &sa, uint32_t wa, uint32_t &hma, uint32_t &sb, uint32_t wb, uint32_t &hmb, uint32_t acc_new)
 {
    const uint32_t wma = wa & 0x0E0E0E0Eu, wmb = wb & 0x0E0E0E0Eu;
@@ -396,6 +408,23 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
          /* Two chains per lane: A = bytes 0..63 (warm-up: the previous lane's last bytes), B = bytes 64..127
             (warm-up: my own bytes before 64).  Same result, 16 % more gathers, but two of them in flight. */
          uint32_t sa = 0, sb = 0;
+         const bool restart = LL && a.ll_filter == 2u;     /* (wave-uniform) the filter's restart table: every part occurrence is flagged */
+         if (restart) {
+            uint32_t seena = 0, seenb = 0;
+            if (WU == 8) {
+               stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 2].x, pa.x), sb, v[NQ / 2 - 2].x, acc_new, seena, seenb);
+               stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 2].y, pa.y), sb, v[NQ / 2 - 2].y, acc_new, seena, seenb);
+            }
+            if (WU >= 6) {
+               stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 2].z, pa.z), sb, v[NQ / 2 - 2].z, acc_new, seena, seenb);
+               stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 2].w, pa.w), sb, v[NQ / 2 - 2].w, acc_new, seena, seenb);
+            }
+            stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 1].x, pb.x), sb, v[NQ / 2 - 1].x, acc_new, seena, seenb);
+            stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 1].y, pb.y), sb, v[NQ / 2 - 1].y, acc_new, seena, seenb);
+            stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 1].z, pb.z), sb, v[NQ / 2 - 1].z, acc_new, seena, seenb);
+            stream_warm4x2_seen(sa, stream_from_prev_lane(v[NQ - 1].w, pb.w), sb, v[NQ / 2 - 1].w, acc_new, seena, seenb);
+            blind = seena | (seenb << 1);
+         } else {
          if (WU == 8) {
             stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].x, pa.x), sb, v[NQ / 2 - 2].x);
             stream_warm4x2(sa, stream_from_prev_lane(v[NQ - 2].y, pa.y), sb, v[NQ / 2 - 2].y);
@@ -413,6 +442,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, MY ? 4 : 8) void k_stream(FusedArgs
             complete automaton the exact pass notices (a score <= tau in the columns before the chunk: it then scans the chunk whole);
             a part occurrence it cannot see -- so the blind chain names its own first byte a candidate and its chunk is scanned. */
          if (LL && a.ll_filter) blind = ((sa == 16u || sa == acc_new) ? 1u : 0u) | ((sb == 16u || sb == acc_new) ? 2u : 0u);
+         }
 #pragma unroll
          for (int r = 0; r < NM / 2; r++) {
             uint32_t hma = 0, hmb = 0;
@@ -872,7 +902,10 @@ __global__ __launch_bounds__(256) void k_lead_apply(ScanArgs a, const uint32_t *
          const uint32_t ps = a.hit_start[k - 1];
          const uint32_t pabs = ps != 0xFFFFFFFFu ? ps + hit_col[k - 1] : hit_col[k - 1];
          const uint32_t abs_ = hit_col[k];
-         const uint32_t free_end = ((pabs / ch) + 2u) * ch;          /* end of the chunk behind the previous candidate's */
+         /* end of the chunk behind the previous candidate's -- behind the restart table (round 5) the end of the previous candidate's WINDOW: m + tau + 2
+            columns behind it (k_exact1; the walk may step up to a block further, which the 64 below allow for, and k_lead_check holds every fresh
+            start against where the walk before it really ended) */
+         const uint32_t free_end = a.ll_restart ? pabs + (uint32_t)a.m + (uint32_t)a.tau + 2u : ((pabs / ch) + 2u) * ch;
          const uint32_t ls = a.hit_start[f1 - 1u];
          /* (k_exact1 walks windows only in lines that end inside the segment: the same test) */
          const bool win = ls != 0xFFFFFFFFu && (last_seg || (lastnl != 0u && (int64_t)ls - (int64_t)a.pos_bias < (int64_t)lastnl));

@@ -78,6 +78,7 @@ struct ScanArgs {
                                    the segment-wide offsets, made by the three-launch scan) */
    uint32_t        walk_ext;    /* window walk behind a partition FILTER on long lines: columns a window runs on behind the chunk of its candidate --
                                    m + tau + 2: an occurrence ends no further behind the part occurrence the filter saw (0: the candidates are hit ends) */
+   uint32_t        ll_restart;  /* the long-line filter walked its RESTART table (seeq_dfa_restart_variant): windows end m + tau + 2 behind a candidate */
    uint32_t        rec_pitch;   /* packed read batches: the exact pass runs on a private staging text -- a record's line offset is reported as
                                    (line - 1) * rec_pitch, the offset the same read has in the ASCII form of the batch (0: the line's real offset) */
    uint32_t       *nz_sum;      /* k_verify: per chunk the entries with >= 1 hit (NULL: not wanted) */

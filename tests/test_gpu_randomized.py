@@ -91,9 +91,13 @@ print("FUZZ OK", tot, "record scans", ks)
 REGRESSION_SEEDS = [100, 103, 109, 112]        # (round 2's extended fuzz: seeds 100..111 and 112..123; one of each residue mod 3 / mod 4)
 
 
+_seed_calls = [0]
+
+
 def _fresh_seed():
     env = os.environ.get("SEEQ_FUZZ_SEED")
-    seed = int(env) if env else (int(time.time() * 1000) ^ os.getpid()) % 1_000_000_007
+    _seed_calls[0] += 1                           # (the campaigns of a run are queued within the same millisecond: every call its own seed)
+    seed = int(env) if env else ((int(time.time() * 1000) ^ os.getpid()) + 7919 * _seed_calls[0]) % 1_000_000_007
     print("SEEQ_FUZZ_SEED=%d" % seed)              # (pytest shows it with the failure; rerun with it set to replay)
     return seed
 
