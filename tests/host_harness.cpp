@@ -377,7 +377,7 @@ void plan_ensure_host(void *ctx, int which, int complete_only, PlanAutomata *au)
 
 // flags: bit 0 force_ll, 1 no_stream, 2 no_stream_nd, 3 no_window, 4 sample_dirty, 5 multi_active; knob_kernel: SEEQ_FUSED_KERNEL (0 auto).
 // out[16]: rc, path, fw, use_stream, use_pair, use_myers, filter, stream_ll, stream_sub, stream_wu, verify, order2, leaders, window_ok,
-//          ll_filter, skip_back.  Returns 0.
+//          ll_filter (2: on the restart table), skip_back.  Returns 0.
 extern "C" int harness_plan(const char *keys, int m, int tau, int options, int want, double avg_line, int flags, int knob_kernel, int *out)
 {
    ScanKnobs kn;
@@ -395,7 +395,7 @@ extern "C" int harness_plan(const char *keys, int m, int tau, int options, int w
    plan_ctx ctx = {keys, m, tau};
    const ScanPlan p = seeq_plan_scan(in, au, plan_ensure_host, &ctx);
    const int v[16] = {p.rc, p.path, p.fw, p.use_stream, p.use_pair, p.use_myers, p.filter, p.stream_ll, p.stream_sub, p.stream_wu, p.verify, p.order2,
-                      p.leaders, p.window_ok, p.ll_filter, (int)p.skip_back};
+                      p.leaders, p.window_ok, p.ll_restart ? 2 : (p.ll_filter ? 1 : 0), (int)p.skip_back};
    for (int i = 0; i < 16; i++) out[i] = v[i];
    return 0;
 }

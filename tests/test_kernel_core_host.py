@@ -591,8 +591,12 @@ def test_scan_plans_of_the_baseline_configurations(harness):
     p = plan(head, 3, SQ_ALL, RECORDS, 1.3e8)
     assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"], p["verify"], p["order2"]) == (5, 1, 0, 0, 1, 0, 0), p
     full = "GATGTAGCGCGATTAGCCTGAAAATGCGAGTACGGCGCGAAT"
-    p = plan(full[:27], 4, SQ_ALL, RECORDS, 1.3e8)
+    p = plan(full[:27], 3, SQ_ALL, RECORDS, 1.3e8)          # a selective filter: the absorbing table
     assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (5, 1, 1, 1, 1), p
+    p = plan(full[:27], 4, SQ_ALL, RECORDS, 1.3e8)          # round 5: filters that flag more than a position in 20 KB walk their restart table
+    assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (5, 1, 1, 2, 1), p
+    p = plan(full[:34], 7, SQ_ALL, RECORDS, 1.3e8)
+    assert (p["path"], p["fw"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (5, 2, 1, 1, 2, 1), p
     p = plan(full, 15, SQ_ALL, RECORDS, 1.3e8)
     assert (p["path"], p["use_myers"], p["fw"], p["stream_ll"], p["filter"]) == (7, 1, 2, 1, 0), p
     # patterns beyond the two-word column, SQ_STREAM input: the generic path; a multi-pattern scan that is not k_pair's: a scan per pattern
