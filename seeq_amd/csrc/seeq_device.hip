@@ -1374,7 +1374,7 @@ static int run_setup(seeqdev_scan *s, SegRun &r)
          if (use_pair) {
 #define SEEQ_PAIR_FN(...) (stream_wu == 4 ? (const void *)k_pair<4, __VA_ARGS__> : stream_wu == 5 ? (const void *)k_pair<5, __VA_ARGS__> : stream_wu == 6 ? (const void *)k_pair<6, __VA_ARGS__> \
                           : stream_wu == 7 ? (const void *)k_pair<7, __VA_ARGS__> : (const void *)k_pair<8, __VA_ARGS__>)
-            stream_fn = fasta ? SEEQ_PAIR_FN(true) : plan.ig ? SEEQ_PAIR_FN(false, true) : SEEQ_PAIR_FN(false);
+            stream_fn = fasta ? SEEQ_PAIR_FN(true) : plan.ig ? SEEQ_PAIR_FN(false, true) : plan.pair_ll ? SEEQ_PAIR_FN(false, false, true) : SEEQ_PAIR_FN(false);
             dfa_lds = (size_t)pat->pair_units * 16;
 #undef SEEQ_PAIR_FN
          }

@@ -194,10 +194,15 @@ __device__ __forceinline__ void pair_walk(const fused_v4u (&v)[8], uint32_t halo
  * (FusedArgs.ig_thr = m - tau); a line belongs to the tile it starts in, which reads the part of it that lies behind the tile (256 bytes) to count it
  * whole: FASTQ quality lines hold ~10 such characters in 150 and stay silent, headers and '+' lines hold none.  k_bounds2 (seeq_order.h) adds a
  * frequency bound on the pattern's most frequent base, and counts the rare line that was marked unseen (longer than a tile, or than the 256 bytes). */
-template <int WU, bool FA, bool IG = false>
+/* LL (round 5): long lines -- the text of k_stream's long-line variant (a chromosome per line) on this walk: per-tile flags and the
+ * segment's last newline for the window walk of the exact pass (seeq_exact1.h), EVERY flag of a chain kept (the walk jumps from
+ * candidate to candidate: what lies between two of them is not scanned), no request for another kernel.  The candidates are this
+ * kernel's as ever: every occurrence holds one or ends on the byte before one, and the exact pass scans m + tau + 1 either side. */
+template <int WU, bool FA, bool IG = false, bool LL = false>
 __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
 {
    static_assert(!(FA && IG), "SQ_IGNORE on FASTA input stays with k_stream");
+   static_assert(!(LL && (FA || IG)), "the long-line variant serves plain text under SQ_FAIL / SQ_CONVERT");
    constexpr int NW = STREAM_NW;
    constexpr int CH = 128;
    constexpr int NQ = CH / 16;                            /* 16-byte pieces per lane */
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
    if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) { a.clk_probe[0] = __builtin_readcyclecounter(); a.clk_probe[1] = wall_clock64(); }
    uint32_t wv_lines = 0, wv_hitlines = 0, wv_hdrs = 0, slice_pos = 0;    /* wave-uniform */
    bool wv_overflow = false;
-   uint32_t wv_dirty = 0;
+   uint32_t wv_dirty = 0, wv_lastnl = 0;
    uint32_t dmode = 0;                                    /* wave-uniform: a tile of mine failed the fast alphabet check (DM, below) */
    uint4 *slice = a.tmp + (size_t)gwave * a.slice_cap;
    const uint64_t lim = a.seg_base + a.seg_len;           /* bytes at or beyond it are not this segment's */
@@ -272,10 +277,13 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          uint32_t tile_bad;
          pair_walk<WU, true>(v, halo, halo_nl, hm, nmask, tile_bad);
          /* the fast check failed somewhere in the tile (wave-uniform): a byte that is not an upper-case base, N or a newline */
-         dmode = (uint32_t)__builtin_amdgcn_readfirstlane(__ballot(tile_bad != 0) != 0 ? 1 : 0);
+         const uint64_t badlanes = __ballot(tile_bad != 0);
+         dmode = (uint32_t)__builtin_amdgcn_readfirstlane(badlanes != 0 ? 1 : 0);
+         if (LL && lane == 0) { a.tile_dirty[tile] = badlanes != 0 ? 1u : 0u; a.tile_dmask[tile] = badlanes; }   /* (the window walk jumps over clean stretches only) */
       } else {
          uint32_t unused;
          pair_walk<WU, false>(v, halo, halo_nl, hm, nmask, unused);
+         if (LL && lane == 0) { a.tile_dirty[tile] = 1u; a.tile_dmask[tile] = ~0ull; }      /* (no check in this mode: nothing of the tile counts as clean) */
       }
       /* DM (round 5): text with bytes outside { A C G T N \n } -- FASTQ quality lines, lower case.  Such a byte may alias onto the
          newline column ('+', ':', 'J' ...), so the newline masks are made exactly, from the registers, which still hold the tile
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          and of those behind its last one; between two newlines (short lines) all of them.  The exact pass scans a line
          from before its first candidate to behind its last one: what is dropped lies in between.  Wave-uniform, rare on
          read-length lines with a prefix automaton, the rule with a partition filter. */
-      if (__ballot(((hm[0] & (hm[0] - 1u)) | (hm[1] & (hm[1] - 1u))) != 0)) {
+      if (!LL && __ballot(((hm[0] & (hm[0] - 1u)) | (hm[1] & (hm[1] - 1u))) != 0)) {      /* (LL: the window walk scans around every candidate, not from the first to the last) */
 #pragma unroll
          for (int x = 0; x < 2; x++) {
             const uint32_t n0 = nmask[2 * x], n1 = nmask[2 * x + 1], h = hm[x];
@@ -470,12 +478,14 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       }
       /* last newline per lane (tile-relative + 2 = start of the next line + 1; 0: none) and its prefix maximum */
       uint32_t incl_last = 0;
-      if (tot_n && tot_h) {                               /* wave-uniform */
+      if (tot_n && (tot_h || LL)) {                       /* wave-uniform */
          uint32_t my_last = 0;
 #pragma unroll
          for (int r = 0; r < NM; r++)
             if (nmask[r]) my_last = (uint32_t)lane * CH + 32u * r + (31u - (uint32_t)__builtin_ctz(nmask[r])) + 2u;
          incl_last = wave_incl_max_u32(my_last);
+         /* the segment's last newline decides which line runs on into the next segment (k_exact1) */
+         if (LL) wv_lastnl = tile * TB + (uint32_t)__builtin_amdgcn_readlane((int)incl_last, 63) - 1u;
       }
       /* ---- ordered compaction of the candidates: per-wave slice, no atomics ---- */
       if (tot_h) {
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
          a.tile_hits[tile] = tot_h;
       }
       /* a candidate inside a line of >= a whole tile: this is long-line input -- k_stream's long-line variant takes over */
-      if (tot_h && !tot_n && !partial && !(t0 <= last && last < t0 + TB)) wv_dirty |= 2u;
+      if (!LL && tot_h && !tot_n && !partial && !(t0 <= last && last < t0 + TB)) wv_dirty |= 2u;
       wv_lines += tot_n + extra;
       wv_hdrs += tot_d + hd_extra;
       wv_hitlines += tot_h;
@@ -532,6 +542,7 @@ __global__ __launch_bounds__(64 * STREAM_NW, 8) void k_pair(FusedArgs a)
       a.wg_hits[gwave] = wv_overflow ? 0u : slice_pos;
       a.wg_part[4 * gwave + 0] = wv_lines;
       a.wg_part[4 * gwave + 1] = wv_hdrs;
+      if (LL) a.wg_lastnl[gwave] = wv_lastnl;    /* offset + 1 of the last newline this wave saw */
       a.wg_part[4 * gwave + 2] = wv_overflow ? (wv_hitlines | 0x80000000u) : wv_hitlines;
       a.wg_part[4 * gwave + 3] = wv_dirty;       /* 1: a byte outside the alphabet, 2: long-line input (k_fused_post acts on them) */
    }   if (a.clk_probe != nullptr && blockIdx.x == 0 && tid == 0) { a.clk_probe[2] = __builtin_readcyclecounter(); a.clk_probe[3] = wall_clock64(); }

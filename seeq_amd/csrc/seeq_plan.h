@@ -64,6 +64,7 @@ struct ScanPlan {
    bool superset, need_nh, nh_is_count;
    bool window_ok;         /* k_pair: the exact pass scans candidate windows */
    bool ll_filter;         /* k_stream's long-line variant over a partition filter */
+   bool pair_ll;           /* k_pair's long-line variant (round 5) */
    bool ll_restart;        /* ... walking the filter's RESTART table: every part occurrence is a candidate, windows of m + tau either side (round 5) */
    bool leaders;           /* long lines: candidates far behind the one before them get lanes of their own */
    bool lead_best;
@@ -139,16 +140,21 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
       keep a superset a superset; a skipped byte, SQ_IGNORE, does not), while it makes few false candidates. */
    {
       const bool long_lines = (in.avg_line > 600.0 && kn.kernel != 3) || in.force_ll;      /* (a candidate inside a line of a whole tile sets force_ll) */
+      /* (round 5: long lines too -- LL in seeq_pair.h -- under SQ_FAIL / SQ_CONVERT on plain text, for one pattern, while its automaton flags few enough
+         positions for the window walk: the rule of k_stream's long-line filters below, with the restart walk's cost per candidate) */
+      const bool pair_ll = long_lines && (nd == 0 || nd == PLAN_SQ_CONVERT) && !fasta && !in.multi_active && kn.kernel != 1 && !kn.no_window;
       /* (round 5: SQ_IGNORE too -- a line that holds a skipped byte is named whole by a marker, every other line is what it is under SQ_FAIL: IG in
          seeq_pair.h; not FASTA input, not several patterns at once) */
       const bool ig_ok = nd == PLAN_SQ_IGNORE && !fasta && !in.multi_active;
-      if (p.fusable && in.force_path != 1 && (options & PLAN_MASK_INPUT) == 0 && (nd == 0 || nd == PLAN_SQ_CONVERT || ig_ok) && !long_lines && !in.no_stream &&
+      if (p.fusable && in.force_path != 1 && (options & PLAN_MASK_INPUT) == 0 && (nd == 0 || nd == PLAN_SQ_CONVERT || ig_ok) && (!long_lines || pair_ll) && !in.no_stream &&
           /* (round 5: text full of foreign bytes -- FASTQ records -- stays here: a tile that fails the fast alphabet check makes its newline
              masks again from its registers, and the exact pass looks at the bytes before a window, seeq_verify.h.  FASTA records with a
              header per read stay with k_stream: the header test of the FA variant reads a byte per newline) */
           (kn.kernel == 3 || (kn.kernel == 0 && !(in.sample_dirty && in.line_hint <= 0 && fasta))) && in.seg_bytes % (64u * 128u) == 0) {
          if (au.pair_state == 0) ensure(ctx, 1, 0, &au);
-         p.use_pair = au.pair_state == 1 && (kn.kernel == 3 || in.multi_active || au.pair_pacc * in.avg_line <= 0.25);
+         p.use_pair = au.pair_state == 1 && (kn.kernel == 3 || in.multi_active || (long_lines ? au.pair_pacc > 0.0 && au.pair_pacc <= (p.fw == 1 ? 0.00058 : 0.0010) && in.wlen + in.tau + 2 <= 64      /* (0: no estimate -- a prefix that accepts nearly everything, m = 42 with 15 errors) */
+                                                                                                   : au.pair_pacc * in.avg_line <= 0.25));
+         p.pair_ll = p.use_pair && long_lines;
       }
       if (p.use_pair) { p.use_stream = true; p.can_sub = false; p.ig = nd == PLAN_SQ_IGNORE; }
       if (in.multi_active && !p.use_pair) { p.rc = -2; return p; }      /* this text / these options are not k_pair's: a scan per pattern */
@@ -169,7 +175,7 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
       p.stream_ll = in.avg_line > 600.0 || in.force_ll;   /* long lines: bookkeeping for the window walk */
       p.stream_sub = p.can_sub ? (nd == PLAN_SQ_IGNORE ? 2 : 1) : 0;
       if (p.use_myers) { p.stream_ll = true; p.stream_sub = 0; }       /* (the window walk of the exact pass serves every line length) */
-      if (p.use_pair) { p.stream_ll = false; p.stream_sub = 0; }
+      if (p.use_pair) { p.stream_ll = p.pair_ll; p.stream_sub = 0; }
    }
    p.use_direct = p.use_fused && !p.use_stream;
    p.path = p.use_fused ? (p.use_pair ? 6 : p.use_myers ? 7 : p.use_stream ? 5 : 3) : 1;
@@ -177,13 +183,13 @@ static inline ScanPlan seeq_plan_scan(const PlanIn &in, PlanAutomata &au, seeq_p
    if (p.superset) p.need_nh = true;
    /* ---- the post-pass ---- */
    p.skip_back = (uint32_t)(in.wlen + in.tau - 1) + (p.use_pair ? 1u : 0u);      /* (k_pair reports the second byte of a pair) */
-   p.window_ok = p.use_pair && !in.no_window && !kn.no_window;
+   p.window_ok = p.use_pair && !p.pair_ll && !in.no_window && !kn.no_window;
    p.ll_filter = p.use_fused && p.use_stream && p.stream_ll && p.filter && !p.use_pair && !p.use_myers;
    /* Which table the long-line filter walks.  Absorbing (round 4): one candidate per chain and line, the exact pass scans the rest of the candidate's
       chunk (~145 columns, lanes of very different lengths).  Restart (round 5): every part occurrence is a candidate (about twice as many), the exact
       pass scans m + tau either side of each (~2 (m + tau) columns, all lanes alike); its warm-up remembers acceptances (2 VALU per warm-up byte and
       chain).  The restart table pays where the exact pass is the larger part of the scan: filters that flag more than ~1 position in 20 KB. */
-   p.ll_restart = p.ll_filter && !kn.no_window && au.sdfa_pacc > 0.00005;      /* (SEEQ_NO_WINDOW=1: the absorbing table, A/B and tests) */
+   p.ll_restart = (p.ll_filter && !kn.no_window && au.sdfa_pacc > 0.00005) || p.pair_ll;      /* (SEEQ_NO_WINDOW=1: the absorbing table, A/B and tests; k_pair's automata are restart automata) */
    p.walk_ext = p.ll_filter ? (uint32_t)(in.wlen + in.tau + 2) : 0u;
    p.skip_thr = (p.use_fused && p.use_stream && !p.use_pair && !p.use_myers && p.stream_sub == 2 && au.sdfa_parts == 1) ? (uint32_t)(in.wlen - in.tau) : 0u;
    p.lead_best = want == PLAN_WANT_RECORDS && match_opt == PLAN_SQ_BEST;      /* (one record per line: the groups' best hits are reduced per line) */
@@ -201,7 +207,7 @@ static inline void seeq_plan_print(FILE *f, const PlanIn &in, const PlanAutomata
               "automata: stream %s (parts %d, warm %d, p_acc %.2g), pair %s (warm %d, p_acc %.2g) | "
               "post-pass: %s, %s%s%s, skip_back %u%s\n",
            in.wlen, in.tau, (unsigned)in.options, in.want, in.avg_line, in.line_hint > 0 ? " (hint)" : "",
-           kname[p.path & 7], p.filter ? " [candidates: filter / prefix]" : "", p.stream_ll ? " [long lines]" : "", p.ll_restart ? " [filter on long lines, restart table]" : p.ll_filter ? " [filter on long lines]" : "",
+           kname[p.path & 7], p.filter ? " [candidates: filter / prefix]" : "", p.pair_ll ? " [long lines: LL variant, windows of the restart walk]" : p.stream_ll ? " [long lines]" : "", p.ll_restart ? " [filter on long lines, restart table]" : p.ll_filter ? " [filter on long lines]" : "",
            p.rc == -2 ? " [multi: not k_pair's -- a scan per pattern]" : "",
            p.fw, 4 * p.stream_wu, p.stream_sub,
            au.sdfa_state == 1 ? "yes" : au.sdfa_state == 0 ? "not asked" : "none", au.sdfa_parts, au.sdfa_warm, au.sdfa_pacc,

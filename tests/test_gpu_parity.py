@@ -1387,7 +1387,7 @@ def test_stream_fuzz_long_lines(gpu, capi, oracle, seg, monkeypatch):
         expa = oracle.buffer_scan(pattern, tau, buf, SQ_ALL, fasta=fasta)
         c2 = _scan(capi, pattern, tau, buf, 0, dev.WANT_COUNTMATCH, fasta)
         assert c2["nhits"] == len(expa["records"]) and c2["nmatchlines"] == expa["nmatchlines"], (it, pattern, tau)
-    assert seen.get("k_stream", 0) + seen.get("k_myers", 0) >= 24, seen
+    assert seen.get("k_stream", 0) + seen.get("k_myers", 0) + seen.get("k_pair", 0) >= 24 and seen.get("k_forward", 0) + seen.get("k_direct", 0) <= 12, seen      # (the long-line plans: round 5, k_pair's LL variant among them)
 
 
 def test_long_string_match(gpu, capi, oracle):
@@ -1776,14 +1776,15 @@ def test_published_sweep_cells_small(gpu, capi, oracle, m, k):
     got = sc.scan_host(pat, buf, SQ_ALL, dev.WANT_RECORDS)
     # (20, 3): the complete automaton; cells whose partition filter makes fewer than ~3 candidates per KB (round 4: the filter on
     # long lines, the window walk running on m + k + 2 columns behind a candidate's chunk); the rest: k_stream's Myers mode
-    if (m, k) == (20, 3):
-        assert sc.last_kernel() == "k_stream" and not sc.last_filter()
-    elif (m, k) in ((42, 8), (27, 4), (34, 6)):
+    # (round 5: where the pattern's pair automaton is selective enough, k_pair's long-line variant -- its candidates verified by the window walk)
+    if (m, k) in ((20, 3), (27, 4), (34, 6)):
+        assert sc.last_kernel() == "k_pair" and sc.last_filter(), (sc.last_kernel(), sc.last_filter())
+    elif (m, k) == (42, 8):
         assert sc.last_kernel() == "k_stream" and sc.last_filter(), (sc.last_kernel(), sc.last_filter())
     elif (m, k) in ((42, 15), (34, 10), (27, 8)):
         assert sc.last_kernel() == "k_myers", sc.last_kernel()
     else:
-        assert sc.last_kernel() in ("k_stream", "k_myers")
+        assert sc.last_kernel() in ("k_pair", "k_stream", "k_myers")
     assert got["nlines"] == exp["nlines"] == 6 and got["nmatchlines"] == exp["nmatchlines"]
     assert np.array_equal(got["records"].astype(np.uint64), exp["records"]), (m, k)
     expb = oracle.buffer_scan(pattern, k, buf, SQ_BEST)

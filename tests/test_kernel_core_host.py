@@ -588,21 +588,31 @@ def test_scan_plans_of_the_baseline_configurations(harness):
     p = plan(head, 3, SQ_BEST | FASTA, RECORDS, 79.0, flags=16)
     assert (p["path"], p["use_pair"]) == (5, 0), p
     # the published sweep (chromosome lines): complete automaton / partition filter on long lines / Myers mode
-    p = plan(head, 3, SQ_ALL, RECORDS, 1.3e8)
-    assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"], p["verify"], p["order2"]) == (5, 1, 0, 0, 1, 0, 0), p
+    # (round 5: where the pair automaton is selective enough k_pair's long-line variant walks, its candidates go through the window walk -- ll_filter 2:
+    #  windows of the restart walk; forced onto k_stream the plans of round 4 stay: the complete automaton, the filters' absorbing / restart tables)
     full = "GATGTAGCGCGATTAGCCTGAAAATGCGAGTACGGCGCGAAT"
-    p = plan(full[:27], 3, SQ_ALL, RECORDS, 1.3e8)          # a selective filter: the absorbing table
+    p = plan(head, 3, SQ_ALL, RECORDS, 1.3e8)
+    assert (p["path"], p["use_pair"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"], p["verify"], p["order2"], p["window_ok"]) == (6, 1, 1, 1, 2, 1, 0, 0, 0), p
+    p = plan(head, 3, SQ_ALL, RECORDS, 1.3e8, kernel=1)
+    assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"], p["verify"], p["order2"]) == (5, 1, 0, 0, 1, 0, 0), p
+    p = plan(full[:27], 3, SQ_ALL, RECORDS, 1.3e8, kernel=1)          # a selective filter: the absorbing table
     assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (5, 1, 1, 1, 1), p
-    p = plan(full[:27], 4, SQ_ALL, RECORDS, 1.3e8)          # round 5: filters that flag more than a position in 20 KB walk their restart table
+    p = plan(full[:27], 4, SQ_ALL, RECORDS, 1.3e8, kernel=1)          # filters that flag more than a position in 20 KB walk their restart table
     assert (p["path"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (5, 1, 1, 2, 1), p
     p = plan(full[:34], 7, SQ_ALL, RECORDS, 1.3e8)
+    assert (p["path"], p["fw"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (6, 2, 1, 1, 2, 1), p
+    p = plan(full[:34], 7, SQ_ALL, RECORDS, 1.3e8, kernel=1)
     assert (p["path"], p["fw"], p["stream_ll"], p["filter"], p["ll_filter"], p["leaders"]) == (5, 2, 1, 1, 2, 1), p
+    p = plan(full, 8, SQ_ALL, RECORDS, 1.3e8)                          # (its pair automaton flags 2.4 positions per KB: k_stream's filter, 0.035)
+    assert (p["path"], p["stream_ll"], p["filter"]) == (5, 1, 1), p
     p = plan(full, 15, SQ_ALL, RECORDS, 1.3e8)
     assert (p["path"], p["use_myers"], p["fw"], p["stream_ll"], p["filter"]) == (7, 1, 2, 1, 0), p
     # patterns beyond the two-word column, SQ_STREAM input: the generic path; a multi-pattern scan that is not k_pair's: a scan per pattern
     assert plan("ACGT" * 20, 4, 0, COUNTLINES, 151.0)["path"] == 1
     assert plan(head, 3, 0x10, COUNTLINES, 151.0)["path"] in (1, 3)
     assert plan(head, 3, SQ_IGNORE, COUNTLINES, 151.0, flags=32)["rc"] == -2
-    # a context that has met a line of a whole tile (force_ll) leaves k_pair for k_stream's long-line variant
+    # a context that has met a line of a whole tile (force_ll) goes to the long-line variants: k_pair's own (round 5), k_stream's under SQ_IGNORE
     p = plan(head, 3, SQ_BEST, RECORDS, 151.0, flags=1)
-    assert (p["path"], p["use_pair"], p["stream_ll"]) == (5, 0, 1), p
+    assert (p["path"], p["use_pair"], p["stream_ll"], p["window_ok"], p["order2"]) == (6, 1, 1, 0, 0), p
+    p = plan(head, 3, SQ_BEST | SQ_IGNORE, RECORDS, 151.0, flags=1)
+    assert (p["use_pair"], p["stream_ll"]) == (0, 1) or p["path"] in (1, 3), p
