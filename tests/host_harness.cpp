@@ -181,6 +181,40 @@ extern "C" long harness_dfa_filter(const uint8_t *text, size_t n, const char *ke
    return (long)ne;
 }
 
+// The long-line filter's RESTART table (seeq_dfa_restart_variant; k_stream<.., LL> with FusedArgs.ll_filter == 2): the kernel's decomposition
+// on the host -- every `chain`-byte chain (64 in the kernel) is walked on its own from the root after a warm-up over the `warm_bytes` bytes before
+// it; a step that lands on ACC_NEW inside the chain reports its position, and a chain that landed on it inside its warm-up window reports its own
+// first byte (it is out of step with the walk the line's start would have made).  Returns the number of events, -1 when no filter fits.
+extern "C" long harness_dfa_filter_restart(const uint8_t *text, size_t n, const char *keys, int m, int tau, int parts, int chain, int warm_bytes,
+                                           uint64_t *out, size_t cap, uint32_t *info)
+{
+   seeq_dfa_t *d = parts >= 2 ? seeq_dfa_build_filter(keys, m, tau, parts) : seeq_dfa_plan_stream(keys, m, tau, 0);
+   if (!d) return -1;
+   if (d->nparts < 2) { seeq_dfa_free(d); return -1; }
+   uint16_t *t = seeq_dfa_restart_variant(d);
+   if (!t) { seeq_dfa_free(d); return -1; }
+   if (info) { info[0] = d->nstates; info[1] = (uint32_t)d->nparts; info[2] = (uint32_t)d->warm; info[3] = (uint32_t)(d->p_accept * 1e9); }
+   const int warm = warm_bytes > 0 ? warm_bytes : ((d->warm + 3) & ~3);
+   size_t ne = 0;
+   for (size_t c0 = 0; c0 < n; c0 += (size_t)chain) {
+      uint32_t state = 0;
+      bool seen = false;
+      for (long long p = (long long)c0 - warm; p < (long long)c0 + chain && p < (long long)n; p++) {
+         const uint8_t b = p < 0 ? (uint8_t)'\n' : text[p];
+         state = t[(state ^ (uint32_t)(b & 0xE)) >> 1];
+         const bool acc = state == d->acc_final;
+         if (p < (long long)c0) { seen = seen || acc; continue; }
+         if (acc || (seen && p == (long long)c0)) {
+            if (ne < cap) out[ne] = (uint64_t)p;
+            ne++;
+         }
+      }
+   }
+   free(t);
+   seeq_dfa_free(d);
+   return (long)ne;
+}
+
 // ---- the pair automaton of k_pair (seeq_dfa.h section 3, seeq_pair.h) ----
 // Emulates the kernel's decomposition on the host: every `chain`-byte chain of the text (64 in the kernel) is walked on
 // its own from the root state, two bytes per step (2-bit codes = bits 1-2 of the byte), after a warm-up over the

@@ -227,6 +227,66 @@ def test_filter_automaton_is_a_superset(harness, oracle):
     assert seen_filter >= 8
 
 
+def test_restart_table_names_every_occurrence_on_long_lines(harness, oracle):
+    """Round 5, the long-line filter's restart table (seeq_dfa_restart_variant) under the kernel's chunked walk: EVERY occurrence the oracle
+    reports on a long line (SQ_ALL records) holds a candidate -- a position s <= c <= e -- so that the exact pass may scan m + tau either side
+    of a candidate and nothing else (seeq_exact1.h, ScanArgs.ll_restart).  The absorbing table of round 4 does not have the property (one
+    candidate per chain and line): checked too, so that the test would notice if it were handed the wrong table."""
+    import ctypes as C
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    harness.harness_dfa_filter_restart.restype = C.c_long
+    harness.harness_dfa_filter_restart.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    harness.harness_dfa_filter.restype = C.c_long
+    harness.harness_dfa_filter.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    rng = random.Random(505)
+    full = "GATGTAGCGCGATTAGCCTGAAAATGCGAGTACGGCGCGAAT"
+    cases = [(full[:34], 6, 0), (full[:34], 8, 0), (full[:27], 4, 0), (full[:27], 5, 0), (full, 8, 0), ("GATGTAGCGCGATTAGCCTGAAAA", 3, 0),
+             ("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5, 0), (full[:34], 6, 2), (full[:30], 5, 3)]
+    checked = absorbing_misses = 0
+    for pat, tau, parts in cases:
+        keys, _ = oracle.parse(pat)
+        m = len(keys)
+        core = plain(pat)
+        lines = []
+        for _ in range(3):                                  # long lines with copies all over: clean hits, near misses, tandem copies
+            n = rng.choice([20000, 40000])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            q = rng.randrange(0, 300)
+            while q + 2 * m + 20 < n:
+                cp = mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
+                t[q:q + len(cp)] = list(cp)
+                if rng.random() < 0.2:                      # a tandem copy right behind
+                    cp2 = mutate(rng, core.replace("N", "A"), rng.randint(0, tau))
+                    t[q + len(cp):q + len(cp) + len(cp2)] = list(cp2)
+                q += rng.choice([m + 3, 150, 400, 1000])
+            lines.append("".join(t[:n]))
+        buf = ("\n".join(lines) + "\n").encode()
+        starts = np.cumsum([0] + [len(x) + 1 for x in lines])
+        rec = oracle.buffer_scan(pat, tau, buf, SQ_ALL)["records"]
+        assert len(rec) > 50
+        occ = [(int(starts[int(l) - 1]) + int(s_), int(starts[int(l) - 1]) + int(e) - 1) for l, s_, e, _d in rec.tolist()]     # absolute [s, e]
+        for chain in (64, 128):
+            out = np.zeros(1 << 18, dtype=np.uint64)
+            info = (C.c_uint32 * 4)()
+            ne = harness.harness_dfa_filter_restart(buf, len(buf), bytes(keys), m, tau, parts, chain, 0, out.ctypes.data, out.size, info)
+            if ne < 0:
+                continue
+            cand = np.sort(out[:ne].astype(np.int64))
+            for s_, e in occ:
+                k = int(np.searchsorted(cand, s_, side="left"))
+                assert k < len(cand) and cand[k] <= e, (pat, tau, parts, chain, s_, e, cand[max(0, k - 1):k + 2].tolist())
+                checked += 1
+            ne2 = harness.harness_dfa_filter(buf, len(buf), bytes(keys), m, tau, parts, chain, out.ctypes.data, out.size, info)
+            cand2 = np.sort(out[:max(ne2, 0)].astype(np.int64))
+            for s_, e in occ:
+                k = int(np.searchsorted(cand2, s_, side="left"))
+                absorbing_misses += not (k < len(cand2) and cand2[k] <= e)
+    assert checked > 2000 and absorbing_misses > 100, (checked, absorbing_misses)
+
+
 def _pair_events(harness, buf, keys, m, tau, chain=64, warm=0):
     import ctypes as C
     harness.harness_pair_walk.restype = C.c_long
@@ -313,6 +373,47 @@ def test_pair_automaton_is_a_superset_and_its_first_candidate_bounds_the_scan(ha
         if (pat, tau) == ("GATGTAGCGCGATTAGCCTG", 3):
             assert info[2] == 17 and info[1] == 1839, info
     assert nwalked >= 40
+
+
+def test_pair_automaton_names_every_occurrence_on_long_lines(harness, oracle):
+    """Round 5, k_pair's long-line variant: with every flag of a chain kept, EVERY occurrence the oracle reports on a long line holds a
+    candidate or ends on the byte before one (s <= c <= e + 1: a candidate is the second byte of a pair) -- what the window walk's
+    m + tau + 1 columns either side of a candidate rest on (seeq_pair.h LL, seeq_exact1.h ll_restart)."""
+    sys.path.insert(0, GOLDEN)
+    from make_golden import mutate, plain
+    rng = random.Random(506)
+    full = "GATGTAGCGCGATTAGCCTGAAAATGCGAGTACGGCGCGAAT"
+    checked = 0
+    for pat, tau in ((full[:20], 3), (full[:27], 3), (full[:27], 5), (full[:34], 5), (full[:34], 7), ("GATG[TA]AGCNCGATTAGC[CG]TGAAAATGNGAGTAC[GAT]GCGCGA", 5)):
+        keys, _ = oracle.parse(pat)
+        m = len(keys)
+        core = plain(pat)
+        lines = []
+        for _ in range(3):
+            n = rng.choice([20000, 40000])
+            t = [rng.choice("ACGT") for _ in range(n)]
+            q = rng.randrange(0, 300)
+            while q + 2 * m + 20 < n:
+                cp = mutate(rng, core.replace("N", "A"), rng.randint(0, tau + 2))
+                t[q:q + len(cp)] = list(cp)
+                if rng.random() < 0.2:
+                    cp2 = mutate(rng, core.replace("N", "A"), rng.randint(0, tau))
+                    t[q + len(cp):q + len(cp) + len(cp2)] = list(cp2)
+                q += rng.choice([m + 3, 150, 400, 1000])
+            lines.append("".join(t[:n]))
+        buf = ("\n".join(lines) + "\n").encode()
+        starts = np.cumsum([0] + [len(x) + 1 for x in lines])
+        rec = oracle.buffer_scan(pat, tau, buf, SQ_ALL)["records"]
+        assert len(rec) > 50
+        ne, ev, info = _pair_events(harness, buf, keys, m, tau)
+        assert ne > 0, (pat, tau)
+        cand = np.sort(ev.astype(np.int64))
+        for l, s_, e, _d in rec.tolist():
+            a, b = int(starts[int(l) - 1]) + int(s_), int(starts[int(l) - 1]) + int(e) - 1      # the occurrence, absolute [a, b]
+            k = int(np.searchsorted(cand, a, side="left"))
+            assert k < len(cand) and cand[k] <= b + 1, (pat, tau, a, b, cand[max(0, k - 1):k + 2].tolist())
+            checked += 1
+    assert checked > 1500, checked
 
 
 def test_quad_automaton_flags_every_hit_read_and_bounds_its_window(harness, oracle):
