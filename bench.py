@@ -747,7 +747,7 @@ def timed_steps(ctx, sc, pat, text_ptr, nbytes, opt, want, steps, barrier):
 
 
 def run_workload(ctx, name, n, steps, warmup, candidates, first_steps, check_lines, check_mode, keep):
-    """One workload of WORKLOADS at `n` reads per rank: the text in a buffer from the PRODUCT's allocator (seeqdevTextAllocInfo through
+    """One workload of WORKLOADS at `n` reads per rank: the text in a buffer from the PRODUCT's allocator (seeqdevTextAllocFor through
     dev.TextBuffer: `candidates` probed, the fastest kept), `steps` timed steps, the checks outside the timed region.  Before that, when
     candidates > 1, the same text in a plain first allocation (what a caller that hipMallocs once gets) for `first_steps` timed steps:
     `first_allocation`.  Returns the section of the bench line; with `keep` also the live objects (text, scanner, pattern, records)."""
@@ -790,7 +790,8 @@ def run_workload(ctx, name, n, steps, warmup, candidates, first_steps, check_lin
                        "scan_launch_ms": round(a0["fwd_ms"] / max(1, a0["launches"]), 4), "scan_launch_ms_full_segments": stats3(full0),
                        "what": "the same text in a plain hipMalloc (seeqdevTextAlloc with one candidate), this rank only"}
         tb0.free()
-    tb = dev.TextBuffer(nbytes, 1 if args.dry_run else candidates)
+    # (the candidates are probed with THIS scan context, reserved above: the launch time is a property of the pair text buffer / workspace)
+    tb = dev.TextBuffer(nbytes, 1 if args.dry_run else candidates, scanner=sc)
     text = tb.tensor(ctx.device)
     if not args.dry_run:
         synth(tb.ptr)
@@ -804,7 +805,7 @@ def run_workload(ctx, name, n, steps, warmup, candidates, first_steps, check_lin
         hbm["note"] = ("one rank's allocations (text + scan workspace reserved for its segments + record buffers), measured with hipMemGetInfo "
                        "around them; every rank of a multi-GPU run holds the same")
         return {"dry_run": True, "workload": wl[5] % n, "hbm_per_rank": hbm}, None
-    placement = {"api": "seeqdevTextAllocInfo", "candidates": candidates, "probed": len(tb.probe_ms), "chosen": tb.chosen,
+    placement = {"api": "seeqdevTextAllocFor", "candidates": candidates, "probed": len(tb.probe_ms), "chosen": tb.chosen,
                  "probe_forward_ms": [round(x, 3) for x in tb.probe_ms], "allocated_bytes": tb.allocated_bytes, "selected": len(tb.probe_ms) > 1}
 
     for _ in range(warmup):
@@ -946,7 +947,7 @@ def main():
                     help="allocate ONE rank's text, workspace and record buffers, print what it needs of the GPU's memory "
                          "(per rank of --gpus N: every rank holds the same) and exit -- no scan, no launcher")
     ap.add_argument("--placement-candidates", type=int, default=12,
-                    help="candidates the PRODUCT's allocator (seeqdevTextAllocInfo) probes for the resident text: the plain allocation, then power-of-two "
+                    help="candidates the PRODUCT's allocator (seeqdevTextAllocFor) probes for the resident text: the plain allocation, then power-of-two "
                          "blocks; the fastest is kept (k_pair's launch time follows the physical pages a buffer gets: DESIGN.md section 5).  The plain "
                          "first allocation's figure is reported beside `value` as `first_allocation`; 1 = the plain allocation only; capped at 4 per rank "
                          "under --gpus N > 1")

@@ -158,6 +158,12 @@ typedef struct seeqdev_textinfo {
    size_t probe_peak_bytes;    /* device memory held at the peak of the call */
 } seeqdev_textinfo_t;
 void * seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_textinfo_t * info);
+/* The same with the candidates probed by the CALLER's scan context.  The scan kernel's time is a property of the pair (text buffer, scan context's
+ * workspace): one text runs at 0.72 or at 0.84 ms per 3.75 GiB with two contexts of one process, reproducibly (profiles/r05/workspace_probe.txt) --
+ * so the candidate that is fastest with a context made for the probe need not be the fastest with the context that will scan the text.  `scan`: the
+ * context that will (seeqdevScanReserve it first, so that its workspace is the one that stays); NULL: as seeqdevTextAllocInfo.  The context's
+ * last results are those of the probe's last scan. */
+void * seeqdevTextAllocFor(seeqdev_scan_t * scan, size_t bytes, int candidates, seeqdev_textinfo_t * info);
 void   seeqdevTextFree(void * d_text);
 
 /* Convenience: host buffer in, counts (+ records) out.  Stages through the

@@ -70,7 +70,7 @@ EXPORTS = [
     "seeqdevPatternOf", "seeqdevScanNew", "seeqdevScanFree", "seeqdevScanReserve", "seeqdevScanRun",
     "seeqdevScanFetch", "seeqdevScanRecordsDevice", "seeqdevScanCopyRecords", "seeqdevScanHost",
     "seeqdevScanSetProfiling", "seeqdevScanLastTimes", "seeqdevScanLastLaunches", "seeqdevScanLastLaunchTimes", "seeqdevScanLastClockMHz", "seeqdevSynthReads",
-    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanLastPackedQuad", "seeqdevScanCopyOffsets", "seeqdevHostAlloc", "seeqdevTextAlloc", "seeqdevTextAllocInfo", "seeqdevTextFree",
+    "seeqdevScanSetLineHint", "seeqdevScanLastPath", "seeqdevScanLastFilter", "seeqdevScanLastPackedQuad", "seeqdevScanCopyOffsets", "seeqdevHostAlloc", "seeqdevTextAlloc", "seeqdevTextAllocInfo", "seeqdevTextAllocFor", "seeqdevTextFree",
     "seeqdevHostFree", "seeqdevStringMatch", "seeqdevScanHostBegin", "seeqdevScanLastCopyMs", "seeqdevPatternDevice",
     "seeqdevScanRunMulti", "seeqdevScanHostMulti", "seeqdevScanMultiRecords", "seeqdevScanLastMulti", "seeqdevScanPacked", "seeqdevPackReads", "seeqdevPackReadsDevice",
 ]
@@ -208,6 +208,8 @@ def lib():
     L.seeqdevTextAlloc.restype = C.c_void_p
     L.seeqdevTextAllocInfo.argtypes = [C.c_size_t, C.c_int, C.POINTER(seeqdev_textinfo_t)]
     L.seeqdevTextAllocInfo.restype = C.c_void_p
+    L.seeqdevTextAllocFor.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(seeqdev_textinfo_t)]
+    L.seeqdevTextAllocFor.restype = C.c_void_p
     L.seeqdevTextFree.argtypes = [C.c_void_p]
     L.seeqdevTextFree.restype = None
     L.seeqdevSynthReads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int,

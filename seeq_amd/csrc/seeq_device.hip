@@ -2349,7 +2349,7 @@ extern "C" void seeqdevHostFree(void *p)
  * candidate allocations (the plain one, then blocks of p bytes, p = the power of two >= bytes), each filled with synthetic reads and
  * scanned twice with the benchmark pattern; the one whose scan kernel was fastest is returned, the
  * others are freed.  probe_ms (may be NULL): the candidates' scan-kernel times, *nprobed of them.  The buffer's contents are undefined. */
-extern "C" void *seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_textinfo_t *info)
+extern "C" void *seeqdevTextAllocFor(seeqdev_scan_t *scan, size_t bytes, int candidates, seeqdev_textinfo_t *info)
 {
    seeqerr = 0;
    if (info) memset(info, 0, sizeof *info);
@@ -2388,7 +2388,12 @@ extern "C" void *seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_text
       char keys[20];
       for (int i = 0; i < 20; i++) keys[i] = plain[i] == 'A' ? 1 : plain[i] == 'C' ? 2 : plain[i] == 'G' ? 4 : 8;
       seeqdev_pattern_t *pat = seeqdevPatternNew(keys, 20, 3);
-      sc = pat ? seeqdevScanNew(NULL) : NULL;
+      /* Round 5: the launch time is a property of the PAIR (text buffer, scan context's workspace) -- the same text runs at 0.72 or 0.84 ms with
+         two contexts of one process, reproducibly (profiles/r05/workspace_probe.txt) -- so a caller that scans the text with a context of its own
+         (`scan`: reserve it first, so that its workspace is the one that stays) has the candidates probed with THAT context; NULL: a context made here. */
+      sc = pat ? (scan ? scan : seeqdevScanNew(NULL)) : NULL;
+      const bool own_sc = scan == nullptr;
+      const bool prof_was = sc ? sc->prof : false;
       const uint64_t nreads = bytes / 151;
       bool ok = pat && sc && nreads > 0 && seeqdevScanSetProfiling(sc, 1) == 0;
       for (int i = 0; ok && i < n; i++) {
@@ -2401,7 +2406,8 @@ extern "C" void *seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_text
          if (ok) ok = seeqdevScanLastTimes(sc, t) == 0;
          ms[i] = t[1];
       }
-      if (sc) seeqdevScanFree(sc);
+      if (sc && own_sc) seeqdevScanFree(sc);
+      else if (sc) (void)seeqdevScanSetProfiling(sc, prof_was ? 1 : 0);
       if (pat) seeqdevPatternFree(pat);
       if (ok) {
          for (int i = 1; i < n; i++) if (ms[i] < ms[best]) best = i;
@@ -2413,6 +2419,8 @@ extern "C" void *seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_text
    if (info) { info->chosen = best; info->allocated_bytes = blk_bytes[best]; info->probe_peak_bytes = n > 1 ? peak + headroom : peak; }
    return blk[best];
 }
+
+extern "C" void *seeqdevTextAllocInfo(size_t bytes, int candidates, seeqdev_textinfo_t *info) { return seeqdevTextAllocFor(NULL, bytes, candidates, info); }
 
 extern "C" void *seeqdevTextAlloc(size_t bytes, int candidates, float *probe_ms, int *nprobed)
 {

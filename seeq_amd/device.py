@@ -44,9 +44,14 @@ class TextBuffer:
     call held on the device at its peak.  Contents undefined; free() or the garbage collector releases it.  `tensor()`: a torch uint8
     view of the first `nbytes` bytes (plumbing for callers that slice / copy with torch; the buffer must outlive the view)."""
 
-    def __init__(self, nbytes, candidates=12):
+    def __init__(self, nbytes, candidates=12, scanner=None):
+        """scanner: the Scanner that will scan the text (seeqdevTextAllocFor: the candidates are probed with ITS workspace -- reserve() it first);
+        None: a context made for the probe."""
         info = _capi.seeqdev_textinfo_t()
-        p = _capi.lib().seeqdevTextAllocInfo(int(nbytes), int(candidates), C.byref(info))
+        if scanner is not None:
+            p = _capi.lib().seeqdevTextAllocFor(scanner._h, int(nbytes), int(candidates), C.byref(info))
+        else:
+            p = _capi.lib().seeqdevTextAllocInfo(int(nbytes), int(candidates), C.byref(info))
         if not p:
             raise SeeqDeviceError(_capi.error_text())
         self.ptr, self.nbytes = int(p), int(nbytes)

@@ -342,6 +342,17 @@ def test_text_alloc_picks_a_buffer_by_measurement(gpu, capi):
     sc.run(pat, buf.ptr, nb, SQ_BEST, dev.WANT_RECORDS)
     b = sc.fetch(); rb = sc.records(b["nrecords"])
     assert a == b and a["nmatchlines"] > n // 50 and np.array_equal(ra, rb)
+    # seeqdevTextAllocFor (round 5): the candidates probed with the caller's own scan context -- the launch time is a property of the pair
+    # text buffer / workspace -- which stays usable, profiling as it was, and scans the chosen buffer like any other
+    sc.set_profiling(False)
+    mine = dev.TextBuffer(nb, candidates=3, scanner=sc)
+    assert mine.ptr and len(mine.probe_ms) == 3 and all(t > 0 for t in mine.probe_ms) and mine.probe_ms[mine.chosen] == min(mine.probe_ms)
+    dev.synth_reads(mine.ptr, 0, n, L, pattern, tau, stream=stream)
+    torch.cuda.synchronize()
+    sc.run(pat, mine.ptr, nb, SQ_BEST, dev.WANT_RECORDS)
+    c = sc.fetch(); rc_ = sc.records(c["nrecords"])
+    assert a == c and np.array_equal(ra, rc_)
+    mine.free()
     sc.close(); pat.close()
     buf.free()
     small = dev.TextBuffer(1 << 20, candidates=8)

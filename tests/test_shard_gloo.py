@@ -200,7 +200,7 @@ def test_bench_launches_its_own_ranks(gpu):
 
 @pytest.mark.gpu
 def test_bench_default_line_sections_at_small_sizes(gpu):
-    """The sections of the default `bench.py` line, shrunk: the headline (text from seeqdevTextAllocInfo, `first_allocation` beside it), the
+    """The sections of the default `bench.py` line, shrunk: the headline (text from seeqdevTextAllocFor, `first_allocation` beside it), the
     FASTQ shape (k_pair under SQ_FAIL / SQ_CONVERT since round 5, counts = the reference binary's, prefix records = the oracle's) and
     BASELINE configs[4] as a section with its own roofline and full check; `results` and `roofline` close the line."""
     import json
@@ -291,10 +291,10 @@ def test_two_real_segments_full_size_parity(gpu, workload, reads):
     assert line["results"]["lines"] == reads and chk["result"] == "bit-exact"
     assert chk["oracle_lines_checked"] >= 1_000_000 and chk["segment_seams_checked"] >= 1
     assert line["roofline"]["launches_per_step"] >= 2
-    # the text lies in a buffer from the PRODUCT's allocator (seeqdevTextAllocInfo: several candidates probed, the fastest kept, DESIGN.md
+    # the text lies in a buffer from the PRODUCT's allocator (seeqdevTextAllocFor: several candidates probed with the run's own scan context, the fastest kept, DESIGN.md
     # section 5), and the same text in a plain first allocation was timed beside it
     pl = line["placement"]
-    assert pl["api"] == "seeqdevTextAllocInfo" and pl["probed"] >= 2 and pl["selected"] and pl["allocated_bytes"] >= reads * (151 if workload == "best" else 251)
+    assert pl["api"] == "seeqdevTextAllocFor" and pl["probed"] >= 2 and pl["selected"] and pl["allocated_bytes"] >= reads * (151 if workload == "best" else 251)
     assert pl["probe_forward_ms"][pl["chosen"]] == min(pl["probe_forward_ms"])
     fa = line["first_allocation"]
     assert fa["steps"] == 2 and fa["value"] > 0 and fa["scan_launch_ms"] > 0
