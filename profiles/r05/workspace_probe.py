@@ -29,7 +29,11 @@ for rnd in range(2):
         for sc in scs:
             fwd = launches = 0.0
             for it in range(5):
-                sc.run(pat, x.data_ptr(), x.numel(), dev.SQ_BEST, dev.WANT_RECORDS); sc.fetch()
+                sc.run(pat, x.data_ptr(), x.numel(), dev.SQ_BEST, dev.WANT_RECORDS)
+                try:
+                    sc.fetch()
+                except Exception:          # (an experiment library with void results may trip the library's own checks)
+                    pass
                 if it >= 2:
                     tm = sc.last_times_ms(); fwd += tm["forward"]; launches += tm["forward_launches"]
             row.append(round(fwd / launches, 4))
